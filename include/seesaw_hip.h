@@ -1,0 +1,144 @@
+/*
+ * seesaw_hip.h -- C-ABI of libseesaw_hip.so, the MI355X (gfx950) hot path behind
+ * seesaw's Python API surface.
+ *
+ * The reference (orm011/seesaw) has no FFI: its boundary is a duck-typed Python
+ * interface whose numeric work is delegated to numpy / scipy / torch-CPU.  Every
+ * entry point below replaces one of those numeric call sites; the reference
+ * file:line each one stands in for is cited next to it (paths relative to the
+ * reference root).  The Python mirror of the reference interface that binds
+ * these symbols lives in seesaw_amd/ (see INTEGRATION.md for the ctypes stub a
+ * reference maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types cross this boundary;
+ *   - every function returns ssw_status: 0 = OK, <0 = error, and the failing
+ *     thread can read a message with ssw_last_error();
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP device
+ *     memory on the handle's device (e.g. torch.Tensor.data_ptr());
+ *   - a handle is bound to one device and one HIP stream and is NOT thread-safe:
+ *     the same serial-per-session model the reference uses
+ *     (seesaw/web/web_session_actor.py:13-16);
+ *   - functions with a host-side result synchronise the handle's stream before
+ *     returning; the *_dev / *_async forms only enqueue work.
+ */
+#ifndef SEESAW_HIP_H
+#define SEESAW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t ssw_status;
+#define SSW_OK 0
+#define SSW_ERR_INVALID (-1)     /* bad argument                                  */
+#define SSW_ERR_HIP (-2)         /* a HIP runtime call failed                     */
+#define SSW_ERR_NOMEM (-3)       /* device or host allocation failed              */
+#define SSW_ERR_UNSUPPORTED (-4) /* shape / size outside what the kernels support */
+#define SSW_ERR_NUMERIC (-5)     /* NaN / bound violation the reference asserts on */
+
+#define SSW_ABI_VERSION 1
+#define SSW_MAX_TOPK 4096        /* largest k ssw_index_topk accepts               */
+
+int32_t ssw_abi_version(void);
+const char *ssw_last_error(void);
+ssw_status ssw_device_count(int32_t *out_count);
+/* name / CU count / HBM bytes of a device, for bench reports. name_cap >= 64. */
+ssw_status ssw_device_info(int32_t device, char *name, int32_t name_cap, int32_t *out_cus,
+                           int64_t *out_hbm_bytes);
+
+/* ------------------------------------------------------------------------- */
+/* Vector index: resident [N, d] f32 matrix + brute-force cosine scan + top-k */
+/* replaces: vectors @ q ; np.argsort(-scores)                                */
+/*   seesaw/indices/multiscale/multiscale_index.py:170-175 (_get_top_exact)   */
+/*   seesaw/indices/multiscale/multiscale_index.py:177-199 (_get_top_dbidxs)  */
+/*   seesaw/indices/coarse/coarse_index.py:57-96 (CoarseIndex.query)          */
+/*   seesaw/vector_index.py:44-60 (VectorIndex.query)                         */
+/* ------------------------------------------------------------------------- */
+typedef struct ssw_index ssw_index;
+
+/* dev_vectors_or_null: borrow an existing device matrix (row-major, 16-byte
+ * aligned, must outlive the handle); NULL -> the handle allocates n_rows*dim*4
+ * bytes itself.  dim must be a multiple of 256 and <= 1024 (CLIP: 512). */
+ssw_status ssw_index_create(int32_t device, int64_t n_rows, int32_t dim,
+                            const float *dev_vectors_or_null, ssw_index **out);
+ssw_status ssw_index_destroy(ssw_index *idx);
+/* run all of this handle's work on an existing hipStream_t (e.g. torch's current
+ * stream) instead of the handle's own stream. NULL restores the own stream. */
+ssw_status ssw_index_set_stream(ssw_index *idx, void *hip_stream);
+ssw_status ssw_index_sync(ssw_index *idx);
+ssw_status ssw_index_shape(const ssw_index *idx, int64_t *n_rows, int32_t *dim, int64_t *n_images);
+/* device pointers of the resident matrix and of the score buffer ([n_rows] f32,
+ * valid after the last scan). */
+ssw_status ssw_index_device_ptrs(ssw_index *idx, void **dev_vectors, void **dev_scores);
+
+/* copy rows [first_row, first_row+n) from host memory into the index. */
+ssw_status ssw_index_upload(ssw_index *idx, const float *host_rows, int64_t first_row, int64_t n);
+/* copy rows back (tests / subset()). */
+ssw_status ssw_index_download(ssw_index *idx, float *host_rows, int64_t first_row, int64_t n);
+/* fill the whole index on the device with the counter-based synthetic generator
+ * (unit-norm rows; bit-identical to oracle.synth_rows(seed, global_first_row+i)). */
+ssw_status ssw_index_fill_random(ssw_index *idx, uint64_t seed, int64_t global_first_row);
+
+/* row -> image map (vector_meta.dbidx of the reference, multiscale_index.py:192):
+ * host array [n_rows] int32, non-decreasing, values are *positions* 0..n_images-1 of
+ * the distinct images in ascending dbidx order.  NULL -> identity (one vector per
+ * image, CoarseIndex). */
+ssw_status ssw_index_set_row2image(ssw_index *idx, const int32_t *row2image_host, int64_t n_images);
+
+/* scores = vectors @ q   (index.score(): multiscale_index.py:284-285, coarse_index.py:37-38).
+ * Leaves the scores resident on the device; out_host may be NULL. */
+ssw_status ssw_index_scan(ssw_index *idx, const float *q_host, float *out_scores_host_or_null);
+/* same, q already on the device, nothing copied back, no synchronisation. */
+ssw_status ssw_index_scan_dev(ssw_index *idx, const float *q_dev);
+
+/* Top-k distinct images by their best-scoring row, skipping excluded images:
+ * _get_top_exact + _get_top_dbidxs (multiscale_index.py:170-199).  Order: score
+ * descending, ties by ascending image position.  q_host==NULL reuses the resident
+ * scores of the previous scan.  excluded = image positions (any order, may repeat).
+ * Outputs (host, capacity k): image position, its max score, the row that attains it
+ * (lowest row on ties).  *out_count = min(k, #non-excluded images). */
+ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *excluded_images,
+                          int64_t n_excluded, int32_t k, int64_t *out_images, float *out_scores,
+                          int64_t *out_best_rows, int32_t *out_count);
+/* device-resident form used by bench.py and the sharded index: q_dev [dim] f32;
+ * the excluded set is whatever the last ssw_index_set_excluded installed; results
+ * stay on the device in the handle's result buffers (ssw_index_result_ptrs).
+ * Enqueues only. */
+ssw_status ssw_index_set_excluded(ssw_index *idx, const int64_t *excluded_images, int64_t n_excluded);
+ssw_status ssw_index_topk_dev(ssw_index *idx, const float *q_dev, int32_t k);
+/* device result buffers of the last topk: keys [SSW_MAX_TOPK] u64 =
+ * (orderable(score) << 32) | (0xFFFFFFFF - image), sorted descending; count [1] i32;
+ * best_rows [SSW_MAX_TOPK] u32. */
+ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_count,
+                                 void **dev_best_rows);
+/* read the last device-side result back (synchronises). */
+ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, float *out_scores,
+                                int64_t *out_best_rows, int32_t *out_count);
+
+/* scores of arbitrary rows from the resident score buffer (stage-2 rescoring of
+ * the candidate images' tiles, multiscale_index.py:341-345). */
+ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
+                                   float *out_scores_host);
+
+/* merge several sorted key lists (e.g. the all-gathered per-shard top-k of a
+ * row-sharded index; keys as in ssw_index_result_ptrs but with GLOBAL image ids
+ * added by the caller via id_offsets) into the global top-k.  All pointers device. */
+ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *dev_keys_in,
+                              int32_t n_lists, int32_t list_stride, const int32_t *dev_counts,
+                              int32_t k, uint64_t *dev_keys_out, int32_t *dev_count_out);
+
+/* per-launch device time of the dominant (scan) kernel, measured with HIP events
+ * on the handle's stream.  enable=1 starts recording one event pair per scan
+ * launch (up to 4096 launches); ssw_index_profile_read synchronises and returns
+ * the durations in milliseconds. */
+ssw_status ssw_index_profile(ssw_index *idx, int32_t enable);
+ssw_status ssw_index_profile_read(ssw_index *idx, float *out_ms, int32_t cap, int32_t *out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEESAW_HIP_H */

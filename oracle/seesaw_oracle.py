@@ -1,0 +1,215 @@
+"""CPU ORACLE -- test infrastructure, never the product path.
+
+numpy / scipy / torch-CPU restatements of the reference's hot path, each citing the
+reference file:line it follows (paths relative to the reference root, orm011/seesaw).
+Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may
+import this module; nothing under ``seesaw_amd/`` does.
+
+Parity status: every function here is pinned against outputs of the reference itself
+(``tests/golden/*.npz``, produced in the build container by ``oracle/gen_golden.py``,
+which imports the reference from /root/reference) and against the reference's own
+known-answer tests where it has them (rank-loss table, distinct_topk_positions).
+CLIP is the exception: the reference holds no fixture for it and delegates the
+arithmetic to ``transformers`` -- see ``oracle/clip_oracle.py``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _cpu_has_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            return " fma " in f.read()
+    except OSError:
+        return False
+
+
+def build_c_oracle(force: bool = False) -> str:
+    """Compile oracle/ssw_oracle.c with gcc (rebuilds when the host's FMA support differs
+    from the machine the library was last built on)."""
+    out = os.path.join(_HERE, "_build", "libssw_oracle.so")
+    stamp = os.path.join(_HERE, "_build", f".fma_{int(_cpu_has_fma())}")
+    cmd = ["make", "-C", _HERE]
+    if force or not os.path.exists(stamp):
+        cmd.append("-B")
+    subprocess.run(cmd, check=True, capture_output=True)
+    for f in os.listdir(os.path.join(_HERE, "_build")):
+        if f.startswith(".fma_"):
+            os.remove(os.path.join(_HERE, "_build", f))
+    open(stamp, "w").close()
+    return out
+
+
+def c_lib():
+    global _LIB
+    if _LIB is None:
+        lib = ctypes.CDLL(build_c_oracle())
+        f32p = ctypes.POINTER(ctypes.c_float)
+        lib.ssw_oracle_scores_kernel_order.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int32, f32p]
+        lib.ssw_oracle_scores_kernel_order.restype = None
+        lib.ssw_oracle_scores_f64.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int32,
+                                              ctypes.POINTER(ctypes.c_double)]
+        lib.ssw_oracle_scores_f64.restype = None
+        lib.ssw_oracle_synth_rows.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_int32, f32p]
+        lib.ssw_oracle_synth_rows.restype = None
+        lib.ssw_oracle_topk_images.argtypes = [
+            f32p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64,
+            ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), f32p,
+            ctypes.POINTER(ctypes.c_int64)]
+        lib.ssw_oracle_topk_images.restype = ctypes.c_int64
+        _LIB = lib
+    return _LIB
+
+
+def _f32p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+# --------------------------------------------------------------------------------------
+# scan
+# --------------------------------------------------------------------------------------
+def scores_reference(vectors: np.ndarray, vector: np.ndarray) -> np.ndarray:
+    """`scores = vectors @ vector.reshape(-1)` -- multiscale_index.py:171 / :285,
+    coarse_index.py:38 (BLAS sgemv; summation order unspecified)."""
+    return vectors @ vector.reshape(-1)
+
+
+def scores_kernel_order(vectors: np.ndarray, vector: np.ndarray) -> np.ndarray:
+    """Same dot products in the fixed order of seesaw_amd/csrc/scan.hip (bit-exact twin)."""
+    X = np.ascontiguousarray(vectors, dtype=np.float32)
+    q = np.ascontiguousarray(vector.reshape(-1), dtype=np.float32)
+    assert X.shape[1] == q.shape[0] and X.shape[1] % 256 == 0
+    out = np.empty(X.shape[0], dtype=np.float32)
+    c_lib().ssw_oracle_scores_kernel_order(_f32p(X), _f32p(q), X.shape[0], X.shape[1], _f32p(out))
+    return out
+
+
+def scores_f64(vectors: np.ndarray, vector: np.ndarray) -> np.ndarray:
+    X = np.ascontiguousarray(vectors, dtype=np.float32)
+    q = np.ascontiguousarray(vector.reshape(-1), dtype=np.float32)
+    out = np.empty(X.shape[0], dtype=np.float64)
+    c_lib().ssw_oracle_scores_f64(_f32p(X), _f32p(q), X.shape[0], X.shape[1],
+                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return out
+
+
+def get_top_exact(vector: np.ndarray, *, vectors: np.ndarray):
+    """_get_top_exact -- multiscale_index.py:170-175: full descending argsort."""
+    scores = vectors @ vector.reshape(-1)
+    vec_idxs = np.argsort(-scores)
+    vec_scores = scores[vec_idxs]
+    return vec_idxs, vec_scores
+
+
+def distinct_topk_positions(dbidxs: np.ndarray, topk: int) -> np.ndarray:
+    """distinct_topk_positions -- multiscale_index.py:177-180."""
+    _, index = np.unique(dbidxs, return_index=True)
+    return np.sort(index)[:topk]
+
+
+def get_top_dbidxs(*, vec_idxs, scores, row_dbidx: np.ndarray, exclude, topk: int):
+    """_get_top_dbidxs -- multiscale_index.py:189-199 without the pandas wrapper:
+    map sorted rows to dbidx, drop excluded, keep first occurrence per image, cut at topk.
+    Returns (dbidx[<=topk], max_score[<=topk], row position of that max)."""
+    dbidx = row_dbidx[vec_idxs]
+    excl = np.fromiter(exclude, dtype=np.int64) if exclude is not None else np.zeros(0, np.int64)
+    mask = ~np.isin(dbidx, excl)
+    new_dbidx = dbidx[mask]
+    new_scores = scores[mask]
+    new_rows = np.asarray(vec_idxs)[mask]
+    pos = distinct_topk_positions(new_dbidx, topk=topk)
+    return new_dbidx[pos], new_scores[pos], new_rows[pos]
+
+
+def topk_images_reference(vectors, vector, row_dbidx, exclude, topk):
+    """_query_prelim(force_exact=True) -- multiscale_index.py:291-312."""
+    vec_idxs, vec_scores = get_top_exact(vector, vectors=vectors)
+    return get_top_dbidxs(vec_idxs=vec_idxs, scores=vec_scores, row_dbidx=row_dbidx,
+                          exclude=exclude, topk=topk)
+
+
+def topk_images_tiebreak(scores: np.ndarray, row2image, n_images: int, excluded_positions, k: int):
+    """The same selection with the HIP path's deterministic tie rule (score desc, image
+    position asc, row asc) applied to a GIVEN score vector -- C restatement."""
+    s = np.ascontiguousarray(scores, dtype=np.float32)
+    n = s.shape[0]
+    r2i = None
+    if row2image is not None:
+        r2i_arr = np.ascontiguousarray(row2image, dtype=np.int32)
+        r2i = r2i_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    mask = np.zeros(max(n_images, 1), dtype=np.uint8)
+    ex = np.asarray(list(excluded_positions) if excluded_positions is not None else [], dtype=np.int64)
+    if ex.size:
+        mask[ex] = 1
+    out_i = np.empty(k, dtype=np.int64)
+    out_s = np.empty(k, dtype=np.float32)
+    out_r = np.empty(k, dtype=np.int64)
+    cnt = c_lib().ssw_oracle_topk_images(
+        _f32p(s), n, r2i, n_images, mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), k,
+        out_i.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _f32p(out_s),
+        out_r.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+    return out_i[:cnt], out_s[:cnt], out_r[:cnt]
+
+
+def rounding_band(vectors: np.ndarray, vector: np.ndarray) -> float:
+    """Largest |f32 dot - exact dot| any summation order of `dim` products can reach
+    (standard gamma_n bound), used to decide which top-k boundaries are ambiguous
+    between two valid f32 orders (BLAS vs HIP kernel)."""
+    dim = vectors.shape[1]
+    eps = np.finfo(np.float32).eps
+    bound = float(dim) * eps * float(np.max(np.abs(vectors) @ np.abs(vector.reshape(-1))))
+    return 2.0 * bound
+
+
+def check_topk_against_reference(got_images, ref_scores_f32: np.ndarray, row2image, excluded_positions,
+                                 k: int, band: float):
+    """Set-parity rule (BASELINE.md section 3 / SURVEY section 7 'Hard parts'): the image
+    SET returned must equal the reference's set whenever the gap between the k-th and
+    (k+1)-th best image exceeds the rounding band; otherwise the symmetric difference
+    must lie entirely within the band around the k-th score.  Returns (ok, message)."""
+    n = ref_scores_f32.shape[0]
+    r2i = np.arange(n) if row2image is None else np.asarray(row2image)
+    n_img = int(r2i.max()) + 1 if n else 0
+    best = np.full(n_img, -np.inf, dtype=np.float64)
+    np.maximum.at(best, r2i, ref_scores_f32.astype(np.float64))
+    if excluded_positions is not None and len(excluded_positions):
+        best[np.asarray(list(excluded_positions), dtype=np.int64)] = -np.inf
+    order = np.argsort(-best, kind="stable")
+    valid = int(np.isfinite(best).sum())
+    kk = min(k, valid)
+    ref_set = set(order[:kk].tolist())
+    got_set = set(int(x) for x in got_images)
+    if len(got_set) != kk:
+        return False, f"expected {kk} images, got {len(got_set)}"
+    if ref_set == got_set:
+        return True, "exact"
+    kth = best[order[kk - 1]]
+    diff = ref_set ^ got_set
+    worst = max(abs(best[i] - kth) for i in diff)
+    if worst <= band:
+        return True, f"ambiguous boundary: {len(diff)} images within band {band:.3e}"
+    return False, f"set differs outside the rounding band: worst {worst:.3e} > {band:.3e}"
+
+
+# --------------------------------------------------------------------------------------
+# synthetic data (the benchmark's input generator; not part of the reference)
+# --------------------------------------------------------------------------------------
+def synth_rows(seed: int, first_row: int, n: int, dim: int = 512) -> np.ndarray:
+    """Bit-identical CPU twin of seesaw_amd/csrc/rng.hip."""
+    out = np.empty((n, dim), dtype=np.float32)
+    c_lib().ssw_oracle_synth_rows(ctypes.c_uint64(seed), first_row, n, dim, _f32p(out))
+    return out
+
+
+def synth_query(seed: int, dim: int = 512) -> np.ndarray:
+    """Unit-norm query drawn from the same generator (row `2**40 + seed` of stream 0xC0FFEE)."""
+    return synth_rows(0xC0FFEE, (1 << 40) + seed, 1, dim)[0]

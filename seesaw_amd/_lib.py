@@ -1,0 +1,108 @@
+"""ctypes binding of libseesaw_hip.so (the C-ABI declared in include/seesaw_hip.h).
+
+The HIP library is the product path: if it is missing or fails to load this module
+raises -- there is no CPU fallback anywhere in seesaw_amd.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libseesaw_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip.h")
+
+SSW_OK = 0
+SSW_MAX_TOPK = 4096
+
+
+class SeesawHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libseesaw_hip status {status}: {message}")
+        self.status = status
+
+
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_void_p = ctypes.c_void_p
+c_f32_p = ctypes.POINTER(ctypes.c_float)
+c_f64_p = ctypes.POINTER(ctypes.c_double)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+c_u64_p = ctypes.POINTER(ctypes.c_uint64)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes).  Must list every symbol include/seesaw_hip.h declares
+# (tests/test_abi.py checks the two against each other).
+_SIGNATURES = {
+    "ssw_abi_version": (c_i32, []),
+    "ssw_last_error": (ctypes.c_char_p, []),
+    "ssw_device_count": (c_i32, [c_i32_p]),
+    "ssw_device_info": (c_i32, [c_i32, ctypes.c_char_p, c_i32, c_i32_p, c_i64_p]),
+    "ssw_index_create": (c_i32, [c_i32, c_i64, c_i32, c_void_p, c_void_pp]),
+    "ssw_index_destroy": (c_i32, [c_void_p]),
+    "ssw_index_set_stream": (c_i32, [c_void_p, c_void_p]),
+    "ssw_index_sync": (c_i32, [c_void_p]),
+    "ssw_index_shape": (c_i32, [c_void_p, c_i64_p, c_i32_p, c_i64_p]),
+    "ssw_index_device_ptrs": (c_i32, [c_void_p, c_void_pp, c_void_pp]),
+    "ssw_index_upload": (c_i32, [c_void_p, c_void_p, c_i64, c_i64]),
+    "ssw_index_download": (c_i32, [c_void_p, c_void_p, c_i64, c_i64]),
+    "ssw_index_fill_random": (c_i32, [c_void_p, c_u64, c_i64]),
+    "ssw_index_set_row2image": (c_i32, [c_void_p, c_void_p, c_i64]),
+    "ssw_index_scan": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_index_scan_dev": (c_i32, [c_void_p, c_void_p]),
+    "ssw_index_topk": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p,
+                               c_void_p, c_i32_p]),
+    "ssw_index_set_excluded": (c_i32, [c_void_p, c_void_p, c_i64]),
+    "ssw_index_topk_dev": (c_i32, [c_void_p, c_void_p, c_i32]),
+    "ssw_index_result_ptrs": (c_i32, [c_void_p, c_void_pp, c_void_pp, c_void_pp]),
+    "ssw_index_topk_fetch": (c_i32, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32_p]),
+    "ssw_index_gather_scores": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ssw_topk_merge_dev": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32,
+                                   c_void_p, c_void_p]),
+    "ssw_index_profile": (c_i32, [c_void_p, c_i32]),
+    "ssw_index_profile_read": (c_i32, [c_void_p, c_void_p, c_i32, c_i32_p]),
+}
+
+_lib = None
+
+
+def declared_symbols(header_path: str = HEADER_PATH):
+    """Function names declared in include/seesaw_hip.h."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssw_[a-z0-9_]+)\s*\(", text)))
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the HIP library and install the argument types.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C seesaw_amd/csrc` (hipcc --offload-arch=gfx950). seesaw_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().ssw_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int):
+    if status != SSW_OK:
+        raise SeesawHipError(status, last_error())
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args))

@@ -1,0 +1,524 @@
+// capi_index.hip -- C-ABI of the resident vector index (see include/seesaw_hip.h).
+#include <cmath>
+#include <vector>
+
+#include "ssw_common.h"
+
+namespace ssw {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int num_cus(int device) {
+    static int cache[16] = {0};
+    const int slot = device & 15;
+    if (cache[slot] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            v <= 0)
+            v = 256;
+        cache[slot] = v;
+    }
+    return cache[slot];
+}
+
+ssw_status PinnedStage::push(void *dev_dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return SSW_OK;
+    if (pending) {  // the previous copy out of this buffer must have been consumed
+        SSW_HIP_TRY(hipEventSynchronize(ev));
+        pending = false;
+    }
+    if (bytes > cap) {
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
+        cap = 0;
+        size_t c = 4096;
+        while (c < bytes) c <<= 1;
+        SSW_HIP_TRY(hipHostMalloc(&host, c, hipHostMallocDefault));
+        cap = c;
+    }
+    if (!ev) SSW_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    memcpy(host, src, bytes);
+    SSW_HIP_TRY(hipMemcpyAsync(dev_dst, host, bytes, hipMemcpyHostToDevice, stream));
+    SSW_HIP_TRY(hipEventRecord(ev, stream));
+    pending = true;
+    return SSW_OK;
+}
+
+void PinnedStage::release() {
+    if (pending && ev) (void)hipEventSynchronize(ev);
+    if (host) (void)hipHostFree(host);
+    if (ev) (void)hipEventDestroy(ev);
+    host = nullptr;
+    ev = nullptr;
+    cap = 0;
+    pending = false;
+}
+
+}  // namespace ssw
+
+using namespace ssw;
+
+struct ssw_index {
+    int device = 0;
+    int64_t n = 0;
+    int32_t dim = 0;
+    int64_t n_images = 0;
+    bool has_map = false;
+    float *X = nullptr;
+    bool owns_X = false;
+    float *scores = nullptr;      // [n]
+    float *q_dev = nullptr;       // [dim] device copy of a host query
+    PinnedStage q_stage;
+    int64_t *row_start = nullptr;  // [n_images + 1] when has_map
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    SelectWorkspace ws;
+    bool ws_ready = false;
+    // gather staging
+    int64_t *gather_idx = nullptr;
+    float *gather_out = nullptr;
+    int64_t gather_cap = 0;
+    // profiling of the scan kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    int ev_used = 0;
+};
+
+static ssw_status ensure_ws(ssw_index *idx) {
+    if (idx->ws_ready) return SSW_OK;
+    SSW_TRY(select_alloc(idx->ws, idx->n, idx->n_images, idx->has_map));
+    idx->ws_ready = true;
+    return SSW_OK;
+}
+
+static ssw_status check_query(const ssw_index *idx, const float *q_host) {
+    for (int i = 0; i < idx->dim; ++i) {
+        if (!std::isfinite(q_host[i])) {
+            // the reference asserts on NaN query vectors (seesaw/loops/loop_base.py:47)
+            set_error("query vector has a non-finite component at %d", i);
+            return SSW_ERR_NUMERIC;
+        }
+    }
+    return SSW_OK;
+}
+
+static ssw_status do_scan(ssw_index *idx, const float *q_dev) {
+    if (idx->profiling && idx->ev_used + 2 <= (int)idx->ev.size()) {
+        SSW_HIP_TRY(hipEventRecord(idx->ev[idx->ev_used], idx->stream));
+        SSW_TRY(launch_scan(idx->X, q_dev, idx->scores, idx->n, idx->dim, idx->device, idx->stream));
+        SSW_HIP_TRY(hipEventRecord(idx->ev[idx->ev_used + 1], idx->stream));
+        idx->ev_used += 2;
+        return SSW_OK;
+    }
+    return launch_scan(idx->X, q_dev, idx->scores, idx->n, idx->dim, idx->device, idx->stream);
+}
+
+static ssw_status do_select(ssw_index *idx, int32_t k) {
+    SSW_TRY(ensure_ws(idx));
+    if (idx->has_map) {
+        SSW_TRY(launch_image_max(idx->scores, idx->row_start, idx->n_images, idx->ws.img_score,
+                                 idx->ws.img_best, idx->stream));
+        return launch_select_topk(idx->ws, idx->ws.img_score, idx->n_images, idx->ws.img_best, k,
+                                  idx->device, idx->stream);
+    }
+    return launch_select_topk(idx->ws, idx->scores, idx->n, nullptr, k, idx->device, idx->stream);
+}
+
+extern "C" {
+
+int32_t ssw_abi_version(void) { return SSW_ABI_VERSION; }
+const char *ssw_last_error(void) { return g_last_error.c_str(); }
+
+ssw_status ssw_device_count(int32_t *out_count) {
+    SSW_REQUIRE(out_count != nullptr, "out_count is NULL");
+    int c = 0;
+    SSW_HIP_TRY(hipGetDeviceCount(&c));
+    *out_count = c;
+    return SSW_OK;
+}
+
+ssw_status ssw_device_info(int32_t device, char *name, int32_t name_cap, int32_t *out_cus,
+                           int64_t *out_hbm_bytes) {
+    hipDeviceProp_t p;
+    SSW_HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (out_cus) *out_cus = p.multiProcessorCount;
+    if (out_hbm_bytes) *out_hbm_bytes = (int64_t)p.totalGlobalMem;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_create(int32_t device, int64_t n_rows, int32_t dim,
+                            const float *dev_vectors_or_null, ssw_index **out) {
+    SSW_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    SSW_REQUIRE(n_rows >= 0, "n_rows=%lld < 0", (long long)n_rows);
+    if (dim <= 0 || dim % 256 != 0 || dim > 1024) {
+        set_error("index: dim=%d unsupported (need a multiple of 256, <= 1024)", dim);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    if (n_rows >= (int64_t)0x7fff0000) {
+        set_error("index: %lld rows exceed the 2^31 row limit of one shard", (long long)n_rows);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    SSW_REQUIRE(((uintptr_t)dev_vectors_or_null & 15) == 0, "device matrix is not 16-byte aligned");
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", device);
+        return SSW_ERR_HIP;
+    }
+    ssw_index *idx = new (std::nothrow) ssw_index();
+    if (!idx) return SSW_ERR_NOMEM;
+    idx->device = device;
+    idx->n = n_rows;
+    idx->dim = dim;
+    idx->n_images = n_rows;
+    ssw_status st = SSW_OK;
+    auto fail = [&](ssw_status s) {
+        ssw_index_destroy(idx);
+        return s;
+    };
+    if (hipStreamCreateWithFlags(&idx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        return fail(SSW_ERR_HIP);
+    }
+    idx->stream = idx->own_stream;
+    const size_t row_bytes = (size_t)dim * sizeof(float);
+    if (dev_vectors_or_null) {
+        idx->X = const_cast<float *>(dev_vectors_or_null);
+    } else {
+        hipError_t e = hipMalloc((void **)&idx->X, (size_t)(n_rows > 0 ? n_rows : 1) * row_bytes);
+        if (e != hipSuccess) {
+            set_error("hipMalloc of %.2f GB for the index failed: %s",
+                      (double)n_rows * row_bytes / 1e9, hipGetErrorString(e));
+            idx->X = nullptr;
+            return fail(SSW_ERR_NOMEM);
+        }
+        idx->owns_X = true;
+    }
+    if (hipMalloc((void **)&idx->scores, (size_t)(n_rows + 64) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&idx->q_dev, row_bytes) != hipSuccess) {
+        set_error("hipMalloc of the score buffer failed");
+        return fail(SSW_ERR_NOMEM);
+    }
+    (void)st;
+    *out = idx;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_destroy(ssw_index *idx) {
+    if (!idx) return SSW_OK;
+    DeviceGuard guard(idx->device);
+    if (idx->own_stream) (void)hipStreamSynchronize(idx->own_stream);
+    for (hipEvent_t e : idx->ev) (void)hipEventDestroy(e);
+    if (idx->ws_ready) select_free(idx->ws);
+    if (idx->owns_X) (void)hipFree(idx->X);
+    (void)hipFree(idx->scores);
+    (void)hipFree(idx->q_dev);
+    idx->q_stage.release();
+    (void)hipFree(idx->row_start);
+    (void)hipFree(idx->gather_idx);
+    (void)hipFree(idx->gather_out);
+    if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
+    delete idx;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_set_stream(ssw_index *idx, void *hip_stream) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    idx->stream = hip_stream ? (hipStream_t)hip_stream : idx->own_stream;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_sync(ssw_index *idx) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_shape(const ssw_index *idx, int64_t *n_rows, int32_t *dim, int64_t *n_images) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (n_rows) *n_rows = idx->n;
+    if (dim) *dim = idx->dim;
+    if (n_images) *n_images = idx->n_images;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_device_ptrs(ssw_index *idx, void **dev_vectors, void **dev_scores) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (dev_vectors) *dev_vectors = idx->X;
+    if (dev_scores) *dev_scores = idx->scores;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_upload(ssw_index *idx, const float *host_rows, int64_t first_row, int64_t n) {
+    SSW_REQUIRE(idx != nullptr && host_rows != nullptr, "NULL argument");
+    SSW_REQUIRE(first_row >= 0 && n >= 0 && first_row + n <= idx->n,
+                "rows [%lld, %lld) outside the index of %lld rows", (long long)first_row,
+                (long long)(first_row + n), (long long)idx->n);
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipMemcpyAsync(idx->X + first_row * idx->dim, host_rows,
+                               (size_t)n * idx->dim * sizeof(float), hipMemcpyHostToDevice,
+                               idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_download(ssw_index *idx, float *host_rows, int64_t first_row, int64_t n) {
+    SSW_REQUIRE(idx != nullptr && host_rows != nullptr, "NULL argument");
+    SSW_REQUIRE(first_row >= 0 && n >= 0 && first_row + n <= idx->n,
+                "rows [%lld, %lld) outside the index of %lld rows", (long long)first_row,
+                (long long)(first_row + n), (long long)idx->n);
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipMemcpyAsync(host_rows, idx->X + first_row * idx->dim,
+                               (size_t)n * idx->dim * sizeof(float), hipMemcpyDeviceToHost,
+                               idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_fill_random(ssw_index *idx, uint64_t seed, int64_t global_first_row) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_TRY(launch_fill_random(idx->X, idx->n, idx->dim, seed, global_first_row, idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_set_row2image(ssw_index *idx, const int32_t *row2image_host, int64_t n_images) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (idx->ws_ready) {
+        select_free(idx->ws);
+        idx->ws_ready = false;
+    }
+    (void)hipFree(idx->row_start);
+    idx->row_start = nullptr;
+    if (row2image_host == nullptr) {
+        idx->has_map = false;
+        idx->n_images = idx->n;
+        return SSW_OK;
+    }
+    SSW_REQUIRE(n_images >= 0 && n_images <= idx->n, "n_images=%lld outside [0, n_rows]",
+                (long long)n_images);
+    std::vector<int64_t> start((size_t)n_images + 1, 0);
+    int32_t prev = 0;
+    for (int64_t r = 0; r < idx->n; ++r) {
+        const int32_t m = row2image_host[r];
+        if (m < prev || m >= n_images) {
+            set_error("row2image[%lld]=%d is not non-decreasing within [0, %lld)", (long long)r, m,
+                      (long long)n_images);
+            return SSW_ERR_INVALID;
+        }
+        prev = m;
+        start[(size_t)m + 1]++;
+    }
+    for (int64_t m = 0; m < n_images; ++m) {
+        if (start[(size_t)m + 1] == 0) {
+            set_error("image position %lld has no rows", (long long)m);
+            return SSW_ERR_INVALID;
+        }
+        start[(size_t)m + 1] += start[(size_t)m];
+    }
+    SSW_HIP_TRY(hipMalloc((void **)&idx->row_start, ((size_t)n_images + 1) * sizeof(int64_t)));
+    SSW_HIP_TRY(hipMemcpy(idx->row_start, start.data(), ((size_t)n_images + 1) * sizeof(int64_t),
+                          hipMemcpyHostToDevice));
+    idx->has_map = true;
+    idx->n_images = n_images;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_scan_dev(ssw_index *idx, const float *q_dev) {
+    SSW_REQUIRE(idx != nullptr && q_dev != nullptr, "NULL argument");
+    DeviceGuard guard(idx->device);
+    return do_scan(idx, q_dev);
+}
+
+ssw_status ssw_index_scan(ssw_index *idx, const float *q_host, float *out_scores_host_or_null) {
+    SSW_REQUIRE(idx != nullptr && q_host != nullptr, "NULL argument");
+    SSW_TRY(check_query(idx, q_host));
+    DeviceGuard guard(idx->device);
+    SSW_TRY(idx->q_stage.push(idx->q_dev, q_host, (size_t)idx->dim * sizeof(float), idx->stream));
+    SSW_TRY(do_scan(idx, idx->q_dev));
+    if (out_scores_host_or_null && idx->n > 0) {
+        SSW_HIP_TRY(hipMemcpyAsync(out_scores_host_or_null, idx->scores,
+                                   (size_t)idx->n * sizeof(float), hipMemcpyDeviceToHost,
+                                   idx->stream));
+    }
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_set_excluded(ssw_index *idx, const int64_t *excluded_images, int64_t n_excluded) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    SSW_REQUIRE(n_excluded == 0 || excluded_images != nullptr, "excluded_images is NULL");
+    for (int64_t i = 0; i < n_excluded; ++i) {
+        SSW_REQUIRE(excluded_images[i] >= 0 && excluded_images[i] < idx->n_images,
+                    "excluded image %lld outside [0, %lld)", (long long)excluded_images[i],
+                    (long long)idx->n_images);
+    }
+    DeviceGuard guard(idx->device);
+    SSW_TRY(ensure_ws(idx));
+    return select_set_excluded(idx->ws, idx->n_images, excluded_images, n_excluded, idx->stream);
+}
+
+ssw_status ssw_index_topk_dev(ssw_index *idx, const float *q_dev, int32_t k) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    if (q_dev) SSW_TRY(do_scan(idx, q_dev));
+    if (idx->n_images == 0) return SSW_OK;
+    return do_select(idx, k);
+}
+
+ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_count,
+                                 void **dev_best_rows) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_TRY(ensure_ws(idx));
+    if (dev_keys) *dev_keys = idx->ws.out_keys;
+    if (dev_count) *dev_count = idx->ws.out_count;
+    if (dev_best_rows) *dev_best_rows = idx->ws.out_best;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, float *out_scores,
+                                int64_t *out_best_rows, int32_t *out_count) {
+    SSW_REQUIRE(idx != nullptr && out_count != nullptr, "NULL argument");
+    SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    *out_count = 0;
+    if (idx->n_images == 0) return SSW_OK;
+    DeviceGuard guard(idx->device);
+    SSW_TRY(ensure_ws(idx));
+    bool overflow = false;
+    SSW_TRY(select_check_overflow(idx->ws, idx->stream, &overflow));
+    if (overflow) {
+        const float *values = idx->has_map ? idx->ws.img_score : idx->scores;
+        const uint32_t *best = idx->has_map ? idx->ws.img_best : nullptr;
+        SSW_TRY(launch_select_topk_deep(idx->ws, values, idx->n_images, best, k, idx->device,
+                                        idx->stream));
+    }
+    int32_t count = 0;
+    std::vector<uint64_t> keys((size_t)k);
+    std::vector<uint32_t> best((size_t)k);
+    SSW_HIP_TRY(hipMemcpyAsync(&count, idx->ws.out_count, sizeof(int32_t), hipMemcpyDeviceToHost,
+                               idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(keys.data(), idx->ws.out_keys, (size_t)k * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(best.data(), idx->ws.out_best, (size_t)k * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (count > k) count = k;
+    for (int32_t i = 0; i < count; ++i) {
+        const uint64_t key = keys[(size_t)i];
+        if (out_images) out_images[i] = (int64_t)(0xffffffffu - (uint32_t)(key & 0xffffffffull));
+        if (out_scores) out_scores[i] = ord_to_f32((uint32_t)(key >> 32));
+        if (out_best_rows) out_best_rows[i] = (int64_t)best[(size_t)i];
+    }
+    *out_count = count;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *excluded_images,
+                          int64_t n_excluded, int32_t k, int64_t *out_images, float *out_scores,
+                          int64_t *out_best_rows, int32_t *out_count) {
+    SSW_REQUIRE(idx != nullptr && out_count != nullptr, "NULL argument");
+    SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    *out_count = 0;
+    DeviceGuard guard(idx->device);
+    if (q_host) {
+        SSW_TRY(check_query(idx, q_host));
+        SSW_TRY(idx->q_stage.push(idx->q_dev, q_host, (size_t)idx->dim * sizeof(float),
+                                  idx->stream));
+        SSW_TRY(do_scan(idx, idx->q_dev));
+    }
+    if (idx->n_images == 0) return SSW_OK;
+    SSW_TRY(ssw_index_set_excluded(idx, excluded_images, n_excluded));
+    SSW_TRY(do_select(idx, k));
+    return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
+}
+
+ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
+                                   float *out_scores_host) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (n <= 0) return SSW_OK;
+    SSW_REQUIRE(rows_host != nullptr && out_scores_host != nullptr, "NULL argument");
+    for (int64_t i = 0; i < n; ++i) {
+        SSW_REQUIRE(rows_host[i] >= 0 && rows_host[i] < idx->n, "row %lld outside [0, %lld)",
+                    (long long)rows_host[i], (long long)idx->n);
+    }
+    DeviceGuard guard(idx->device);
+    if (n > idx->gather_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+        (void)hipFree(idx->gather_idx);
+        (void)hipFree(idx->gather_out);
+        idx->gather_idx = nullptr;
+        idx->gather_out = nullptr;
+        idx->gather_cap = 0;
+        int64_t cap = 4096;
+        while (cap < n) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&idx->gather_idx, (size_t)cap * sizeof(int64_t)));
+        SSW_HIP_TRY(hipMalloc((void **)&idx->gather_out, (size_t)cap * sizeof(float)));
+        idx->gather_cap = cap;
+    }
+    SSW_HIP_TRY(hipMemcpyAsync(idx->gather_idx, rows_host, (size_t)n * sizeof(int64_t),
+                               hipMemcpyHostToDevice, idx->stream));
+    SSW_TRY(launch_gather_f32(idx->scores, idx->gather_idx, n, idx->gather_out, idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(out_scores_host, idx->gather_out, (size_t)n * sizeof(float),
+                               hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *dev_keys_in,
+                              int32_t n_lists, int32_t list_stride, const int32_t *dev_counts,
+                              int32_t k, uint64_t *dev_keys_out, int32_t *dev_count_out) {
+    SSW_REQUIRE(dev_keys_in && dev_counts && dev_keys_out && dev_count_out, "NULL argument");
+    DeviceGuard guard(device);
+    return launch_merge_topk(dev_keys_in, n_lists, list_stride, dev_counts, k, dev_keys_out,
+                             dev_count_out, (hipStream_t)hip_stream);
+}
+
+ssw_status ssw_index_profile(ssw_index *idx, int32_t enable) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (enable && idx->ev.empty()) {
+        idx->ev.resize(2 * 4096);
+        for (auto &e : idx->ev) SSW_HIP_TRY(hipEventCreate(&e));
+    }
+    idx->profiling = enable != 0;
+    idx->ev_used = 0;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_profile_read(ssw_index *idx, float *out_ms, int32_t cap, int32_t *out_n) {
+    SSW_REQUIRE(idx != nullptr && out_n != nullptr, "NULL argument");
+    DeviceGuard guard(idx->device);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    const int pairs = idx->ev_used / 2;
+    int n = 0;
+    for (int i = 0; i < pairs && n < cap; ++i) {
+        float ms = 0.f;
+        SSW_HIP_TRY(hipEventElapsedTime(&ms, idx->ev[2 * i], idx->ev[2 * i + 1]));
+        out_ms[n++] = ms;
+    }
+    *out_n = n;
+    idx->ev_used = 0;
+    return SSW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// scan.hip -- brute-force cosine scan: scores[i] = <X[i,:], q>  (gfx950 / MI355X)
+//
+// Replaces `scores = vectors @ vector.reshape(-1)` of the reference
+// (seesaw/indices/multiscale/multiscale_index.py:171, :285, :345;
+//  seesaw/indices/coarse/coarse_index.py:38, :73).
+//
+// Roofline: HBM-bound.  Algorithmic traffic = dim*4 bytes per row read once
+// (2048 B at dim=512) + 4 B per row of score written.  No reuse -> no LDS staging:
+// rows go straight from HBM to VGPRs with 16-byte loads, a wave reading one whole
+// row (2 KiB at dim=512) with `dim/256` fully coalesced 1-KiB wave-instructions.
+//
+// Work decomposition (64-wide wavefronts):
+//   * one wave owns a BATCH of 64 consecutive rows (128 KiB contiguous at dim=512) and
+//     walks it in GROUPS of U rows (U = 4 at dim=512); the loads of group g+1 are
+//     issued before group g is reduced (register double buffer), so with 16-20 waves
+//     per CU there are >= 128 KiB of loads in flight per CU.
+//   * lane l accumulates, for one row, two fmaf chains over the elements it loaded
+//     (float4 v[c] = X[row, 256*c + 4*l .. +3], c < dim/256):
+//         a0 = fma(v[c].x, q.x, a0); a1 = fma(v[c].y, q.y, a1);
+//         a0 = fma(v[c].z, q.z, a0); a1 = fma(v[c].w, q.w, a1);     (c ascending)
+//     both starting from +0.0f; the lane partial is p = a0 + a1.  (The two chains
+//     are what v_pk_fma_f32 computes on a register pair.)
+//   * the 64 lane partials of a row are summed by the xor-butterfly
+//         v <- v + v[lane ^ off],   off = 1, 2, 4, 8, 16, 32
+//     (f32 add is commutative, so every lane ends with the same bits).  For the
+//     first log2(U) offsets the U rows of a group are reduced TOGETHER by a
+//     transpose-reduce (each exchange halves the number of live registers and leaves
+//     lane l with row l % U), which is value-identical to the butterfly; the
+//     remaining offsets are plain butterfly steps.  U + 5 - log2(U) exchanges per U
+//     rows instead of 6 per row.
+//   * lane l = U*g + j then owns the finished score of row j of group g; after the
+//     64/U groups of a batch lane l holds the score of row l and the wave stores its
+//     64 scores with one coalesced 256-B write.
+//   oracle/ssw_oracle.c::ssw_oracle_scores_kernel_order restates exactly this order,
+//   which makes the scores BIT-EXACT against the CPU oracle, not merely close.
+//
+// Grid: persistent, (#CUs x resident blocks per CU) blocks of 256 threads; waves
+// stride over the batches.
+#include "ssw_common.h"
+
+namespace ssw {
+
+namespace {
+
+template <int C>
+struct RowFrag {
+    float4 v[C];
+};
+
+template <int C>
+__device__ __forceinline__ RowFrag<C> load_row(const float4 *__restrict__ X4, int row, int lane) {
+    RowFrag<C> r;
+    const float4 *p = X4 + (int64_t)row * (C * 64) + lane;
+#pragma unroll
+    for (int c = 0; c < C; ++c) r.v[c] = p[c * 64];
+    return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the two fmaf chains (a0 over .x/.z, a1 over .y/.w) as packed math on register pairs
+template <int C>
+__device__ __forceinline__ float dot_frag(const RowFrag<C> &x, const RowFrag<C> &q) {
+    f32x2 a = {0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        a = __builtin_elementwise_fma(f32x2{x.v[c].x, x.v[c].y}, f32x2{q.v[c].x, q.v[c].y}, a);
+        a = __builtin_elementwise_fma(f32x2{x.v[c].z, x.v[c].w}, f32x2{q.v[c].z, q.v[c].w}, a);
+    }
+    return a.x + a.y;
+}
+
+// U lane-partial registers (acc[j] = row j of the group) -> every lane l holds the
+// complete sum of row (l % U): transpose-reduce over offsets 1..U/2, then butterfly
+// over offsets U..32.  Canonical offset order 1,2,4,8,16,32 for every U.
+template <int U>
+__device__ __forceinline__ float group_reduce(float (&acc)[U], int lane) {
+#pragma unroll
+    for (int off = 1; off < U; off <<= 1) {
+        // register distance of the pair merged at this offset == off
+        const bool upper = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < U; i += 2 * off) {
+            const float keep = upper ? acc[i + off] : acc[i];
+            const float send = upper ? acc[i] : acc[i + off];
+            acc[i] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    float v = acc[0];
+#pragma unroll
+    for (int off = U; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int C, int U>
+struct Group {
+    RowFrag<C> r[U];
+};
+
+template <int C, int U>
+__device__ __forceinline__ void load_group(Group<C, U> &g, const float4 *__restrict__ X4,
+                                           int first_row, int last, int lane) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) g.r[u] = load_row<C>(X4, min(first_row + u, last), lane);
+}
+
+template <int C, int U>
+__global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restrict__ X,
+                                                         const float *__restrict__ q,
+                                                         float *__restrict__ scores, int n) {
+    constexpr int GPB = 64 / U;  // groups per batch
+    const int lane = threadIdx.x & 63;
+    // wave index through readfirstlane: keeps every row/address computation on the SALU
+    // (rows are 32-bit: n < 2^31 - 2^16 is checked by the launcher)
+    const int gwave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * 4;
+    const int nbatches = (n + 63) >> 6;
+    const int last = n - 1;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X);
+    if (gwave >= nbatches) return;
+
+    RowFrag<C> qf;
+#pragma unroll
+    for (int c = 0; c < C; ++c) qf.v[c] = reinterpret_cast<const float4 *>(q)[c * 64 + lane];
+
+    const int my_group = lane / U;
+    Group<C, U> cur, nxt;
+    load_group<C, U>(cur, X4, gwave << 6, last, lane);
+    for (int b = gwave; b < nbatches; b += nwaves) {
+        const int row0 = b << 6;
+        const int nb = b + nwaves;
+        const int next0 = (nb < nbatches ? nb : b) << 6;  // no next batch: re-touch own rows
+        float out = 0.0f;
+#pragma unroll 2
+        for (int g = 0; g < GPB; ++g) {
+            // request group g+1 (or the first group of this wave's next batch) ...
+            const int nrow = (g + 1 < GPB) ? row0 + (g + 1) * U : next0;
+            load_group<C, U>(nxt, X4, nrow, last, lane);
+            // ... then finish group g
+            float acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = dot_frag<C>(cur.r[u], qf);
+            const float v = group_reduce<U>(acc, lane);
+            out = (my_group == g) ? v : out;
+            cur = nxt;
+        }
+        if (row0 + lane < n) scores[row0 + lane] = out;
+    }
+}
+
+template <int C, int U>
+ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t n, int device,
+                         hipStream_t stream) {
+    static int blocks_per_cu[16] = {0};
+    int dev_slot = device & 15;
+    if (blocks_per_cu[dev_slot] == 0) {
+        int nb = 0;
+        SSW_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_scores_kernel<C, U>,
+                                                                 256, 0));
+        if (nb < 1) nb = 1;
+        if (nb > 8) nb = 8;
+        blocks_per_cu[dev_slot] = nb;
+    }
+    if (n >= (int64_t)0x7fff0000) {
+        set_error("scan: n=%lld rows exceeds the 2^31 row limit of one index shard", (long long)n);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    const int64_t nbatches = (n + 63) >> 6;
+    int64_t grid = (int64_t)num_cus(device) * blocks_per_cu[dev_slot];
+    const int64_t need = (nbatches + 3) / 4;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((scan_scores_kernel<C, U>), dim3((unsigned)grid), dim3(256), 0, stream, X,
+                       q, scores, (int)n);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace
+
+ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_t n, int32_t dim,
+                       int device, hipStream_t stream) {
+    if (n <= 0) return SSW_OK;
+    switch (dim) {
+        case 256: return launch_scan_t<1, 8>(X, q_dev, scores, n, device, stream);
+        case 512: return launch_scan_t<2, 4>(X, q_dev, scores, n, device, stream);
+        case 768: return launch_scan_t<3, 2>(X, q_dev, scores, n, device, stream);
+        case 1024: return launch_scan_t<4, 2>(X, q_dev, scores, n, device, stream);
+        default:
+            set_error("scan: dim=%d unsupported (need a multiple of 256, <= 1024)", dim);
+            return SSW_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace ssw

@@ -1,0 +1,492 @@
+// select.hip -- exact top-k of the per-image best scores (gfx950 / MI355X)
+//
+// Replaces the reference's full sort + pandas passes:
+//   np.argsort(-scores)                      seesaw/indices/multiscale/multiscale_index.py:172
+//   dbidx gather / ~isin(exclude) / np.unique(return_index) / sort / [:topk]
+//                                            seesaw/indices/multiscale/multiscale_index.py:177-199
+//   np.argsort(-scores)[:topk]               seesaw/indices/coarse/coarse_index.py:75
+// Only the first `shortlist_size` distinct images of that order are ever used, so the
+// N-key sort is replaced by an exact radix SELECT:
+//   1. image_max    : rows are stored sorted by image, so "first occurrence of each image
+//                     in descending score order" == per-image max over a contiguous row
+//                     range (lowest row on ties).            [skipped for 1 vector/image]
+//   2. hist<1>/pick : 4096-bin histogram of the top 12 bits of the order-preserving u32
+//                     key of the image score; find the bin holding the k-th largest.
+//   3. hist<2>/pick : same on the next 12 bits, only inside that bin, only when the bin
+//                     is too full to sort directly.
+//   4. collect      : every image at or above the (12- or 24-bit) prefix is appended as a
+//                     64-bit composite key (score_key << 32 | ~image) -- unique per image,
+//                     so there are no ties left to break.
+//   5. final        : one workgroup bitonic-sorts the <= 8192 candidates in LDS and emits
+//                     the k largest = (score desc, image asc).
+// Excluded images (InteractiveQuery.returned, query_interface.py:43-48) are skipped in
+// steps 2-4 through a device bitmap.  Bound: reads 4 B/image three times -- < 0.6 % of
+// the scan's traffic at dim=512.
+#include "ssw_common.h"
+
+namespace ssw {
+
+namespace {
+
+constexpr int NBINS = 4096;
+constexpr int FINAL_CAP = 8192;  // candidates the final sort can take (64 KiB of LDS)
+enum StateSlot : int {
+    ST_B1 = 0, ST_ABOVE1, ST_CNT1, ST_B2, ST_ABOVE2, ST_CNT2, ST_MODE, ST_NCAND, ST_OVERFLOW, ST_K,
+    ST_WORDS = 16
+};
+
+__device__ __forceinline__ bool is_excluded(const uint32_t *__restrict__ excl, int64_t i) {
+    return excl != nullptr && ((excl[i >> 5] >> (i & 31)) & 1u);
+}
+
+__global__ void k_set_bits(uint32_t *bits, const int64_t *ids, int64_t n, int64_t m, int set) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    if (id < 0 || id >= m) return;
+    if (set)
+        atomicOr(&bits[id >> 5], 1u << (id & 31));
+    else
+        bits[id >> 5] = 0u;  // clearing whole words is fine: every set bit is in the old list
+}
+
+__global__ void k_image_max(const float *__restrict__ scores, const int64_t *__restrict__ row_start,
+                            int64_t n_images, float *__restrict__ img_score,
+                            uint32_t *__restrict__ img_best) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_images) return;
+    const int64_t r0 = row_start[m], r1 = row_start[m + 1];
+    float best = -INFINITY;
+    int64_t br = r0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float s = scores[r];
+        if (s > best) {  // strict: lowest row wins ties (score_frame2 `.head(n=1)`)
+            best = s;
+            br = r;
+        }
+    }
+    img_score[m] = best;
+    img_best[m] = (uint32_t)br;
+}
+
+// LEVEL 1: bins = key >> 20.  LEVEL 2: bins = (key >> 8) & 0xfff for keys with key>>20 == b1.
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_hist(const float *__restrict__ values, int64_t m,
+                                              const uint32_t *__restrict__ excl,
+                                              uint32_t *__restrict__ hist,
+                                              const uint32_t *__restrict__ state) {
+    __shared__ uint32_t lh[NBINS];
+    uint32_t b1 = 0;
+    if (LEVEL == 2) {
+        if (state[ST_MODE] == 0) return;  // level 1 was enough
+        b1 = state[ST_B1];
+    }
+    for (int i = threadIdx.x; i < NBINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        if (is_excluded(excl, i)) continue;
+        const uint32_t key = f32_to_ord(values[i]);
+        if (LEVEL == 1) {
+            atomicAdd(&lh[key >> 20], 1u);
+        } else if ((key >> 20) == b1) {
+            atomicAdd(&lh[(key >> 8) & 0xfffu], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBINS; i += 256) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// one block of 1024 threads: find the bin that holds the kk-th largest element.
+template <int LEVEL>
+__global__ __launch_bounds__(1024) void k_pick(const uint32_t *__restrict__ hist,
+                                               uint32_t *__restrict__ state, int k) {
+    __shared__ uint32_t sums[1024];
+    const int t = threadIdx.x;
+    uint32_t kk = (uint32_t)k;  // LEVEL 0 (deep path): k is already the rank inside the prefix
+    if (LEVEL == 2) {
+        if (state[ST_MODE] == 0) return;
+        kk = (uint32_t)k - state[ST_ABOVE1];  // rank inside bin b1 (>= 1 by construction)
+    }
+    const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2],
+                   h3 = hist[4 * t + 3];
+    const uint32_t local = h0 + h1 + h2 + h3;
+    sums[t] = local;
+    __syncthreads();
+    // inclusive suffix sum over threads (from the top bin downwards)
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (t + d < 1024) ? sums[t + d] : 0u;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    const uint32_t total = sums[0];
+    const uint32_t above_t = sums[t] - local;  // elements in bins above this thread's 4
+    uint32_t b = 0, above = 0, cnt = 0;
+    bool found = false;
+    if (total < kk) {
+        // fewer than k elements in all: everything is a candidate
+        if (t == 0) {
+            found = true;
+            b = 0;
+            cnt = h0;
+            above = total - h0;
+        }
+    } else if (above_t < kk && kk <= above_t + local) {
+        const uint32_t hh[4] = {h0, h1, h2, h3};
+        uint32_t c = above_t;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (!found && c + hh[j] >= kk) {
+                found = true;
+                b = 4 * t + j;
+                above = c;
+                cnt = hh[j];
+            }
+            c += hh[j];
+        }
+    }
+    if (found) {
+        if (LEVEL != 2) {
+            state[ST_B1] = b;
+            state[ST_ABOVE1] = above;
+            state[ST_CNT1] = cnt;
+            state[ST_MODE] = (above + cnt > (uint32_t)FINAL_CAP) ? 1u : 0u;
+        } else {
+            state[ST_B2] = b;
+            state[ST_ABOVE2] = above;
+            state[ST_CNT2] = cnt;
+            if (state[ST_ABOVE1] + above + cnt > (uint32_t)FINAL_CAP) state[ST_OVERFLOW] = 1u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_collect(const float *__restrict__ values, int64_t m,
+                                                 const uint32_t *__restrict__ excl,
+                                                 uint32_t *__restrict__ state,
+                                                 uint64_t *__restrict__ cand) {
+    const uint32_t mode = state[ST_MODE];
+    const uint32_t prefix = mode ? ((state[ST_B1] << 12) | state[ST_B2]) : state[ST_B1];
+    const int shift = mode ? 8 : 20;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        if (is_excluded(excl, i)) continue;
+        const uint32_t key = f32_to_ord(values[i]);
+        if ((key >> shift) >= prefix) {
+            const uint32_t slot = atomicAdd(&state[ST_NCAND], 1u);
+            if (slot < (uint32_t)FINAL_CAP)
+                cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        }
+    }
+}
+
+
+// ---- deep path: only when more than FINAL_CAP candidates share a 24-bit score prefix
+// (massive exact ties, e.g. duplicated vectors).  Radix select on the full 64-bit
+// composite key, one digit per host-synchronised round; composite keys are unique, so
+// the loop always ends.
+__device__ __forceinline__ uint64_t composite_key(float v, int64_t i) {
+    return ((uint64_t)f32_to_ord(v) << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_hist_deep(const float *__restrict__ values, int64_t m,
+                                                   const uint32_t *__restrict__ excl,
+                                                   uint32_t *__restrict__ hist, uint64_t prefix,
+                                                   int prefix_shift, int digit_shift,
+                                                   uint32_t digit_mask) {
+    __shared__ uint32_t lh[NBINS];
+    for (int i = threadIdx.x; i < NBINS; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        if (is_excluded(excl, i)) continue;
+        const uint64_t ck = composite_key(values[i], i);
+        const bool match = (prefix_shift >= 64) || ((ck >> prefix_shift) == prefix);
+        if (match) atomicAdd(&lh[(uint32_t)(ck >> digit_shift) & digit_mask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NBINS; i += 256) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_collect_deep(const float *__restrict__ values, int64_t m,
+                                                      const uint32_t *__restrict__ excl,
+                                                      uint32_t *__restrict__ state,
+                                                      uint64_t *__restrict__ cand,
+                                                      uint64_t threshold) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
+        if (is_excluded(excl, i)) continue;
+        const uint64_t ck = composite_key(values[i], i);
+        if (ck >= threshold) {
+            const uint32_t slot = atomicAdd(&state[ST_NCAND], 1u);
+            if (slot < (uint32_t)FINAL_CAP) cand[slot] = ck;
+        }
+    }
+}
+
+// descending bitonic sort of p (power of two) u64 keys in LDS, 1024 threads
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t *s, int p, int t) {
+    for (int k2 = 2; k2 <= p; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < p; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool desc = ((i & k2) == 0);
+                    const uint64_t a = s[i], b = s[ixj];
+                    if ((a < b) == desc) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// candidates (n_lists lists of counts[l] keys at keys_in + l*stride; or one list whose
+// length is *ncand_ptr) -> k largest, sorted descending.
+__global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ keys_in, int n_lists,
+                                                int list_stride, const int32_t *__restrict__ counts,
+                                                const uint32_t *__restrict__ ncand_ptr, int k,
+                                                const uint32_t *__restrict__ best_src,
+                                                uint64_t *__restrict__ keys_out,
+                                                int32_t *__restrict__ count_out,
+                                                uint32_t *__restrict__ best_out) {
+    extern __shared__ uint64_t s[];  // FINAL_CAP entries
+    const int t = threadIdx.x;
+    int n = 0;
+    if (ncand_ptr != nullptr) {
+        n = (int)min(*ncand_ptr, (uint32_t)FINAL_CAP);
+        for (int i = t; i < n; i += 1024) s[i] = keys_in[i];
+    } else {
+        for (int l = 0; l < n_lists; ++l) {
+            const int c = min(counts[l], list_stride);
+            if (n + c > FINAL_CAP) break;  // launcher guarantees n_lists*stride <= FINAL_CAP
+            for (int i = t; i < c; i += 1024) s[n + i] = keys_in[(int64_t)l * list_stride + i];
+            n += c;
+        }
+    }
+    int p = 1;
+    while (p < n) p <<= 1;
+    for (int i = n + t; i < p; i += 1024) s[i] = 0ull;  // below every real key
+    __syncthreads();
+    bitonic_sort_desc(s, p, t);
+    const int out = min(k, n);
+    for (int i = t; i < out; i += 1024) {
+        const uint64_t key = s[i];
+        keys_out[i] = key;
+        if (best_out != nullptr) {
+            const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+            best_out[i] = best_src ? best_src[id] : id;
+        }
+    }
+    if (t == 0) *count_out = out;
+}
+
+__global__ void k_gather_f32(const float *__restrict__ src, const int64_t *__restrict__ idx,
+                             int64_t n, float *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+template <typename T>
+ssw_status dev_alloc(T **p, size_t count) {
+    SSW_HIP_TRY(hipMalloc((void **)p, count * sizeof(T) + 16));
+    return SSW_OK;
+}
+
+int grid_for(int64_t m, int device) {
+    int64_t g = (m + 255) / 256;
+    const int64_t cap = (int64_t)num_cus(device) * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map) {
+    SSW_TRY(dev_alloc(&ws.hist1, 2 * NBINS + ST_WORDS));
+    ws.hist2 = ws.hist1 + NBINS;
+    ws.state = ws.hist1 + 2 * NBINS;
+    SSW_TRY(dev_alloc(&ws.cand, FINAL_CAP));
+    SSW_TRY(dev_alloc(&ws.out_keys, SSW_MAX_TOPK));
+    SSW_TRY(dev_alloc(&ws.out_count, 4));
+    SSW_TRY(dev_alloc(&ws.out_best, SSW_MAX_TOPK));
+    if (has_map) {
+        SSW_TRY(dev_alloc(&ws.img_score, n_images));
+        SSW_TRY(dev_alloc(&ws.img_best, n_images));
+    }
+    const int64_t words = (n_images + 31) / 32;
+    SSW_TRY(dev_alloc(&ws.excl_bits, words));
+    SSW_HIP_TRY(hipMemset(ws.excl_bits, 0, words * 4));
+    SSW_HIP_TRY(hipMemset(ws.out_count, 0, 16));
+    (void)n_rows;
+    return SSW_OK;
+}
+
+void select_free(SelectWorkspace &ws) {
+    (void)hipFree(ws.hist1);
+    (void)hipFree(ws.cand);
+    (void)hipFree(ws.out_keys);
+    (void)hipFree(ws.out_count);
+    (void)hipFree(ws.out_best);
+    (void)hipFree(ws.img_score);
+    (void)hipFree(ws.img_best);
+    (void)hipFree(ws.excl_bits);
+    (void)hipFree(ws.excl_ids);
+    ws.excl_stage.release();
+    ws = SelectWorkspace();
+}
+
+ssw_status select_set_excluded(SelectWorkspace &ws, int64_t n_images, const int64_t *ids_host,
+                               int64_t n, hipStream_t stream) {
+    // clear the bits of the previously installed list, then set the new one
+    if (ws.excl_dirty && ws.n_excluded_distinct > 0) {
+        const int64_t old = ws.n_excluded_distinct;
+        hipLaunchKernelGGL(k_set_bits, dim3((unsigned)((old + 255) / 256)), dim3(256), 0, stream,
+                           ws.excl_bits, ws.excl_ids, old, n_images, 0);
+        SSW_HIP_TRY(hipGetLastError());
+    }
+    ws.excl_dirty = false;
+    ws.n_excluded_distinct = 0;
+    if (n <= 0) return SSW_OK;
+    if (n > ws.excl_ids_cap) {
+        // the old list must have been consumed by the clear kernel before its buffer goes
+        SSW_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(ws.excl_ids);
+        ws.excl_ids = nullptr;
+        ws.excl_ids_cap = 0;
+        int64_t cap = 1024;
+        while (cap < n) cap <<= 1;
+        SSW_TRY(dev_alloc(&ws.excl_ids, cap));
+        ws.excl_ids_cap = cap;
+    }
+    SSW_TRY(ws.excl_stage.push(ws.excl_ids, ids_host, (size_t)n * sizeof(int64_t), stream));
+    hipLaunchKernelGGL(k_set_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       ws.excl_bits, ws.excl_ids, n, n_images, 1);
+    SSW_HIP_TRY(hipGetLastError());
+    ws.excl_dirty = true;
+    ws.n_excluded_distinct = n;  // length of the installed list (may contain repeats)
+    return SSW_OK;
+}
+
+ssw_status launch_image_max(const float *scores, const int64_t *row_start, int64_t n_images,
+                            float *img_score, uint32_t *img_best, hipStream_t stream) {
+    if (n_images <= 0) return SSW_OK;
+    hipLaunchKernelGGL(k_image_max, dim3((unsigned)((n_images + 255) / 256)), dim3(256), 0, stream,
+                       scores, row_start, n_images, img_score, img_best);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t m,
+                              const uint32_t *best_rows_or_null, int32_t k, int device,
+                              hipStream_t stream) {
+    if (k < 1 || k > SSW_MAX_TOPK) {
+        set_error("topk: k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+        return SSW_ERR_INVALID;
+    }
+    if (m >= (int64_t)0xffffffffll) {
+        set_error("topk: %lld images exceed the 32-bit id space of one shard", (long long)m);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
+    SSW_HIP_TRY(hipMemsetAsync(ws.hist1, 0, (2 * NBINS + ST_WORDS) * sizeof(uint32_t), stream));
+    const int g = grid_for(m, device);
+    hipLaunchKernelGGL(k_hist<1>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist1, ws.state);
+    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, (int)k);
+    hipLaunchKernelGGL(k_hist<2>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist2, ws.state);
+    hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, (int)k);
+    hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
+                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (int)k,
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+
+ssw_status select_check_overflow(SelectWorkspace &ws, hipStream_t stream, bool *overflow) {
+    uint32_t st[ST_WORDS];
+    SSW_HIP_TRY(hipMemcpyAsync(st, ws.state, sizeof(st), hipMemcpyDeviceToHost, stream));
+    SSW_HIP_TRY(hipStreamSynchronize(stream));
+    *overflow = st[ST_OVERFLOW] != 0 || st[ST_NCAND] > (uint32_t)FINAL_CAP;
+    return SSW_OK;
+}
+
+ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,
+                                   const uint32_t *best_rows_or_null, int32_t k, int device,
+                                   hipStream_t stream) {
+    const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
+    const int g = grid_for(m, device);
+    static const int digit_shift[6] = {52, 40, 32, 20, 8, 0};
+    static const int digit_bits[6] = {12, 12, 8, 12, 12, 8};
+    uint64_t prefix = 0;
+    int prefix_shift = 64;
+    uint32_t kk = (uint32_t)k;
+    uint64_t threshold = 0;
+    for (int lvl = 0; lvl < 6; ++lvl) {
+        SSW_HIP_TRY(hipMemsetAsync(ws.hist1, 0, (2 * NBINS + ST_WORDS) * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(k_hist_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist1,
+                           prefix, prefix_shift, digit_shift[lvl],
+                           (uint32_t)((1u << digit_bits[lvl]) - 1u));
+        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, (int)kk);
+        SSW_HIP_TRY(hipGetLastError());
+        uint32_t st[ST_WORDS];
+        SSW_HIP_TRY(hipMemcpyAsync(st, ws.state, sizeof(st), hipMemcpyDeviceToHost, stream));
+        SSW_HIP_TRY(hipStreamSynchronize(stream));
+        const uint32_t b = st[ST_B1], above = st[ST_ABOVE1], cnt = st[ST_CNT1];
+        prefix = (prefix << digit_bits[lvl]) | b;
+        prefix_shift = digit_shift[lvl];
+        threshold = prefix << prefix_shift;
+        // everything above the prefix is fewer than k <= SSW_MAX_TOPK elements in total
+        const uint32_t above_total = (uint32_t)k - kk + above;
+        if (above_total + cnt <= (uint32_t)FINAL_CAP) break;
+        kk -= above;
+    }
+    SSW_HIP_TRY(hipMemsetAsync(ws.state, 0, ST_WORDS * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(k_collect_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state,
+                       ws.cand, threshold);
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
+                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (int)k,
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t list_stride,
+                             const int32_t *counts, int32_t k, uint64_t *keys_out,
+                             int32_t *count_out, hipStream_t stream) {
+    if (n_lists < 1 || list_stride < 1 || (int64_t)n_lists * list_stride > FINAL_CAP) {
+        set_error("merge: %d lists x %d keys exceed %d candidates", n_lists, list_stride, FINAL_CAP);
+        return SSW_ERR_INVALID;
+    }
+    if (k < 1 || k > SSW_MAX_TOPK) {
+        set_error("merge: k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+        return SSW_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,
+                       (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr, (int)k,
+                       (const uint32_t *)nullptr, keys_out, count_out, (uint32_t *)nullptr);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+ssw_status launch_gather_f32(const float *src, const int64_t *idx_dev, int64_t n, float *dst,
+                             hipStream_t stream) {
+    if (n <= 0) return SSW_OK;
+    hipLaunchKernelGGL(k_gather_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,
+                       idx_dev, n, dst);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace ssw

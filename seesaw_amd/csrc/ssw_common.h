@@ -1,0 +1,141 @@
+// Shared host-side helpers for libseesaw_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/seesaw_hip.h"
+
+namespace ssw {
+
+void set_error(const char *fmt, ...);
+
+#define SSW_HIP_TRY(expr)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ssw::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                       \
+            return (_e == hipErrorOutOfMemory) ? SSW_ERR_NOMEM : SSW_ERR_HIP;               \
+        }                                                                                   \
+    } while (0)
+
+#define SSW_REQUIRE(cond, ...)           \
+    do {                                 \
+        if (!(cond)) {                   \
+            ssw::set_error(__VA_ARGS__); \
+            return SSW_ERR_INVALID;      \
+        }                                \
+    } while (0)
+
+#define SSW_TRY(expr)                   \
+    do {                                \
+        ssw_status _s = (expr);         \
+        if (_s != SSW_OK) return _s;    \
+    } while (0)
+
+// Orderable key of an f32: ascending unsigned order == ascending float order
+// (-inf lowest; used with -inf for excluded images).
+__host__ __device__ inline uint32_t f32_to_ord(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord_to_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int num_cus(int device);
+
+// Pinned host staging for small host->device inputs (query vectors, id lists): the
+// caller's buffer is copied into pinned memory on the CPU, so the async H2D copy never
+// reads memory the caller may free, and no stream synchronisation is needed.
+struct PinnedStage {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    ssw_status push(void *dev_dst, const void *src, size_t bytes, hipStream_t stream);
+    void release();
+};
+
+// ---- launchers implemented in the kernel translation units -----------------
+
+// scan.hip: scores[i] = dot(X[i,:], q) in the fixed kernel order (see scan.hip).
+ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_t n, int32_t dim,
+                       int device, hipStream_t stream);
+// rng.hip: synthetic unit-norm rows.
+ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
+                              hipStream_t stream);
+
+// select.hip: exact top-k of per-image best scores.
+struct SelectWorkspace {
+    // all device pointers
+    uint32_t *hist1 = nullptr;      // [4096]
+    uint32_t *hist2 = nullptr;      // [4096]
+    uint32_t *state = nullptr;      // [16] see select.hip
+    uint64_t *cand = nullptr;       // [SELECT_CAND_CAP]
+    uint64_t *out_keys = nullptr;   // [SSW_MAX_TOPK]
+    int32_t *out_count = nullptr;   // [1]
+    uint32_t *out_best = nullptr;   // [SSW_MAX_TOPK]
+    float *img_score = nullptr;     // [n_images]   (only when row2image is set)
+    uint32_t *img_best = nullptr;   // [n_images]
+    uint32_t *excl_bits = nullptr;  // [(n_images+31)/32]
+    int64_t *excl_ids = nullptr;    // device copy of the installed excluded-id list
+    PinnedStage excl_stage;
+    int64_t excl_ids_cap = 0;
+    int64_t n_excluded_distinct = 0;  // distinct excluded images currently installed
+    bool excl_dirty = false;          // bitmap currently has bits set
+};
+
+ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map);
+void select_free(SelectWorkspace &ws);
+// install the excluded set (host ids) into ws.excl_bits; counts distinct ids.
+ssw_status select_set_excluded(SelectWorkspace &ws, int64_t n_images, const int64_t *ids_host,
+                               int64_t n, hipStream_t stream);
+// per-image max over contiguous row ranges (row_start [n_images+1]).
+ssw_status launch_image_max(const float *scores, const int64_t *row_start, int64_t n_images,
+                            float *img_score, uint32_t *img_best, hipStream_t stream);
+// top-k over values[m] (f32), skipping ids whose excl bit is set. Results in ws.out_*.
+ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t m,
+                              const uint32_t *best_rows_or_null, int32_t k, int device,
+                              hipStream_t stream);
+// the fast path flags a 24-bit prefix bin with more candidates than the final sort can
+// take (massive exact ties); the caller then reruns the selection on the deep path.
+ssw_status select_check_overflow(SelectWorkspace &ws, hipStream_t stream, bool *overflow);
+ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,
+                                   const uint32_t *best_rows_or_null, int32_t k, int device,
+                                   hipStream_t stream);
+ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t list_stride,
+                             const int32_t *counts, int32_t k, uint64_t *keys_out,
+                             int32_t *count_out, hipStream_t stream);
+ssw_status launch_gather_f32(const float *src, const int64_t *idx_dev, int64_t n, float *dst,
+                             hipStream_t stream);
+
+}  // namespace ssw

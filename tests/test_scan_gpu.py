@@ -1,0 +1,149 @@
+"""GPU parity tests for the scan + top-k path (through the C-ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def DeviceIndex():
+    from seesaw_amd.device_index import DeviceIndex
+    return DeviceIndex
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 127, 1000, 10007])
+def test_synth_rows_bit_exact(DeviceIndex, oracle, n):
+    idx = DeviceIndex.synthetic(n, 512, seed=11, first_row=5)
+    got = idx.download()
+    ref = oracle.synth_rows(11, 5, n, 512)
+    assert np.array_equal(bits(got), bits(ref))
+    idx.close()
+
+
+@pytest.mark.parametrize("dim", [256, 512, 768, 1024])
+@pytest.mark.parametrize("n", [1, 64, 65, 4097, 20011])
+def test_scores_bit_exact_vs_kernel_order_oracle(DeviceIndex, oracle, n, dim):
+    X = oracle.synth_rows(3, 100, n, dim)
+    q = oracle.synth_query(1, dim)
+    idx = DeviceIndex.from_numpy(X)
+    got = idx.scores(q)
+    ref = oracle.scores_kernel_order(X, q)
+    assert np.array_equal(bits(got), bits(ref)), f"max abs diff {np.abs(got - ref).max()}"
+    # and within f32 rounding of the reference expression `vectors @ q`
+    assert np.abs(got - oracle.scores_reference(X, q)).max() <= oracle.rounding_band(X, q)
+    idx.close()
+
+
+def test_scores_general_values(DeviceIndex, oracle):
+    rng = np.random.default_rng(0)
+    X = (rng.standard_normal((5000, 512)) * np.exp(rng.uniform(-20, 20, (5000, 1)))).astype(np.float32)
+    q = rng.standard_normal(512).astype(np.float32)
+    idx = DeviceIndex.from_numpy(X)
+    assert np.array_equal(bits(idx.scores(q)), bits(oracle.scores_kernel_order(X, q)))
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [1, 10, 100, 1000, 4096])
+@pytest.mark.parametrize("tiles", [1, 13])
+def test_topk_images_vs_oracle(DeviceIndex, oracle, k, tiles):
+    n = 50000
+    X = oracle.synth_rows(5, 0, n, 512)
+    q = oracle.synth_query(2)
+    row2image = None if tiles == 1 else (np.arange(n) // tiles).astype(np.int32)
+    n_images = n if tiles == 1 else int(row2image[-1]) + 1
+    rng = np.random.default_rng(k)
+    excluded = rng.choice(n_images, size=min(500, n_images // 2), replace=False)
+    idx = DeviceIndex.from_numpy(X, row2image=row2image)
+    imgs, scores, rows = idx.topk(q, k, excluded=excluded)
+    ref_scores = oracle.scores_kernel_order(X, q)
+    o_imgs, o_scores, o_rows = oracle.topk_images_tiebreak(ref_scores, row2image, n_images, excluded, k)
+    assert np.array_equal(imgs, o_imgs)
+    assert np.array_equal(bits(scores), bits(o_scores))
+    assert np.array_equal(rows, o_rows)
+    # set parity against the reference expression (BLAS order + argsort), band rule
+    ok, msg = oracle.check_topk_against_reference(imgs, oracle.scores_reference(X, q), row2image,
+                                                  excluded, k, oracle.rounding_band(X, q))
+    assert ok, msg
+    idx.close()
+
+
+def test_topk_ragged_images_and_reuse(DeviceIndex, oracle):
+    rng = np.random.default_rng(1)
+    counts = rng.integers(1, 40, size=3000)
+    row2image = np.repeat(np.arange(3000), counts).astype(np.int32)
+    n = row2image.shape[0]
+    X = oracle.synth_rows(9, 0, n, 512)
+    idx = DeviceIndex.from_numpy(X, row2image=row2image)
+    returned = []
+    q = oracle.synth_query(4)
+    ref_scores = oracle.scores_kernel_order(X, q)
+    for rnd in range(5):  # the exclusion list grows like InteractiveQuery.returned
+        imgs, scores, rows = idx.topk(q if rnd == 0 else None, 50, excluded=returned)
+        o_imgs, o_scores, o_rows = oracle.topk_images_tiebreak(ref_scores, row2image, 3000, returned, 50)
+        assert np.array_equal(imgs, o_imgs) and np.array_equal(rows, o_rows)
+        assert np.array_equal(bits(scores), bits(o_scores))
+        g = idx.gather_scores(rows)
+        assert np.array_equal(bits(g), bits(scores))
+        returned.extend(imgs[:10].tolist())
+    idx.close()
+
+
+def test_topk_fewer_than_k_and_all_excluded(DeviceIndex, oracle):
+    X = oracle.synth_rows(2, 0, 300, 512)
+    q = oracle.synth_query(0)
+    idx = DeviceIndex.from_numpy(X)
+    imgs, scores, rows = idx.topk(q, 1000)
+    assert imgs.shape[0] == 300
+    ref = oracle.topk_images_tiebreak(oracle.scores_kernel_order(X, q), None, 300, [], 1000)
+    assert np.array_equal(imgs, ref[0])
+    imgs, _, _ = idx.topk(q, 10, excluded=range(300))
+    assert imgs.shape[0] == 0
+    imgs, _, _ = idx.topk(q, 10, excluded=range(295))
+    assert sorted(imgs.tolist()) == [295, 296, 297, 298, 299]
+    idx.close()
+
+
+def test_topk_massive_ties_take_deep_path(DeviceIndex, oracle):
+    # 30000 identical rows + a few better ones: more candidates share one score than the
+    # final sort can hold, so the selection must fall back to the deep radix path and
+    # still return the lowest image positions among the ties.
+    base = oracle.synth_rows(1, 0, 1, 512)[0]
+    q = base.copy()
+    X = np.repeat(base[None, :] * np.float32(0.5), 30000, axis=0)
+    better = oracle.synth_rows(1, 0, 20, 512)
+    better[:] = base[None, :] * np.linspace(0.6, 0.9, 20, dtype=np.float32)[:, None]
+    pos = np.arange(20) * 1000 + 7
+    X[pos] = better
+    idx = DeviceIndex.from_numpy(X)
+    for k in (10, 20, 21, 100, 4096):
+        imgs, scores, rows = idx.topk(q, k)
+        ref = oracle.topk_images_tiebreak(oracle.scores_kernel_order(X, q), None, 30000, [], k)
+        assert np.array_equal(imgs, ref[0]), k
+        assert np.array_equal(bits(scores), bits(ref[1]))
+    idx.close()
+
+
+def test_nan_query_rejected(DeviceIndex, oracle):
+    from seesaw_amd._lib import SeesawHipError
+    idx = DeviceIndex.synthetic(128, 512, seed=0)
+    q = oracle.synth_query(0)
+    q[5] = np.nan
+    with pytest.raises(SeesawHipError):
+        idx.scores(q)
+    idx.close()
+
+
+def test_scan_of_device_generated_shard(DeviceIndex, oracle):
+    # a shard generated on the device is scanned without ever touching the host
+    n, first = 200000, 12345678
+    idx = DeviceIndex.synthetic(n, 512, seed=42, first_row=first)
+    q = oracle.synth_query(9)
+    imgs, scores, rows = idx.topk(q, 100)
+    X = oracle.synth_rows(42, first, n, 512)
+    ref = oracle.topk_images_tiebreak(oracle.scores_kernel_order(X, q), None, n, [], 100)
+    assert np.array_equal(imgs, ref[0]) and np.array_equal(bits(scores), bits(ref[1]))
+    idx.close()
