@@ -1,0 +1,147 @@
+"""Row-sharded index: one process per GPU, each scanning its contiguous slice of the rows,
+one RCCL all-gather of the per-shard top-k over xGMI, deterministic merge on every rank.
+
+The reference has no counterpart (its index is a single numpy array in host RAM,
+seesaw/indices/multiscale/multiscale_index.py:220); this is the multi-GPU form of the
+same `_get_top_exact` + `_get_top_dbidxs` selection (multiscale_index.py:170-199).
+
+Shards are cut at image boundaries (rows are stored sorted by image, coarse_index.py:49),
+so the per-image max never crosses a rank and the only exchange is k x 8 bytes per rank:
+the composite keys (score_key << 32 | ~image) produced by the select kernels, made global
+by subtracting the shard's first image position.  The payload is ~1 KB per rank, i.e. the
+collective is latency-bound: one fused all_gather_into_tensor, never a ring of sends.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of n_total units: [lo, hi) of `rank`."""
+    assert 0 <= rank < world
+    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+
+
+def shard_bounds_by_image(row_start: np.ndarray, world: int, rank: int) -> Tuple[int, int, int, int]:
+    """Partition rows at image boundaries so that every rank gets ~n_rows/world rows.
+    row_start: [n_images+1] first row of every image.  Returns (img_lo, img_hi, row_lo, row_hi)."""
+    n_images = row_start.shape[0] - 1
+    n_rows = int(row_start[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = (r * n_rows) // world
+        cuts.append(int(np.searchsorted(row_start, target, side="left")))
+    cuts.append(n_images)
+    cuts = np.maximum.accumulate(np.minimum(cuts, n_images))
+    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+    return lo, hi, int(row_start[lo]), int(row_start[hi])
+
+
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch.as_tensor()."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def merge_keys_hip(device: int, stream_ptr: int, keys, counts, k: int, out_keys, out_count):
+    """Global top-k of `world` sorted key lists on the GPU (ssw_topk_merge_dev)."""
+    world, stride = keys.shape
+    _lib.call("ssw_topk_merge_dev", int(device), ctypes.c_void_p(stream_ptr),
+              ctypes.c_void_p(keys.data_ptr()), int(world), int(stride),
+              ctypes.c_void_p(counts.data_ptr()), int(k), ctypes.c_void_p(out_keys.data_ptr()),
+              ctypes.c_void_p(out_count.data_ptr()))
+
+
+class ShardedTopK:
+    """Exchange + merge step shared by every sharded index.  `local_topk(k)` must leave the
+    shard's sorted composite keys / count in (keys_ptr, count_ptr) device buffers."""
+
+    def __init__(self, *, rank: int, world: int, device, image_offset: int, k_max: int,
+                 group=None, merge=merge_keys_hip):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self.device = device
+        self.image_offset = int(image_offset)
+        self.group = group
+        self.merge = merge
+        self.k_max = int(k_max)
+        dev = device
+        self.send_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
+        self.send_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.all_keys = torch.zeros((world, self.k_max), dtype=torch.int64, device=dev)
+        self.all_counts = torch.zeros(world, dtype=torch.int32, device=dev)
+        self.out_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
+        self.out_count = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def exchange(self, local_keys, local_count, k: int):
+        """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys), local ids.
+        Returns (out_keys[k_max], out_count[1]) holding the global top-k on every rank."""
+        torch = self.torch
+        assert k <= self.k_max
+        # globalise: low 32 bits hold 0xFFFFFFFF - local_id, so subtracting the shard's
+        # first image position yields 0xFFFFFFFF - global_id (no borrow: ids < 2^32)
+        self.send_keys[:k] = local_keys[:k] - self.image_offset
+        self.send_count.copy_(local_count)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.all_keys, self.send_keys, group=self.group)
+            dist.all_gather_into_tensor(self.all_counts, self.send_count, group=self.group)
+        else:
+            self.all_keys[0] = self.send_keys
+            self.all_counts[0] = self.send_count[0]
+        stream_ptr = torch.cuda.current_stream().cuda_stream if self.all_keys.is_cuda else 0
+        dev_index = self.all_keys.device.index if self.all_keys.is_cuda else -1
+        self.merge(dev_index, stream_ptr, self.all_keys, self.all_counts, k, self.out_keys,
+                   self.out_count)
+        return self.out_keys, self.out_count
+
+
+class ShardedSyntheticIndex:
+    """BASELINE config C4: N_total x dim synthetic rows, one vector per image, row-sharded
+    over the ranks of the default process group; each rank generates its slice in place."""
+
+    def __init__(self, n_total: int, dim: int, seed: int, rank: int, world: int,
+                 local_device: int, k_max: int = 128, group=None):
+        import torch
+        from .device_index import DeviceIndex
+        self.torch = torch
+        self.n_total, self.dim = int(n_total), int(dim)
+        self.rank, self.world = rank, world
+        self.row_lo, self.row_hi = shard_bounds(self.n_total, world, rank)
+        self.n_local = self.row_hi - self.row_lo
+        self.device = torch.device("cuda", local_device)
+        self.local = DeviceIndex.synthetic(self.n_local, dim, seed=seed, first_row=self.row_lo,
+                                           device=local_device)
+        # run the library's kernels on torch's current stream so the collective and the
+        # merge are ordered behind the scan without host synchronisation
+        self.local.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        keys_ptr, count_ptr, _ = self.local.result_ptrs()
+        self.local_keys = torch.as_tensor(_DevArray(keys_ptr, (_lib.SSW_MAX_TOPK,), "<i8"),
+                                          device=self.device)
+        self.local_count = torch.as_tensor(_DevArray(count_ptr, (1,), "<i4"), device=self.device)
+        self.xchg = ShardedTopK(rank=rank, world=world, device=self.device,
+                                image_offset=self.row_lo, k_max=k_max, group=group)
+
+    def topk_async(self, q_dev_ptr: int, k: int):
+        """scan + local select + all-gather + merge, all enqueued on the current stream."""
+        self.local.topk_dev(q_dev_ptr, k)
+        return self.xchg.exchange(self.local_keys, self.local_count, k)
+
+    def topk(self, q_dev_ptr: int, k: int):
+        from .device_index import decode_keys
+        keys, count = self.topk_async(q_dev_ptr, k)
+        self.torch.cuda.synchronize(self.device)
+        c = int(count.item())
+        imgs, scores = decode_keys(keys[:c].cpu().numpy().view(np.uint64))
+        return imgs, scores
+
+    def close(self):
+        self.local.close()
