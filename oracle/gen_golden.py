@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from
+/root/reference through oracle/_ref_import.py) on seeded synthetic inputs.
+
+Run in the build container only:   python oracle/gen_golden.py [family ...]
+The fixtures are data (inputs or the seeds that regenerate them, plus the reference's
+outputs); no reference source travels.  Large inputs are regenerated from seeds with the
+bit-exact synthetic generator (oracle.seesaw_oracle.synth_rows), so the fixtures stay small.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _ref_import as R  # noqa: E402
+from oracle import seesaw_oracle as orc  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLDEN, exist_ok=True)
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+def synth_vector_meta(n_images, tiles_per_image, dbidx_of_position, rng):
+    """vector_meta as the reference's MultiscaleIndex holds it (multiscale_index.py:257-259):
+    one row per tile: dbidx, zoom_level, x1, y1, x2, y2; rows sorted by dbidx."""
+    import pandas as pd
+    rows = []
+    for pos in range(n_images):
+        t = tiles_per_image[pos]
+        for j in range(t):
+            zoom = 0 if j < max(1, t - 1) else 1
+            x1 = float(rng.integers(0, 400))
+            y1 = float(rng.integers(0, 300))
+            side = 224.0 * (1 + zoom)
+            rows.append((int(dbidx_of_position[pos]), zoom, x1, y1, x1 + side, y1 + side))
+    df = pd.DataFrame(rows, columns=["dbidx", "zoom_level", "x1", "y1", "x2", "y2"])
+    df = df.assign(zoom_level=df.zoom_level.astype("int16"),
+                   **{c: df[c].astype("float32") for c in ["x1", "y1", "x2", "y2"]})
+    return df
+
+
+# ------------------------------------------------------------------------------------
+def gen_scan_topk():
+    """(i) _query_prelim(force_exact=True) and CoarseIndex.query on seeded vectors."""
+    import pandas as pd
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    coarse = R.ref("seesaw.indices.coarse.coarse_index")
+    pr = sys.modules["pyroaring"]
+
+    # known-answer pin the reference itself carries (multiscale_index.py:182-187)
+    msi.test_distinct_topk_positions()
+
+    cases = []
+    for case_id, (n_images, tmax, k, n_excl, seed) in enumerate(
+            [(1539, 13, 50, 40, 101), (400, 1, 100, 0, 102), (997, 30, 50, 300, 103), (64, 5, 200, 10, 104)]):
+        rng = np.random.default_rng(seed)
+        tiles = np.full(n_images, tmax) if tmax in (1, 13) else rng.integers(1, tmax + 1, n_images)
+        dbidx_of_position = np.arange(n_images) * 3 + 5  # non-trivial dbidx values
+        meta = synth_vector_meta(n_images, tiles, dbidx_of_position, rng)
+        n = meta.shape[0]
+        X = orc.synth_rows(seed, 0, n, 512)
+        q = orc.synth_query(seed)
+        excl_pos = rng.choice(n_images, size=n_excl, replace=False) if n_excl else np.zeros(0, np.int64)
+        exclude = pr.BitMap(dbidx_of_position[excl_pos])
+        index = msi.MultiscaleIndex(embedding=None, vectors=X, vector_meta=meta, vec_index=None)
+        df = index._query_prelim(vector=q, topk_dbidx=k, exclude_dbidx=exclude, force_exact=True)
+        scores_full = index.score(q)
+        cases.append(dict(seed=seed, n_images=n_images, tiles=tiles, k=k, excl_pos=excl_pos,
+                          dbidx=df["dbidx"].values.astype(np.int64),
+                          max_score=df["max_score"].values.astype(np.float32),
+                          scores_head=scores_full[:256].astype(np.float32)))
+    out = {}
+    for i, c in enumerate(cases):
+        for key, v in c.items():
+            out[f"c{i}_{key}"] = np.asarray(v)
+    out["n_cases"] = np.asarray(len(cases))
+
+    # CoarseIndex.query (coarse_index.py:57-96)
+    n = 3000
+    Xc = orc.synth_rows(201, 0, n, 512)
+    qc = orc.synth_query(201)
+    dbidx = np.arange(n) * 2 + 1
+    cmeta = pd.DataFrame({"dbidx": dbidx})
+    cidx = coarse.CoarseIndex(embedding=None, vectors=Xc, vector_meta=cmeta)
+    excl = pr.BitMap(dbidx[np.random.default_rng(5).choice(n, 200, replace=False)])
+    res = cidx.query(topk=100, vector=qc, exclude=excl)
+    out["coarse_seed"] = np.asarray(201)
+    out["coarse_n"] = np.asarray(n)
+    out["coarse_excl"] = np.array(sorted(excl), dtype=np.int64)
+    out["coarse_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+    out["coarse_nextstartk"] = np.asarray(res["nextstartk"])
+    out["coarse_scores"] = np.array([a.score.values[0] for a in res["activations"]], dtype=np.float32)
+    save("scan_topk", **out)
+
+
+# ------------------------------------------------------------------------------------
+def gen_multiscale_query():
+    """(ii) MultiscaleIndex.query(agg_method='plain_score') -- multiscale_index.py:314-403."""
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    pr = sys.modules["pyroaring"]
+    seed, n_images = 301, 800
+    rng = np.random.default_rng(seed)
+    tiles = rng.integers(1, 20, n_images)
+    dbidx_of_position = np.arange(n_images) * 7 + 2
+    meta = synth_vector_meta(n_images, tiles, dbidx_of_position, rng)
+    X = orc.synth_rows(seed, 0, meta.shape[0], 512)
+    q = orc.synth_query(seed)
+    index = msi.MultiscaleIndex(embedding=None, vectors=X, vector_meta=meta, vec_index=None)
+    out = dict(seed=np.asarray(seed), n_images=np.asarray(n_images), tiles=tiles,
+               meta=meta[["dbidx", "zoom_level", "x1", "y1", "x2", "y2"]].values.astype(np.float64))
+    returned = pr.BitMap()
+    for rnd in range(4):
+        res = index.query(vector=q, topk=5, shortlist_size=50, exclude=returned, force_exact=True,
+                          agg_method="plain_score", aug_larger="all",
+                          rescore_method=lambda vecs: vecs @ q.reshape(-1, 1))
+        out[f"r{rnd}_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+        acts = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64)
+                         for a in res["activations"]])
+        out[f"r{rnd}_activations"] = acts
+        returned.update(res["dbidxs"])
+    # vector2 form (multiscale_index.py:347-349)
+    q2 = orc.synth_query(seed + 1)
+    res = index.query(vector=q, vector2=q2, topk=5, shortlist_size=50, exclude=pr.BitMap(), force_exact=True,
+                      agg_method="plain_score", aug_larger="all", rescore_method=None)
+    out["v2_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+    out["v2_scores"] = np.array([a.score.values[0] for a in res["activations"]], dtype=np.float64)
+    save("multiscale_query", **out)
+
+
+# ------------------------------------------------------------------------------------
+def gen_labelprop():
+    """(iii) compute_exact_knn -> get_weight_matrix -> LabelPropagation.fit_transform
+    (knn_graph.py:31-104,170-191; label_propagation.py:6-79; knn_methods.py:97-199)."""
+    kg = R.ref("seesaw.knn_graph")
+    lp = R.ref("seesaw.label_propagation")
+    km = R.ref("seesaw.research.knn_methods")
+    seed, n, k = 401, 1500, 10
+    X = orc.synth_rows(seed, 0, n, 512)
+    # clustered data so the graph is not trivial: mix rows with 20 centres
+    rng = np.random.default_rng(seed)
+    centres = orc.synth_rows(seed + 1, 0, 20, 512)
+    assign = rng.integers(0, 20, n)
+    X = X + 1.5 * centres[assign]
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    df = kg.compute_exact_knn(X, n_neighbors=k)
+    graph = kg.KNNGraph(df).restrict_k(k=k)
+    out = dict(seed=np.asarray(seed), n=np.asarray(n), k=np.asarray(k), X=X.astype(np.float32),
+               src=df.src_vertex.values, dst=df.dst_vertex.values, dist=df.distance.values,
+               rank=df.dst_rank.values, restricted_rows=np.asarray(graph.knn_df.shape[0]))
+    for name, edist, symmetric in [("e05", 0.05, True), ("e10", 0.1, True), ("asym", 0.05, False)]:
+        W = kg.get_weight_matrix(graph.knn_df, kfun=kg.rbf_kernel(edist), self_edges=False,
+                                 normalized=False, symmetric=symmetric)
+        out[f"{name}_indptr"] = W.indptr.astype(np.int64)
+        out[f"{name}_indices"] = W.indices.astype(np.int64)
+        out[f"{name}_data"] = W.data.astype(np.float64)
+    # Laplacian and xlx (graph_based.py:45-49)
+    L = kg.get_weight_matrix(graph.knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False,
+                             symmetric=True, laplacian=True)
+    Ln = L / L.diagonal().sum()
+    xlx = X.T @ (Ln @ X)
+    out["lap_indptr"], out["lap_indices"], out["lap_data"] = L.indptr.astype(np.int64), L.indices.astype(np.int64), L.data
+    out["xlx"] = np.asarray(xlx, dtype=np.float64)
+
+    W = kg.get_weight_matrix(graph.knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False,
+                             symmetric=True)
+    q = centres[3]
+    base_scores = X @ q
+    n_runs = 0
+    for lam in [0.0, 1.0, 3.0]:
+        for n_lab in [0, 6, 40]:
+            counter = {"n": 0}
+            model = lp.LabelPropagation(W, reg_lambda=lam, max_iter=300)
+            orig_step = model._step
+
+            def counting_step(*a, _o=orig_step, **kw):
+                counter["n"] += 1
+                return _o(*a, **kw)
+
+            model._step = counting_step
+            prior = km.sigmoid(10.0 * (base_scores + (-0.2))).astype(np.float64)
+            lab_ids = rng.choice(n, n_lab, replace=False) if n_lab else np.zeros(0, np.int64)
+            lab_vals = (assign[lab_ids] == 3).astype(np.float64)
+            reg = prior if lam > 0 else None
+            start = prior.copy()
+            res = model.fit_transform(label_ids=lab_ids, label_values=lab_vals, reg_values=reg,
+                                      start_value=start)
+            out[f"run{n_runs}_lam"] = np.asarray(lam)
+            out[f"run{n_runs}_ids"] = lab_ids.astype(np.int64)
+            out[f"run{n_runs}_vals"] = lab_vals
+            out[f"run{n_runs}_start"] = start
+            out[f"run{n_runs}_out"] = np.asarray(res, dtype=np.float64)
+            out[f"run{n_runs}_steps"] = np.asarray(counter["n"])
+            n_runs += 1
+    out["n_runs"] = np.asarray(n_runs)
+
+    # LabelPropagationRanker2 driver: set_base_scores / update / top_k (knn_methods.py:97-199)
+    ranker = km.LabelPropagationRanker2(weight_matrix=W, normalize_scores=False, sigmoid_before_propagate=True,
+                                        calib_a=10.0, calib_b=-0.2, prior_weight=1.0)
+    ranker.set_base_scores(base_scores)
+    ids0, sc0 = ranker.top_k(k=20)
+    out["rk_base_scores"] = base_scores.astype(np.float32)
+    out["rk_top0_ids"], out["rk_top0_scores"] = ids0, sc0
+    upd_ids = np.concatenate([ids0[:5], rng.choice(n, 5, replace=False)])
+    upd_labels = (assign[upd_ids] == 3).astype(np.float64)
+    upd_labels[-1] = 0.0  # make sure there is a negative so propagation runs
+    ranker.update(upd_ids, upd_labels)
+    ids1, sc1 = ranker.top_k(k=20)
+    out["rk_upd_ids"], out["rk_upd_labels"] = upd_ids.astype(np.int64), upd_labels
+    out["rk_top1_ids"], out["rk_top1_scores"] = ids1, sc1
+    out["rk_scores1"] = np.asarray(ranker.current_scores(), dtype=np.float64)
+    out["assign"] = assign
+    save("labelprop", **out)
+
+
+# ------------------------------------------------------------------------------------
+def gen_rank_loss():
+    """(v) the reference's known-answer table (seesaw/test_rank_loss.py:9-234) re-evaluated by
+    the reference's own functions, plus seeded random cases (rank_loss.py:3-187)."""
+    import torch
+    rl = R.ref("seesaw.rank_loss")
+    trl = R.ref("seesaw.test_rank_loss")
+    tests = trl.TEST_CASES if hasattr(trl, "TEST_CASES") else None
+    cases = []
+    if tests is None:
+        # locate the table whatever it is called
+        for name in dir(trl):
+            v = getattr(trl, name)
+            if isinstance(v, (list, tuple)) and len(v) > 5 and isinstance(v[0], dict):
+                tests = v
+                break
+    assert tests is not None, "rank-loss known-answer table not found"
+    out = {}
+    for i, case in enumerate(tests):
+        target = torch.as_tensor(case["target"]).float()
+        scores = torch.as_tensor(case["scores"]).float()
+        margin = float(case.get("margin", 0.0))
+        out[f"t{i}_target"], out[f"t{i}_scores"], out[f"t{i}_margin"] = target.numpy(), scores.numpy(), np.asarray(margin)
+        out[f"t{i}_inversions"] = rl.ref_signed_inversions(target, scores=scores, margin=margin).numpy()
+        out[f"t{i}_loss"] = rl.ref_pairwise_rank_loss(target, scores=scores, margin=margin).numpy()
+        out[f"t{i}_grad"] = rl.ref_pairwise_rank_loss_gradient(target, scores=scores, margin=margin).numpy()
+        for key in case:
+            if key not in ("target", "scores", "margin"):
+                try:
+                    out[f"t{i}_expected_{key}"] = np.asarray(torch.as_tensor(case[key]).numpy(), dtype=np.float64)
+                except Exception:
+                    pass
+    out["n_table"] = np.asarray(len(tests))
+    rng = np.random.default_rng(7)
+    for i in range(6):
+        n = int(rng.integers(2, 60))
+        target = torch.from_numpy(rng.integers(0, 3 if i % 2 else 2, n).astype(np.float32))
+        scores = torch.from_numpy(np.round(rng.standard_normal(n), 1 if i < 3 else 5).astype(np.float32))
+        margin = float([0.0, 0.2, 1.0][i % 3])
+        out[f"r{i}_target"], out[f"r{i}_scores"], out[f"r{i}_margin"] = target.numpy(), scores.numpy(), np.asarray(margin)
+        ls, mx = rl.ref_pairwise_rank_loss(target, scores=scores, margin=margin, aggregate="sum",
+                                           return_max_inversions=True)
+        out[f"r{i}_hinge_sum"], out[f"r{i}_max_inv"] = ls.numpy(), mx.numpy()
+        ll, _ = rl.ref_pairwise_logistic_loss(target, scores=scores, aggregate="sum", return_max_inversions=True)
+        out[f"r{i}_logistic_sum"] = ll.numpy()
+        out[f"r{i}_hinge_grad"] = rl.ref_pairwise_rank_loss_gradient(target, scores=scores, margin=margin).numpy()
+        g, maxrev, total = rl.quick_pairwise_gradient_zero_margin(target, scores=scores, return_max_inversions=True)
+        out[f"r{i}_quick_grad"], out[f"r{i}_quick_maxrev"], out[f"r{i}_quick_total"] = g.numpy(), maxrev.numpy(), np.asarray(total)
+        out[f"r{i}_cheap_loss"] = rl.cheap_pairwise_rank_loss(target, scores=scores).numpy()
+    out["n_random"] = np.asarray(6)
+    save("rank_loss", **out)
+
+
+# ------------------------------------------------------------------------------------
+def _labelled_set(seed, n, n_pos, dim=512):
+    """A small labelled set shaped like q.getXy(): tile vectors of seen images."""
+    rng = np.random.default_rng(seed)
+    target = orc.synth_query(seed)
+    X = orc.synth_rows(seed, 0, n, dim)
+    y = np.zeros(n)
+    pos = rng.choice(n, n_pos, replace=False)
+    X[pos] = X[pos] + 0.6 * target
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    y[pos] = 1.0
+    q = target + 0.8 * orc.synth_query(seed + 77)
+    q = (q / np.linalg.norm(q)).astype(np.float32)
+    return X, y, q
+
+
+def gen_logreg():
+    """(iv-a) LogisticRegressionPT.fit -> get_coeff (logistic_regression.py:270-421)."""
+    import torch
+    lr = R.ref("seesaw.logistic_regression")
+    out = {}
+    i = 0
+    for (n, n_pos, lam, cw, with_weights) in [(40, 6, 1.0, "balanced", False), (300, 30, 3.3, "balanced", False),
+                                              (120, 10, 10.0, 1.0, True), (13, 1, 1.0, "balanced", False)]:
+        X, y, q = _labelled_set(500 + i, n, n_pos)
+        captured = {}
+        orig_init = lr.LogisticRegModule.__init__
+
+        def patched(self, *a, _o=orig_init, **kw):
+            _o(self, *a, **kw)
+            captured["w0"] = self.linear.weight.detach().clone().numpy()
+            captured["b0"] = None if self.linear.bias is None else self.linear.bias.detach().clone().numpy()
+
+        lr.LogisticRegModule.__init__ = patched
+        try:
+            torch.manual_seed(1000 + i)
+            model = lr.LogisticRegressionPT(class_weights=cw, scale="centered", reg_lambda=lam,
+                                            regularizer_vector=q, fit_intercept=False, max_iter=200, lr=1.0)
+            sw = None
+            if with_weights:
+                sw = np.ones((n, 1))
+                sw[: n // 3] = 4.0
+            model.fit(X, y.reshape(-1, 1), sw)
+        finally:
+            lr.LogisticRegModule.__init__ = orig_init
+        out[f"c{i}_X"], out[f"c{i}_y"], out[f"c{i}_q"] = X, y, q
+        out[f"c{i}_lam"] = np.asarray(lam)
+        out[f"c{i}_cw"] = np.asarray(-1.0 if cw == "balanced" else cw)
+        out[f"c{i}_sw"] = np.zeros(0) if sw is None else sw.reshape(-1)
+        out[f"c{i}_w0"] = captured["w0"]
+        out[f"c{i}_coeff"] = model.get_coeff()
+        out[f"c{i}_losses"] = np.array([l["loss"] for l in model.losses_], dtype=np.float64)
+        out[f"c{i}_proba"] = model.predict_proba(X).reshape(-1)
+        i += 1
+    out["n_cases"] = np.asarray(i)
+    save("logreg", **out)
+
+
+def gen_multireg():
+    """(iv-b) RegModule.fit -> get_coeff for the three label losses (loops/multi_reg.py:24-200)."""
+    import pandas as pd
+    import torch
+    mr = R.ref("seesaw.loops.multi_reg")
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    xlx = torch.from_numpy(g["xlx"]).float()
+    out = {"xlx": g["xlx"].astype(np.float32)}
+    i = 0
+    for loss_type in ["ce_loss", "pairwise_rank_loss", "pairwise_logistic_loss"]:
+        for (n, n_pos, data_lam, query_lam) in [(60, 8, 0.0, 0.0), (150, 20, 1000.0, 10.0)]:
+            X, y, q = _labelled_set(700 + i, n, n_pos)
+            # tiles grouped into images of 1..5 vectors
+            rng = np.random.default_rng(i)
+            img = np.sort(rng.integers(0, max(2, n // 3), n))
+            matchdf = pd.DataFrame({"dbidx": img, "ys": y, "max_iou": y * 0.5})
+            model = mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(),
+                                 label_loss_type=loss_type, rank_loss_margin=0.2,
+                                 reg_data_lambda=data_lam, reg_norm_lambda=100.0, use_qvec_norm=None,
+                                 reg_query_lambda=query_lam, verbose=False, max_iter=200,
+                                 pos_weight="balanced", lr=1.0)
+            losses = model.fit(X, y, matchdf)
+            out[f"c{i}_X"], out[f"c{i}_y"], out[f"c{i}_q"], out[f"c{i}_img"] = X, y, q, img
+            out[f"c{i}_loss_type"] = np.asarray(loss_type)
+            out[f"c{i}_data_lam"], out[f"c{i}_query_lam"] = np.asarray(data_lam), np.asarray(query_lam)
+            out[f"c{i}_coeff"] = model.get_coeff()
+            out[f"c{i}_raw_weight"] = model.weight.detach().numpy()
+            out[f"c{i}_losses"] = np.array([l["loss"] for l in losses], dtype=np.float64)
+            # one loss/gradient evaluation at w0 = normalised q (pins the fused loss kernel)
+            m0 = mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(),
+                              label_loss_type=loss_type, rank_loss_margin=0.2, reg_data_lambda=data_lam,
+                              reg_norm_lambda=100.0, use_qvec_norm=None, reg_query_lambda=query_lam,
+                              verbose=False, max_iter=200, pos_weight="balanced", lr=1.0)
+            vw = 1.0 / pd.Series(img).map(pd.Series(img).value_counts()).values
+            Xc = X - X.mean(axis=0).reshape(1, -1)
+            ret = m0._step((torch.from_numpy(Xc), torch.from_numpy(y), torch.from_numpy(vw)))
+            ret["loss"].backward()
+            out[f"c{i}_loss0"] = np.asarray(ret["loss"].item())
+            out[f"c{i}_grad0"] = m0.weight.grad.numpy().copy()
+            out[f"c{i}_parts0"] = np.array([ret[k].item() for k in ["loss_norm", "loss_datareg", "loss_queryreg", "loss_labels"]])
+            i += 1
+    out["n_cases"] = np.asarray(i)
+    save("multireg", **out)
+
+
+FAMILIES = {"scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
+            "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FAMILIES)
+    for nm in names:
+        print(f"== {nm}")
+        FAMILIES[nm]()
