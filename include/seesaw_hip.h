@@ -124,6 +124,11 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
 ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
                                    float *out_scores_host);
 
+/* scores of arbitrary rows against another vector, in the scan's summation order
+ * (`vectors[ilocs] @ vector2`, multiscale_index.py:347-349). */
+ssw_status ssw_index_score_rows(ssw_index *idx, const float *q_host, const int64_t *rows_host,
+                                int64_t n, float *out_scores_host);
+
 /* merge several sorted key lists (e.g. the all-gathered per-shard top-k of a
  * row-sharded index; keys as in ssw_index_result_ptrs but with GLOBAL image ids
  * added by the caller via id_offsets) into the global top-k.  All pointers device. */

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ssw_index_result_ptrs": (c_i32, [c_void_p, c_void_pp, c_void_pp, c_void_pp]),
     "ssw_index_topk_fetch": (c_i32, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32_p]),
     "ssw_index_gather_scores": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ssw_index_score_rows": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ssw_topk_merge_dev": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32,
                                    c_void_p, c_void_p]),
     "ssw_index_profile": (c_i32, [c_void_p, c_i32]),

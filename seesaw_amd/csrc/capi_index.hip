@@ -87,6 +87,9 @@ struct ssw_index {
     int64_t *gather_idx = nullptr;
     float *gather_out = nullptr;
     int64_t gather_cap = 0;
+    PinnedStage rows_stage;
+    float *q2_dev = nullptr;  // second query vector (score_rows)
+    PinnedStage q2_stage;
     // profiling of the scan kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -229,6 +232,9 @@ ssw_status ssw_index_destroy(ssw_index *idx) {
     (void)hipFree(idx->row_start);
     (void)hipFree(idx->gather_idx);
     (void)hipFree(idx->gather_out);
+    (void)hipFree(idx->q2_dev);
+    idx->rows_stage.release();
+    idx->q2_stage.release();
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
     return SSW_OK;
@@ -451,16 +457,11 @@ ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *ex
     return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
 }
 
-ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
-                                   float *out_scores_host) {
-    SSW_REQUIRE(idx != nullptr, "idx is NULL");
-    if (n <= 0) return SSW_OK;
-    SSW_REQUIRE(rows_host != nullptr && out_scores_host != nullptr, "NULL argument");
+static ssw_status stage_rows(ssw_index *idx, const int64_t *rows_host, int64_t n) {
     for (int64_t i = 0; i < n; ++i) {
         SSW_REQUIRE(rows_host[i] >= 0 && rows_host[i] < idx->n, "row %lld outside [0, %lld)",
                     (long long)rows_host[i], (long long)idx->n);
     }
-    DeviceGuard guard(idx->device);
     if (n > idx->gather_cap) {
         SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
         (void)hipFree(idx->gather_idx);
@@ -474,8 +475,34 @@ ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int
         SSW_HIP_TRY(hipMalloc((void **)&idx->gather_out, (size_t)cap * sizeof(float)));
         idx->gather_cap = cap;
     }
-    SSW_HIP_TRY(hipMemcpyAsync(idx->gather_idx, rows_host, (size_t)n * sizeof(int64_t),
-                               hipMemcpyHostToDevice, idx->stream));
+    return idx->rows_stage.push(idx->gather_idx, rows_host, (size_t)n * sizeof(int64_t), idx->stream);
+}
+
+ssw_status ssw_index_score_rows(ssw_index *idx, const float *q_host, const int64_t *rows_host,
+                                int64_t n, float *out_scores_host) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (n <= 0) return SSW_OK;
+    SSW_REQUIRE(q_host && rows_host && out_scores_host, "NULL argument");
+    SSW_TRY(check_query(idx, q_host));
+    DeviceGuard guard(idx->device);
+    SSW_TRY(stage_rows(idx, rows_host, n));
+    if (!idx->q2_dev) SSW_HIP_TRY(hipMalloc((void **)&idx->q2_dev, (size_t)idx->dim * sizeof(float)));
+    SSW_TRY(idx->q2_stage.push(idx->q2_dev, q_host, (size_t)idx->dim * sizeof(float), idx->stream));
+    SSW_TRY(launch_score_rows(idx->X, idx->q2_dev, idx->gather_idx, n, idx->dim, idx->gather_out,
+                              idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(out_scores_host, idx->gather_out, (size_t)n * sizeof(float),
+                               hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
+                                   float *out_scores_host) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (n <= 0) return SSW_OK;
+    SSW_REQUIRE(rows_host != nullptr && out_scores_host != nullptr, "NULL argument");
+    DeviceGuard guard(idx->device);
+    SSW_TRY(stage_rows(idx, rows_host, n));
     SSW_TRY(launch_gather_f32(idx->scores, idx->gather_idx, n, idx->gather_out, idx->stream));
     SSW_HIP_TRY(hipMemcpyAsync(out_scores_host, idx->gather_out, (size_t)n * sizeof(float),
                                hipMemcpyDeviceToHost, idx->stream));

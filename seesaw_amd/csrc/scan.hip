@@ -148,6 +148,28 @@ __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restric
     }
 }
 
+// scores of an explicit list of rows, same summation order as the full scan (one wave per
+// row, plain butterfly) -- stage-2 rescoring against a second vector
+// (multiscale_index.py:347-349).
+template <int C>
+__global__ __launch_bounds__(256) void score_rows_kernel(const float *__restrict__ X,
+                                                        const float *__restrict__ q,
+                                                        const int64_t *__restrict__ rows, int64_t n,
+                                                        float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n) return;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X);
+    RowFrag<C> qf;
+#pragma unroll
+    for (int c = 0; c < C; ++c) qf.v[c] = reinterpret_cast<const float4 *>(q)[c * 64 + lane];
+    const RowFrag<C> x = load_row<C>(X4, (int)rows[w], lane);
+    float v = dot_frag<C>(x, qf);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    if (lane == 0) out[w] = v;
+}
+
 template <int C, int U>
 ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t n, int device,
                          hipStream_t stream) {
@@ -190,6 +212,23 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
             set_error("scan: dim=%d unsupported (need a multiple of 256, <= 1024)", dim);
             return SSW_ERR_UNSUPPORTED;
     }
+}
+
+ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *rows_dev, int64_t n,
+                             int32_t dim, float *out, hipStream_t stream) {
+    if (n <= 0) return SSW_OK;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    switch (dim) {
+        case 256: hipLaunchKernelGGL(score_rows_kernel<1>, grid, block, 0, stream, X, q_dev, rows_dev, n, out); break;
+        case 512: hipLaunchKernelGGL(score_rows_kernel<2>, grid, block, 0, stream, X, q_dev, rows_dev, n, out); break;
+        case 768: hipLaunchKernelGGL(score_rows_kernel<3>, grid, block, 0, stream, X, q_dev, rows_dev, n, out); break;
+        case 1024: hipLaunchKernelGGL(score_rows_kernel<4>, grid, block, 0, stream, X, q_dev, rows_dev, n, out); break;
+        default:
+            set_error("score_rows: dim=%d unsupported", dim);
+            return SSW_ERR_UNSUPPORTED;
+    }
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
 }
 
 }  // namespace ssw

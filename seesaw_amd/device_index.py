@@ -137,6 +137,14 @@ class DeviceIndex:
         _lib.call("ssw_index_gather_scores", self._h, _ptr(rows), rows.shape[0], _ptr(out))
         return out
 
+    def score_rows(self, q: np.ndarray, rows: np.ndarray) -> np.ndarray:
+        """`vectors[rows] @ q` on the device, same summation order as the scan."""
+        q = self._query(q)
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty(rows.shape[0], dtype=np.float32)
+        _lib.call("ssw_index_score_rows", self._h, _ptr(q), _ptr(rows), rows.shape[0], _ptr(out))
+        return out
+
     # -- device-resident forms (bench / sharded index) --------------------------------
     def set_excluded(self, excluded: Optional[Iterable[int]]):
         ex = None

@@ -1,0 +1,248 @@
+"""MultiscaleIndex: many tile vectors per image, two-stage lookup on the GPU.
+
+Interface of seesaw/indices/multiscale/multiscale_index.py:201-442 (MultiscaleIndex,
+BoxFeedbackQuery, rescore_candidates, match_labels_to_vectors).
+
+stage 1 (reference :291-312 = `vectors @ q`, full `np.argsort`, pandas gather / isin /
+np.unique over all N rows): one HBM-streaming scan + fused per-image max + exact radix
+select of the top `shortlist_size` distinct non-excluded images (ssw_index_topk).
+stage 2 (reference :341-352, 379-403): the candidate images' tile scores are read back
+from the score buffer the scan left in HBM (ssw_index_gather_scores) -- no second matvec,
+no `isin` over N rows -- and aggregated per image on the host (<= shortlist_size groups).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+from ...bitmap import BitMap, FrozenBitMap
+from ...box_utils import box_join, left_iou_join
+from ...device_index import DeviceIndex
+from ...labeldb import LabelDB
+from ...query_interface import AccessMethod, InteractiveQuery
+from ..coarse.coarse_index import _positions_of
+from ..interface import resolve_path
+
+_ACT_COLS = ["x1", "y1", "x2", "y2", "dbidx", "score"]
+
+
+def distinct_topk_positions(dbidxs, topk):
+    """positions of the first occurrence of the first `topk` distinct values
+    (same contract as multiscale_index.py:177-180; kept for callers and tests)."""
+    _, first = np.unique(dbidxs, return_index=True)
+    return np.sort(first)[:topk]
+
+
+def match_labels_to_vectors(label_db: LabelDB, vec_meta: pd.DataFrame, target_description=None):
+    """tile rows of every seen image with ys = 1 iff the tile overlaps an accepted label box
+    (multiscale_index.py:65-83)."""
+    seen = np.asarray(label_db.get_seen(), dtype=np.int64)
+    vec_meta = vec_meta[np.isin(vec_meta.dbidx.values, seen)]
+    boxdf = label_db.get_box_df(return_description=True)
+    if target_description is not None:
+        target_df = boxdf[boxdf.description == target_description]
+    else:
+        target_df = boxdf[boxdf.marked_accepted > 0]
+    out = left_iou_join(vec_meta, target_df)
+    return out.assign(ys=(out.max_iou > 0).astype("float"))
+
+
+def _avg_score_per_tile(meta_df: pd.DataFrame, aug_larger: str, aug_weight: str = "level_max"):
+    """`avg_score` aggregation of one image's tiles (multiscale_index.py:112-150): every tile's
+    score becomes the mean, over zoom levels, of the score of the best-overlapping tile."""
+    from scipy.special import softmax
+    mdf = meta_df[["x1", "x2", "y1", "y2", "zoom_level", "score"]]
+    joined = box_join(mdf, mdf)
+    if aug_larger == "greater":
+        joined = joined[joined.zoom_level_right >= joined.zoom_level_left]
+    elif aug_larger == "adjacent":
+        joined = joined[joined.zoom_level_right == joined.zoom_level_left]
+    else:
+        assert aug_larger == "all", aug_larger
+    joined = joined.reset_index(drop=True)
+    if aug_weight == "level_max":
+        best = joined.groupby(["iloc_left", "zoom_level_right"]).iou.idxmax()
+        return joined.iloc[best.values].groupby("iloc_left").score_right.mean()
+    assert aug_weight == "cont_weighted", aug_weight
+    return joined.groupby("iloc_left").apply(lambda g: softmax(g.cont.values) @ g.score_right.values)
+
+
+def score_frame2(meta_df: pd.DataFrame, **aug_options):
+    """best tile of one image under the requested aggregation; one-row frame."""
+    agg_method = aug_options["agg_method"]
+    if agg_method != "plain_score":
+        meta_df = meta_df.reset_index(drop=True)
+        scores = _avg_score_per_tile(meta_df, aug_options["aug_larger"], aug_options.get("aug_weight", "level_max"))
+        meta_df = meta_df.assign(unadjusted_score=meta_df.score, score=scores)
+    return meta_df[meta_df.score == meta_df.score.max()].head(n=1)
+
+
+def rescore_candidates(fullmeta: pd.DataFrame, topk: int, **kwargs):
+    """per candidate image: aggregate tile scores, keep the best tile as its activation;
+    return the `topk` best images (multiscale_index.py:379-403)."""
+    fullmeta = fullmeta.reset_index(drop=True)
+    dbidxs, dbscores, activations = [], [], []
+    plain = kwargs.get("agg_method") == "plain_score"
+    if plain and fullmeta.shape[0]:
+        # vectorised form of the per-frame loop: first maximal row of every image
+        d = fullmeta.dbidx.values
+        s = fullmeta.score.values
+        order = np.lexsort((np.arange(d.shape[0]), -s, d))
+        firsts = order[np.concatenate(([True], d[order][1:] != d[order][:-1]))]
+        for i in firsts:
+            dbidxs.append(d[i])
+            dbscores.append(s[i])
+            activations.append(fullmeta.iloc[[i]][_ACT_COLS])
+    else:
+        for dbidx, frame_meta in fullmeta.groupby("dbidx"):
+            tup = score_frame2(frame_meta, **kwargs)
+            dbidxs.append(dbidx)
+            dbscores.append(tup.score.iloc[0])
+            activations.append(tup[_ACT_COLS])
+    dbidxs = np.asarray(dbidxs)
+    dbscores = np.asarray(dbscores, dtype=np.float64)
+    top = np.argsort(-dbscores, kind="stable")[:topk]
+    return {"dbidxs": dbidxs[top].astype("int"), "activations": [activations[i] for i in top]}
+
+
+class MultiscaleIndex(AccessMethod):
+    """implements a two stage lookup"""
+
+    def __init__(self, *, embedding, vectors: np.ndarray, vector_meta: pd.DataFrame, vec_index=None,
+                 min_zoom_level=1, path: str = None, excluded: BitMap = None, device: int = 0):
+        self.embedding = embedding
+        self.path = path
+        self.excluded = BitMap([]) if excluded is None else excluded
+        if min_zoom_level != 1:  # drop the finest zoom level except where it is the only one
+            print("WARNING: filtering out min_zoom_level")
+            zmax = vector_meta.groupby("dbidx").zoom_level.transform("max")
+            keep = ((vector_meta.zoom_level == zmax) | (vector_meta.zoom_level >= min_zoom_level)).values
+            vector_meta = vector_meta[keep].reset_index(drop=True)
+            vectors = vectors[keep]
+        self.vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        self.vector_meta = vector_meta.reset_index(drop=True)
+        self.vec_index = vec_index  # accepted for signature parity; the exact GPU scan is always used
+        row_dbidx = np.asarray(self.vector_meta.dbidx.values, dtype=np.int64)
+        assert np.all(np.diff(row_dbidx) >= 0), "rows must be sorted by dbidx (vectors.sorted.cached)"
+        self._row_dbidx = row_dbidx
+        self._dbidx, self._row2pos = np.unique(row_dbidx, return_inverse=True)
+        self._row_start = np.concatenate(([0], np.cumsum(np.bincount(self._row2pos))))
+        self.all_indices = FrozenBitMap(self._dbidx) - self.excluded
+        self.device = device
+        self._dev = DeviceIndex.from_numpy(self.vectors, row2image=self._row2pos.astype(np.int32), device=device)
+        self._resident_q = None
+
+    # ---- construction -----------------------------------------------------------------
+    @staticmethod
+    def from_path(index_path: str, *, use_vec_index=True, exclude=None, device: int = 0, **options):
+        """<index>/info.json {"constructor", "model", ...}; <index>/vectors.npy [N,512] f32;
+        <index>/vector_meta.parquet (dbidx, zoom_level, x1, y1, x2, y2), rows sorted by dbidx."""
+        index_path = resolve_path(index_path)
+        info = json.load(open(f"{index_path}/info.json"))
+        from ...models.embeddings import load_embedding
+        embedding = load_embedding(info.get("model"), device=device)
+        vectors = np.load(f"{index_path}/vectors.npy", mmap_mode="r")
+        meta = pd.read_parquet(f"{index_path}/vector_meta.parquet").reset_index(drop=True)
+        meta = meta[["dbidx", "zoom_level", "x1", "y1", "x2", "y2"]]
+        return MultiscaleIndex(embedding=embedding, vectors=np.asarray(vectors), vector_meta=meta,
+                               vec_index=None, path=index_path,
+                               excluded=info.get("excluded", None) if exclude is None else exclude, device=device)
+
+    def get_knng(self, path=None):
+        from ...knn_graph import KNNGraph
+        return KNNGraph.from_file(f"{self.path}/knn_graph/{path or ''}")
+
+    def string2vec(self, string: str):
+        vec = self.embedding.from_string(string=string)
+        return vec / np.linalg.norm(vec)
+
+    def score(self, vec):
+        self._resident_q = None
+        return self._dev.scores(vec)
+
+    def __len__(self):
+        return len(self.all_indices)
+
+    # ---- queries ----------------------------------------------------------------------
+    def _excluded_positions(self, exclude_dbidx) -> np.ndarray:
+        ids = [np.asarray(self.excluded, dtype=np.int64)]
+        if exclude_dbidx is not None:
+            ids.append(np.asarray(exclude_dbidx, dtype=np.int64))
+        return _positions_of(self._dbidx, np.unique(np.concatenate(ids)))
+
+    def _query_prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
+        """top `topk_dbidx` distinct non-excluded images by their best tile: DataFrame
+        (dbidx, max_score) in descending score order (multiscale_index.py:291-312)."""
+        excl_pos = self._excluded_positions(exclude_dbidx)
+        n_included = self._dbidx.shape[0] - excl_pos.shape[0]
+        topk_dbidx = min(int(topk_dbidx), n_included)
+        if topk_dbidx == 0:
+            print("no dbidx included")
+            return [], [], []
+        pos, scores, best_rows = self._dev.topk(vector, topk_dbidx, excluded=excl_pos)
+        self._resident_q = np.asarray(vector, dtype=np.float32).reshape(-1).copy()
+        df = pd.DataFrame({"dbidx": self._dbidx[pos], "max_score": scores})
+        df.attrs["positions"] = pos
+        df.attrs["best_rows"] = best_rows
+        return df
+
+    def _candidate_rows(self, positions: np.ndarray) -> np.ndarray:
+        positions = np.sort(np.asarray(positions, dtype=np.int64))
+        return np.concatenate([np.arange(self._row_start[p], self._row_start[p + 1]) for p in positions]) \
+            if positions.size else np.zeros(0, dtype=np.int64)
+
+    def query(self, *, vector, vector2=None, topk, shortlist_size, exclude=None, force_exact=False, **kwargs):
+        if shortlist_size is None:
+            shortlist_size = topk * 5
+        if shortlist_size < topk * 5:
+            print(f"Warning: shortlist_size parameter {shortlist_size} is small compared to topk param {topk}, "
+                  "you may consider increasing it")
+        candidate_df = self._query_prelim(vector=vector, topk_dbidx=shortlist_size, exclude_dbidx=exclude,
+                                          force_exact=force_exact)
+        if isinstance(candidate_df, tuple):  # nothing left to return
+            return {"dbidxs": np.zeros(0, dtype="int"), "activations": []}
+        ilocs = self._candidate_rows(candidate_df.attrs["positions"])
+        scores = self._dev.gather_scores(ilocs)  # tile scores of the scan that just ran
+        if vector2 is not None:
+            scores = scores - self._dev.score_rows(vector2, ilocs)
+        fullmeta = self.vector_meta.iloc[ilocs].assign(score=scores)
+        if kwargs.get("agg_method") == "avg_vector":
+            raise NotImplementedError("agg_method='avg_vector' is not part of the accelerated path")
+        return rescore_candidates(fullmeta, topk, **kwargs)
+
+    def new_query(self):
+        return BoxFeedbackQuery(self)
+
+    def get_data(self, dbidx) -> pd.DataFrame:
+        vmeta = self.vector_meta[self.vector_meta.dbidx == dbidx]
+        return vmeta.assign(vectors=list(self.vectors[vmeta.index]))
+
+    def subset(self, indices: BitMap) -> AccessMethod:
+        mask = np.isin(self._row_dbidx, np.asarray(indices, dtype=np.int64))
+        if mask.all():
+            return self
+        return MultiscaleIndex(embedding=self.embedding, vectors=self.vectors[mask],
+                               vector_meta=self.vector_meta[mask].reset_index(drop=True), vec_index=None,
+                               device=self.device)
+
+
+class BoxFeedbackQuery(InteractiveQuery):
+    index: MultiscaleIndex
+
+    def __init__(self, db):
+        super().__init__(db)
+        assert self.index is not None
+        self.all_dbidx = FrozenBitMap(self.index._dbidx)
+
+    def query_random(self, batch_size):
+        remaining = np.asarray(self.all_dbidx - self.returned, dtype=np.int64)
+        return {"dbidxs": np.random.permutation(remaining)[:batch_size].astype("int"), "activations": None}
+
+    def getXy(self, get_positions=False, target_description=None):
+        matched = match_labels_to_vectors(self.label_db, self.index.vector_meta, target_description=target_description)
+        if get_positions:
+            return matched.index[matched.ys > 0].values, matched.index[matched.ys == 0].values
+        return matched[["dbidx", "ys", "max_iou"]]
