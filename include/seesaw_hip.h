@@ -143,6 +143,31 @@ ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *
 ssw_status ssw_index_profile(ssw_index *idx, int32_t enable);
 ssw_status ssw_index_profile_read(ssw_index *idx, float *out_ms, int32_t cap, int32_t *out_n);
 
+/* ------------------------------------------------------------------------- */
+/* k-NN-graph label propagation                                               */
+/* replaces: LabelPropagation.fit_transform  seesaw/label_propagation.py:45-79 */
+/*           (scipy csr_matvec sweeps, <= 300 per refine: knn_methods.py:186)  */
+/* ------------------------------------------------------------------------- */
+typedef struct ssw_lp ssw_lp;
+
+/* W: n x n CSR with sorted column indices (get_weight_matrix, knn_graph.py:31-104);
+ * host arrays indptr [n+1] i64, indices [nnz] i32, data [nnz] f64.
+ * weight_sum = W.sum(0) [n] f64, or NULL to have it computed in scipy's order. */
+ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr_host,
+                                const int32_t *indices_host, const double *data_host,
+                                const double *weight_sum_host_or_null, ssw_lp **out);
+ssw_status ssw_labelprop_destroy(ssw_lp *lp);
+/* one fit_transform: prior = reg_values (NULL only with reg_lambda == 0), start = the
+ * start iterate (labels are clamped into it first), label ids/values, epsilon, max_iter.
+ * out_f [n] f64 = what the reference returns: the iterate that entered the converging
+ * sweep, or the last sweep's output without convergence.  *out_sweeps = sweeps run.
+ * SSW_ERR_NUMERIC if a sweep leaves [min(0,prior.min()), max(1,prior.max())] -- the
+ * reference's assert (label_propagation.py:36-40). */
+ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const double *start_host,
+                             const int64_t *label_ids, const double *label_vals, int64_t n_labels,
+                             double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
+                             int32_t *out_sweeps, int32_t *out_converged);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,3 +213,42 @@ def synth_rows(seed: int, first_row: int, n: int, dim: int = 512) -> np.ndarray:
 def synth_query(seed: int, dim: int = 512) -> np.ndarray:
     """Unit-norm query drawn from the same generator (row `2**40 + seed` of stream 0xC0FFEE)."""
     return synth_rows(0xC0FFEE, (1 << 40) + seed, 1, dim)[0]
+
+
+# --------------------------------------------------------------------------------------
+# label propagation
+# --------------------------------------------------------------------------------------
+def label_propagation(W, *, label_ids, label_values, reg_lambda, reg_values=None, start_value=None,
+                      max_iter=300, epsilon=1e-5):
+    """LabelPropagation.fit_transform -- seesaw/label_propagation.py:45-79 with _step (:30-43):
+    weighted = W @ f + lambda*reg; f' = weighted / (W.sum(0) + lambda); f'[ids] = values;
+    stop when max((f'-f)^2) < eps returning f (not f'); otherwise f <- f'.
+    Returns (scores, sweeps_run, converged)."""
+    n = W.shape[0]
+    weight_sum = np.asarray(W.sum(0)).reshape(-1)
+    if reg_values is None:
+        assert reg_lambda == 0
+        reg = np.zeros(n)
+    else:
+        reg = reg_values
+    if start_value is not None:
+        old = np.array(start_value, dtype=np.float64)
+    elif reg_values is not None:
+        old = np.array(reg_values, dtype=np.float64)
+    else:
+        old = np.zeros(n)
+    label_ids = np.asarray(label_ids, dtype=np.int64).reshape(-1)
+    old[label_ids] = label_values
+    low = min(0, reg.min())
+    high = max(1.0, reg.max())
+    sweeps, converged = 0, False
+    for _ in range(max_iter):
+        new = (W @ old + reg_lambda * reg) / (weight_sum + reg_lambda)
+        assert (new >= low).all() and (new <= high).all()
+        new[label_ids] = label_values
+        sweeps += 1
+        if np.max((new - old) ** 2) < epsilon:
+            converged = True
+            break
+        old = new
+    return old, sweeps, converged

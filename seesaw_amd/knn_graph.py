@@ -1,0 +1,154 @@
+"""k-NN graph -> sparse weight matrix (host-side, one-off per index) and the KNNGraph record.
+
+Interface of seesaw/knn_graph.py: `rbf_kernel` (:8-21), `get_weight_matrix` (:31-104),
+`post_process_graph_df` (:142-168), `compute_exact_knn` (:170-191), `KNNGraph` (:246-286).
+The weight matrix is built once per index and cached (the reference goes through Ray's
+object store for that); the sweeps that consume it run on the GPU
+(seesaw_amd.label_propagation).  The construction below is a vectorised restatement that
+yields the same CSR arrays (structure and f64 values) as the reference's COO fancy-index
+assignment; tests/test_graph_host.py pins it against matrices captured from the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+
+def rbf_kernel(edist: float):
+    """weight = exp(-cosine_distance / edist): falls from 1 to 1/e when distance grows by edist."""
+    assert edist > 0
+    spread = 1.0 / edist
+
+    def kernel(arr):
+        arr = np.asarray(arr)
+        assert arr.size == 0 or (arr.min() >= -0.0001 and arr.max() <= 2.0001)
+        return np.exp(-(arr.astype("float64") * spread))
+
+    return kernel
+
+
+def knn_kernel(edist=2.1):
+    assert edist > 0.0
+    return lambda arr: (np.asarray(arr) <= edist).astype("float32")
+
+
+def get_weight_matrix(df: pd.DataFrame, *, kfun, self_edges=False, normalized, laplacian=False,
+                      symmetric=True):
+    """edges (src_vertex, dst_vertex, distance; one self edge per vertex) -> CSR weights.
+
+    symmetric: W_ij = (w_ij + w_ji) / (number of directed edges between i and j), i.e. the
+    mean over the directions present; the diagonal is zeroed but stays stored.
+    laplacian: D - W (and D^-1/2 (D - W) D^-1/2 when `normalized`)."""
+    assert not self_edges
+    src = df.src_vertex.values.astype(np.int64)
+    dst = df.dst_vertex.values.astype(np.int64)
+    n = np.unique(src).shape[0]
+    assert int((src == dst).sum()) == n, "every vertex needs exactly one self edge"
+    w = np.asarray(kfun(df.distance.values), dtype=np.float64)
+    assert (w >= 0).all(), "edge weights must be non-negative"
+    # weights that underflow to 0 keep their slot in the symmetric pattern (stored zeros),
+    # exactly like the reference's adjacency-driven assignment; the asymmetric form drops them
+    if symmetric:
+        rows, cols = np.concatenate([src, dst]), np.concatenate([dst, src])
+        wsum = sp.coo_array((np.concatenate([w, w]), (rows, cols)), shape=(n, n)).tocsr()
+        cnt = sp.coo_array((np.ones(2 * w.shape[0]), (rows, cols)), shape=(n, n)).tocsr()
+        wsum.sum_duplicates()
+        cnt.sum_duplicates()
+        wsum.sort_indices()
+        cnt.sort_indices()
+        assert np.array_equal(wsum.indices, cnt.indices) and np.array_equal(wsum.indptr, cnt.indptr)
+        out = sp.csr_array((wsum.data / cnt.data, wsum.indices.copy(), wsum.indptr.copy()), shape=(n, n))
+        assert np.isclose(out.diagonal(), 1.0, atol=1e-5).all(), "repeated edges mishandled"
+    else:
+        nz = w > 0
+        out = sp.coo_array((w[nz], (src[nz], dst[nz])), shape=(n, n)).tocsr()
+        out.sum_duplicates()
+        out.sort_indices()
+    # zero the diagonal in place (entries stay stored, as in the reference's setdiag(0.))
+    rr = np.repeat(np.arange(n), np.diff(out.indptr))
+    out.data[rr == out.indices] = 0.0
+    D = np.asarray(out.sum(axis=1)).reshape(-1)
+    assert (D > 0).all(), "no zero degree nodes allowed"
+    if laplacian:
+        assert symmetric
+        out = out.copy()
+        out.data = -out.data
+        out.data[rr == out.indices] = D
+        if normalized:
+            s = sp.dia_array((1.0 / np.sqrt(D), 0), shape=(n, n))
+            out = (s @ (out @ s)).tocsr()
+    out = out.tocsr()
+    out.sum_duplicates()
+    out.sort_indices()
+    assert out.has_sorted_indices
+    return out
+
+
+def edge_loss(laplacian_m, labels):
+    return labels @ (laplacian_m @ labels)
+
+
+def get_lookup_ranges(sorted_col, nvecs):
+    counts = np.bincount(np.asarray(sorted_col, dtype=np.int64), minlength=nvecs)
+    return np.concatenate(([0], np.cumsum(counts)))
+
+
+def post_process_graph_df(df: pd.DataFrame, nvec: int) -> pd.DataFrame:
+    """normalise dtypes, clip distances at 0, rank neighbours by distance (1-based, first wins
+    ties), add the rank-0 self edge to every vertex, sort by (src_vertex, dst_rank)."""
+    src = df.src_vertex.values.astype("int32")
+    dst = df.dst_vertex.values.astype("int32")
+    dist = np.clip(df.distance.values.astype("float32"), a_min=0.0, a_max=None)
+    keep = src != dst
+    src, dst, dist = src[keep], dst[keep], dist[keep]
+    order = np.lexsort((np.arange(src.shape[0]), dist, src))
+    src, dst, dist = src[order], dst[order], dist[order]
+    starts = np.concatenate(([0], np.cumsum(np.bincount(src, minlength=nvec))))[:-1]
+    rank = (np.arange(src.shape[0]) - starts[src] + 1).astype("int32")
+    ids = np.arange(nvec, dtype="int32")
+    out = pd.DataFrame({"src_vertex": np.concatenate([src, ids]), "dst_vertex": np.concatenate([dst, ids]),
+                        "distance": np.concatenate([dist, np.zeros(nvec, dtype="float32")]),
+                        "dst_rank": np.concatenate([rank, np.zeros(nvec, dtype="int32")])})
+    return out.sort_values(["src_vertex", "dst_rank"]).reset_index(drop=True)
+
+
+def compute_exact_knn(vectors: np.ndarray, n_neighbors: int) -> pd.DataFrame:
+    """all-pairs cosine distances, k+1 nearest per row (offline; knn_graph.py:170-191)."""
+    k = min(n_neighbors + 1, vectors.shape[0])
+    all_pairs = 1.0 - (vectors @ vectors.T)
+    nn = np.argsort(all_pairs, axis=-1)[:, :k]
+    src = np.repeat(np.arange(vectors.shape[0]), k)
+    dst = nn.reshape(-1)
+    df = pd.DataFrame({"src_vertex": src.astype("int32"), "dst_vertex": dst.astype("int32"),
+                       "distance": all_pairs[src, dst].astype("float32")})
+    return post_process_graph_df(df, nvec=vectors.shape[0])
+
+
+class KNNGraph:
+    def __init__(self, knn_df: pd.DataFrame, nvecs=None):
+        self.knn_df = knn_df
+        ks = knn_df.groupby("src_vertex").dst_rank.max()
+        self._ks = ks
+        self.k = ks.min()
+        self.maxk = ks.median()
+        self.nvecs = ks.shape[0]
+        self.ind_ptr = get_lookup_ranges(knn_df.src_vertex, self.nvecs)
+
+    def restrict_k(self, *, k):
+        if k < self.maxk:
+            return KNNGraph(self.knn_df[self.knn_df.dst_rank < k].reset_index(drop=True))
+        assert k == self.maxk, f"can only do up to k={self.k} neighbors based on input df"
+        return self
+
+    @staticmethod
+    def from_file(path):
+        return KNNGraph(pd.read_parquet(f"{path}/forward.parquet"))
+
+    def save(self, path):
+        import os
+        os.makedirs(path, exist_ok=True)
+        self.knn_df.to_parquet(f"{path}/forward.parquet")
+
+    def rev_lookup(self, dst_vertex) -> pd.DataFrame:
+        return self.knn_df.iloc[self.ind_ptr[dst_vertex]:self.ind_ptr[dst_vertex + 1]]

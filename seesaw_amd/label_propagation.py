@@ -1,0 +1,82 @@
+"""LabelPropagation: the reference's interface (seesaw/label_propagation.py:6-79) with the
+sweeps on the GPU (ssw_labelprop_run in libseesaw_hip.so -- CSR f64 SpMV fused with the
+`(+ lambda * prior) / (colsum + lambda)` normalisation, the label clamp and the device-side
+`max((f'-f)^2) < epsilon` early exit)."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+
+
+def _p(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class LabelPropagation:
+    def __init__(self, weight_matrix, *, reg_lambda: float, max_iter: int, epsilon=1e-5, verbose=0, device: int = 0):
+        assert reg_lambda >= 0
+        W = weight_matrix if sp.issparse(weight_matrix) else sp.csr_array(weight_matrix)
+        W = W.tocsr()
+        assert W.has_sorted_indices
+        self.weight_matrix = W
+        self.n = W.shape[0]
+        self.epsilon = epsilon
+        self.verbose = verbose
+        self.reg_lambda = float(reg_lambda)
+        self.max_iter = int(max_iter)
+        self.reg_values = None
+        self.weight_sum = np.asarray(W.sum(0)).reshape(-1).astype(np.float64)  # column sums, as the reference
+        self.last_sweeps = 0
+        self.last_converged = False
+        self._h = ctypes.c_void_p()
+        indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(W.indices, dtype=np.int32)
+        data = np.ascontiguousarray(W.data, dtype=np.float64)
+        _lib.call("ssw_labelprop_create", int(device), self.n, _p(indptr), _p(indices), _p(data),
+                  _p(self.weight_sum), ctypes.byref(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().ssw_labelprop_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fit_transform(self, *, label_ids, label_values, reg_values=None, start_value=None):
+        if reg_values is not None:
+            assert reg_values.shape[0] == self.n
+            self.reg_values = reg_values
+            prior = np.ascontiguousarray(reg_values, dtype=np.float64)
+        else:
+            assert self.reg_lambda == 0
+            self.reg_values = np.zeros(self.n)
+            prior = None
+        if start_value is not None:
+            start = np.array(start_value, dtype=np.float64)
+        elif reg_values is not None:
+            start = np.array(reg_values, dtype=np.float64)
+        else:
+            start = np.zeros(self.n)
+        ids = np.ascontiguousarray(np.asarray(label_ids).reshape(-1), dtype=np.int64)
+        vals = np.ascontiguousarray(np.asarray(label_values).reshape(-1), dtype=np.float64)
+        assert ids.shape == vals.shape
+        out = np.empty(self.n, dtype=np.float64)
+        sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("ssw_labelprop_run", self._h, _p(prior), _p(np.ascontiguousarray(start)), _p(ids), _p(vals),
+                  ids.shape[0], self.reg_lambda, float(self.epsilon), self.max_iter, _p(out),
+                  ctypes.byref(sweeps), ctypes.byref(conv))
+        self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
+        if self.last_converged:
+            if self.verbose > 0:
+                print(f"prop. converged after {self.last_sweeps} iterations")
+        else:
+            print(f"warning: did not converge after {self.last_sweeps} iterations")
+        return out

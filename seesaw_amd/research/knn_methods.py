@@ -1,0 +1,98 @@
+"""Rankers driven by the k-NN graph (interface of seesaw/research/knn_methods.py:8-199).
+
+LabelPropagationRanker2: calibrates the scan scores into a prior, propagates user labels
+over the weight matrix (GPU sweeps through seesaw_amd.label_propagation) and ranks the
+unlabelled vectors by the propagated score.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import expit as sigmoid
+
+from ..bitmap import FrozenBitMap
+from ..knn_graph import KNNGraph  # noqa: F401  (re-exported like the reference)
+from ..label_propagation import LabelPropagation
+
+
+def normalize_scores(scores, epsilon):
+    """affine map of the scores onto [epsilon, 1 - epsilon]; constant input -> 0.5."""
+    assert epsilon < 0.5
+    lo, hi = scores.min(), scores.max()
+    if hi == lo:
+        return np.full_like(scores, 0.5)
+    return (scores - lo) / (hi - lo) * (1 - 2 * epsilon) + epsilon
+
+
+class BaseLabelPropagationRanker:
+    def __init__(self, *, knng, nvecs, normalize_scores, sigmoid_before_propagate, calib_a, calib_b,
+                 prior_weight, normalize_epsilon=None, **other):
+        self.knng = knng
+        self.nvecs = nvecs
+        self.normalize_scores = normalize_scores
+        if normalize_scores:
+            assert normalize_epsilon is not None
+            self.epsilon = normalize_epsilon
+        self.calib_a, self.calib_b = calib_a, calib_b
+        self.prior_weight = prior_weight
+        self.sigmoid_before_propagate = sigmoid_before_propagate
+        self.is_labeled = np.zeros(nvecs)
+        self.labels = np.zeros(nvecs)
+        self.prior_scores = None
+        self._current_scores = None
+        self.all_indices = FrozenBitMap(range(nvecs))
+
+    def set_base_scores(self, init_scores):
+        assert self.nvecs == init_scores.shape[0]
+        if self.normalize_scores:
+            init_scores = normalize_scores(init_scores, epsilon=self.epsilon)
+        if self.sigmoid_before_propagate:
+            self.prior_scores = sigmoid(self.calib_a * (init_scores + self.calib_b))
+        else:
+            self.prior_scores = init_scores
+        # nothing labelled yet: the prior is the score; otherwise propagate right away
+        if self.is_labeled.sum() == 0:
+            self._current_scores = self.prior_scores
+        else:
+            self._current_scores = self._propagate(self.prior_scores)
+
+    def _propagate(self, scores):
+        raise NotImplementedError("implement me")
+
+    def update(self, idxs, labels):
+        for idx, label in zip(idxs, labels):
+            label = float(label)
+            assert np.isclose(label, 0) or np.isclose(label, 1)
+            self.labels[int(idx)] = label
+            self.is_labeled[int(idx)] = 1
+        has_negative = bool((self.labels[self.is_labeled > 0] == 0).any())
+        if has_negative:  # the reference skips propagation until a negative label exists
+            print(" propagating")
+            self._current_scores = self._propagate(self.prior_scores)
+        else:
+            print(" no negatives yet, skipping propagation")
+
+    def current_scores(self):
+        return self._current_scores
+
+    def top_k(self, k, unlabeled_only=True):
+        subset = np.where(self.is_labeled < 1)[0] if unlabeled_only else np.arange(self.nvecs)
+        raw = self.current_scores()
+        order = np.argsort(-raw[subset], kind="stable")[:k]
+        top = subset[order]
+        return top, raw[top]
+
+
+class LabelPropagationRanker2(BaseLabelPropagationRanker):
+    lp: LabelPropagation
+
+    def __init__(self, *, weight_matrix, verbose: int = 0, device: int = 0, **other):
+        super().__init__(knng=None, nvecs=weight_matrix.shape[0], **other)
+        self.knng_intra = None
+        self.weight_matrix = weight_matrix
+        self.lp = LabelPropagation(weight_matrix=weight_matrix, reg_lambda=self.prior_weight, max_iter=300,
+                                   verbose=verbose, device=device)
+
+    def _propagate(self, scores):
+        ids = np.nonzero(self.is_labeled.reshape(-1))[0]
+        return self.lp.fit_transform(label_ids=ids, label_values=self.labels.reshape(-1)[ids],
+                                     reg_values=self.prior_scores, start_value=scores)

@@ -1,0 +1,85 @@
+"""GPU parity of label propagation (ssw_labelprop_run through seesaw_amd.label_propagation)
+against outputs captured from the reference (tests/golden/labelprop.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _W(g, name="e05"):
+    n = int(g["n"])
+    return sp.csr_array((g[f"{name}_data"], g[f"{name}_indices"].astype(np.int32), g[f"{name}_indptr"]), shape=(n, n))
+
+
+def test_fit_transform_bit_exact_vs_reference_golden():
+    from seesaw_amd.label_propagation import LabelPropagation
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    W = _W(g)
+    for r in range(int(g["n_runs"])):
+        lam = float(g[f"run{r}_lam"])
+        start = g[f"run{r}_start"]
+        lp = LabelPropagation(W, reg_lambda=lam, max_iter=300)
+        out = lp.fit_transform(label_ids=g[f"run{r}_ids"], label_values=g[f"run{r}_vals"],
+                               reg_values=start if lam > 0 else None, start_value=start)
+        assert lp.last_sweeps == int(g[f"run{r}_steps"]), (r, lp.last_sweeps)
+        assert np.array_equal(out, g[f"run{r}_out"]), (r, np.abs(out - g[f"run{r}_out"]).max())
+        lp.close()
+
+
+def test_ranker_matches_reference_golden():
+    from seesaw_amd.research.knn_methods import LabelPropagationRanker2
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    ranker = LabelPropagationRanker2(weight_matrix=_W(g), normalize_scores=False, sigmoid_before_propagate=True,
+                                     calib_a=10.0, calib_b=-0.2, prior_weight=1.0)
+    ranker.set_base_scores(g["rk_base_scores"])
+    ids0, sc0 = ranker.top_k(k=20)
+    assert np.array_equal(ids0, g["rk_top0_ids"]) and np.allclose(sc0, g["rk_top0_scores"], rtol=0, atol=1e-12)
+    ranker.update(g["rk_upd_ids"], g["rk_upd_labels"])
+    assert np.array_equal(ranker.current_scores(), g["rk_scores1"])
+    ids1, sc1 = ranker.top_k(k=20)
+    assert np.array_equal(ids1, g["rk_top1_ids"]) and np.array_equal(sc1, g["rk_top1_scores"])
+
+
+@pytest.mark.parametrize("n,deg", [(1, 1), (257, 3), (5000, 20), (40000, 12)])
+def test_random_graphs_vs_oracle(oracle, n, deg):
+    from seesaw_amd.label_propagation import LabelPropagation
+    rng = np.random.default_rng(n)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, n * deg)
+    vals = rng.uniform(0.05, 1.0, n * deg)
+    if n > 300:  # a hub row far longer than one LDS chunk, and an empty row
+        hub = rng.integers(0, n, 9000)
+        rows = np.concatenate([rows[rows != 7], np.full(9000, 5)])
+        cols = np.concatenate([cols[: rows.shape[0] - 9000], hub])
+        vals = np.concatenate([vals[: rows.shape[0] - 9000], rng.uniform(0.05, 1.0, 9000)])
+    W = sp.coo_array((vals, (rows, cols)), shape=(n, n)).tocsr()
+    W.sum_duplicates()
+    W.sort_indices()
+    # make every column sum positive so the normaliser never divides by zero at lambda = 0
+    W = (W + sp.eye_array(n, format="csr") * 0.01).tocsr()
+    W.sort_indices()
+    prior = rng.uniform(0, 1, n)
+    ids = rng.choice(n, size=min(n, 25), replace=False)
+    lab = rng.integers(0, 2, ids.shape[0]).astype(np.float64)
+    for lam, max_iter in [(0.0, 300), (2.0, 300), (1.0, 3), (1.0, 0)]:
+        ref, sweeps, conv = oracle.label_propagation(W, label_ids=ids, label_values=lab, reg_lambda=lam,
+                                                     reg_values=prior, start_value=prior, max_iter=max_iter)
+        lp = LabelPropagation(W, reg_lambda=lam, max_iter=max_iter)
+        out = lp.fit_transform(label_ids=ids, label_values=lab, reg_values=prior, start_value=prior)
+        assert lp.last_sweeps == sweeps and lp.last_converged == conv
+        assert np.array_equal(out, ref), np.abs(out - ref).max()
+        lp.close()
+
+
+def test_bound_violation_is_an_error():
+    from seesaw_amd._lib import SeesawHipError
+    from seesaw_amd.label_propagation import LabelPropagation
+    W = sp.csr_array(np.array([[0.0, 1.0], [1.0, 0.0]]))
+    lp = LabelPropagation(W, reg_lambda=0.0, max_iter=5)
+    with pytest.raises(SeesawHipError):  # start value outside [0, 1]: the reference asserts
+        lp.fit_transform(label_ids=np.zeros(0, np.int64), label_values=np.zeros(0), reg_values=None,
+                         start_value=np.array([5.0, -3.0]))
