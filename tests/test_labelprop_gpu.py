@@ -56,11 +56,11 @@ def test_random_graphs_vs_oracle(oracle, n, deg):
         rows = np.concatenate([rows[rows != 7], np.full(9000, 5)])
         cols = np.concatenate([cols[: rows.shape[0] - 9000], hub])
         vals = np.concatenate([vals[: rows.shape[0] - 9000], rng.uniform(0.05, 1.0, 9000)])
-    W = sp.coo_array((vals, (rows, cols)), shape=(n, n)).tocsr()
+    A = sp.coo_array((vals, (rows, cols)), shape=(n, n)).tocsr()
+    # symmetric (column sums == row sums, so every sweep is a weighted average and the
+    # reference's bound asserts hold) with a small diagonal so no normaliser is zero
+    W = (A + A.T + sp.eye_array(n, format="csr") * 0.01).tocsr()
     W.sum_duplicates()
-    W.sort_indices()
-    # make every column sum positive so the normaliser never divides by zero at lambda = 0
-    W = (W + sp.eye_array(n, format="csr") * 0.01).tocsr()
     W.sort_indices()
     prior = rng.uniform(0, 1, n)
     ids = rng.choice(n, size=min(n, 25), replace=False)
