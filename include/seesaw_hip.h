@@ -168,6 +168,63 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
                              double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
                              int32_t *out_sweeps, int32_t *out_converged);
 
+/* ------------------------------------------------------------------------- */
+/* Online relevance-feedback update: fused loss+gradient on the GPU, L-BFGS    */
+/* (strong Wolfe) driver on the host.                                          */
+/* replaces: LogisticRegressionPT.fit      seesaw/logistic_regression.py:350-406 */
+/*           RegModule.fit (MultiReg)      seesaw/loops/multi_reg.py:139-162    */
+/*           BasicTrainer.fit / torch.optim.LBFGS closure loop                  */
+/*                                         seesaw/basic_trainer.py:11-69        */
+/*           ref_pairwise_rank_loss / ref_pairwise_logistic_loss               */
+/*                                         seesaw/rank_loss.py:34-95            */
+/* ------------------------------------------------------------------------- */
+typedef struct ssw_fb ssw_fb;
+
+enum { SSW_FB_LOGREG = 0, SSW_FB_MULTIREG = 1 };
+enum { SSW_FB_LOSS_CE = 0, SSW_FB_LOSS_PAIRWISE_HINGE = 1, SSW_FB_LOSS_PAIRWISE_LOGISTIC = 2 };
+enum { SSW_FB_REG_NONE = 0, SSW_FB_REG_VECTOR = 1, SSW_FB_REG_NORM = 2, SSW_FB_REG_NORM1 = 3 };
+
+typedef struct ssw_fb_objective {
+    int32_t kind;          /* SSW_FB_LOGREG | SSW_FB_MULTIREG                                  */
+    int32_t loss_type;     /* MULTIREG: label_loss_type (multi_reg.py:34-35)                   */
+    int32_t fit_intercept; /* LOGREG: extra bias parameter after the dim weights               */
+    int32_t reg_kind;      /* LOGREG: regulariser (logistic_regression.py:304-330)             */
+    float pos_weight;      /* LOGREG: BCE pos_weight; MULTIREG ce_loss: < 0 means 'balanced'   */
+    float reg_weight;      /* LOGREG: reg_lambda / n_examples (:366)                           */
+    float margin;          /* MULTIREG: rank_loss_margin                                       */
+    float reg_norm_lambda; /* MULTIREG                                                         */
+    float reg_data_lambda; /* MULTIREG (needs ssw_fb_set_xlx when != 0)                        */
+    float reg_query_lambda;/* MULTIREG                                                         */
+} ssw_fb_objective;
+
+ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out);
+ssw_status ssw_fb_destroy(ssw_fb *fb);
+/* labelled vectors X [n, dim] f32 from the host; center != 0 subtracts the column means
+ * (StandardScaler(with_std=False) / X - X.mean(0)). */
+ssw_status ssw_fb_set_data(ssw_fb *fb, const float *X_host, int64_t n, int32_t center);
+/* same, but the rows are gathered on the device out of a resident matrix (e.g. the index:
+ * ssw_index_device_ptrs) -- `index.vectors[matchdf.index.values]`, multi_reg.py:204. */
+ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int64_t n_matrix_rows,
+                                       const int64_t *rows_host, int64_t n, int32_t center);
+/* targets y [n] f32 and optional per-item sample weights [n] f32. */
+ssw_status ssw_fb_set_targets(ssw_fb *fb, const float *y_host, const float *sample_weight_or_null);
+/* regulariser vector / query vector (normalised inside, F.normalize) and X'LX [dim, dim]. */
+ssw_status ssw_fb_set_query(ssw_fb *fb, const float *q_host);
+ssw_status ssw_fb_set_xlx(ssw_fb *fb, const float *xlx_host);
+/* column means removed by the last set_data (the scaler's mean_). */
+ssw_status ssw_fb_get_mean(ssw_fb *fb, float *out_mu_host);
+/* one closure evaluation: loss and d loss / d params at w ([dim] or [dim+1] with intercept).
+ * out_parts4 (MULTIREG) = loss_norm, loss_datareg, loss_queryreg, loss_labels. */
+ssw_status ssw_fb_lossgrad(ssw_fb *fb, const ssw_fb_objective *obj, const float *w_host,
+                           float *out_loss, float *out_grad, float *out_parts4_or_null);
+/* logits X w (+ b) of the installed rows. */
+ssw_status ssw_fb_scores(ssw_fb *fb, const float *w_host, int32_t has_bias, float *out_logits);
+/* one optimizer.step(closure) of LBFGS(max_iter, lr, line_search_fn='strong_wolfe') starting
+ * from w_inout; returns the fitted parameters in place.  SSW_ERR_NUMERIC on NaN/Inf loss
+ * (the reference raises ValueError, logistic_regression.py:398-401). */
+ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, int32_t max_iter,
+                      float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,141 @@
+"""CPU ORACLE (test infrastructure) for the relevance-feedback update: torch-CPU autograd
+restatements of the two objectives the reference fits with torch.optim.LBFGS.
+
+Pinned against coefficients / losses / gradients captured from the reference itself
+(tests/golden/logreg.npz, multireg.npz, rank_loss.npz; generator oracle/gen_golden.py).
+torch.optim.LBFGS is the third-party optimiser the reference calls (basic_trainer.py:59-63),
+used here as is."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---- rank losses: seesaw/rank_loss.py --------------------------------------------------
+def signed_inversions(target, scores, margin):
+    """ref_signed_inversions (rank_loss.py:3-31)."""
+    t = (target.reshape(-1, 1) - target.reshape(1, -1)).sign()
+    s = scores.reshape(-1, 1) - scores.reshape(1, -1) - margin * t
+    return ((t > 0) & (s <= 0)).float() - ((t < 0) & (s >= 0)).float()
+
+
+def pairwise_hinge(target, scores, margin):
+    """ref_pairwise_rank_loss(aggregate='sum', return_max_inversions=True) (rank_loss.py:63-95)."""
+    t = (target.reshape(-1, 1) - target.reshape(1, -1)).sign()
+    s = scores.reshape(-1, 1) - scores.reshape(1, -1)
+    loss = torch.clamp(margin - t * s, min=0) - margin * (t == 0).float()
+    return loss.sum(0), (t != 0).sum(0), loss
+
+
+def pairwise_logistic(target, scores):
+    """ref_pairwise_logistic_loss(aggregate='sum', return_max_inversions=True) (rank_loss.py:34-61)."""
+    t = (target.reshape(-1, 1) - target.reshape(1, -1)).sign()
+    s = scores.reshape(-1, 1) - scores.reshape(1, -1)
+    loss = (t ** 2) * torch.log(1 + torch.exp(-s * t))
+    return loss.sum(0), (t != 0).sum(0), loss
+
+
+# ---- LogisticRegressionPT: seesaw/logistic_regression.py:68-124, 270-421 ---------------
+def logreg_loss(w, b, Xc, y, sample_weight, pos_weight, reg_weight, qhat, reg_kind="vector"):
+    logits = Xc @ w.reshape(-1, 1) + (b if b is not None else 0.0)
+    ce = F.binary_cross_entropy_with_logits(logits, y.reshape(-1, 1), weight=sample_weight, reduction="none",
+                                            pos_weight=torch.tensor([pos_weight]))
+    wn = w.reshape(1, -1)
+    if reg_kind == "vector":
+        reg = (wn.norm() - 1.0) ** 2 + (F.normalize(wn).reshape(-1) - qhat.reshape(-1)).norm() ** 2
+    elif reg_kind in ("norm", "norm1"):
+        reg = (wn.norm() - (1.0 if reg_kind == "norm1" else 0.0)) ** 2
+    else:
+        reg = 0.0
+    return ce.mean() + reg_weight * reg
+
+
+def logreg_fit(X, y, q, *, w0, reg_lambda, class_weights="balanced", sample_weights=None, max_iter=200, lr=1.0,
+               fit_intercept=False):
+    """LogisticRegressionPT.fit -> get_coeff(), with the start weights given explicitly."""
+    X = np.asarray(X, dtype=np.float32)
+    mu = X.astype(np.float64).mean(axis=0).astype(np.float32)  # StandardScaler(with_std=False)
+    Xc = torch.from_numpy(X - mu)
+    yt = torch.from_numpy(np.asarray(y, dtype=np.float64))
+    if class_weights == "balanced":
+        pos_weight = max(int((y == 0).sum()), 1) / max(int((y == 1).sum()), 1)
+    else:
+        pos_weight = float(class_weights)
+    qhat = F.normalize(torch.from_numpy(np.asarray(q, dtype=np.float32)).reshape(1, -1), dim=-1).reshape(-1)
+    sw = None if sample_weights is None else torch.from_numpy(np.asarray(sample_weights, dtype=np.float64).reshape(-1, 1))
+    w = torch.tensor(np.asarray(w0, dtype=np.float32)[: X.shape[1]].reshape(-1), requires_grad=True)
+    params = [w]
+    b = None
+    if fit_intercept:
+        b = torch.tensor(np.asarray(w0, dtype=np.float32)[X.shape[1]:].reshape(-1), requires_grad=True)
+        params.append(b)
+    opt = torch.optim.LBFGS(params, max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe")
+    reg_weight = reg_lambda / X.shape[0]
+
+    def closure():
+        opt.zero_grad()
+        loss = logreg_loss(w, b, Xc, yt, sw, pos_weight, reg_weight, qhat)
+        loss.backward()
+        return loss
+
+    opt.step(closure)
+    return w.detach().numpy().copy(), (None if b is None else b.detach().numpy().copy())
+
+
+# ---- RegModule: seesaw/loops/multi_reg.py:24-134 ---------------------------------------
+def multireg_loss(w, Xc, y, vec_weight, qhat, xlx, *, loss_type, margin, l_norm, l_data, l_query,
+                  pos_weight="balanced"):
+    sw = vec_weight.float().clone()
+    logits = Xc @ w
+    orig = sw.sum()
+    pos_total = (y == 1).float() @ sw
+    neg_total = orig - pos_total
+    item = w.sum() * torch.zeros_like(sw)
+    if loss_type == "ce_loss":
+        pw = (neg_total + 1.0) / (pos_total + 1.0) if pos_weight == "balanced" else torch.tensor([float(pos_weight)])
+        ce = F.binary_cross_entropy_with_logits(logits, y, weight=None, reduction="none", pos_weight=None)
+        sw[y == 1] *= pw
+        sw *= orig / sw.sum()
+        item = ce
+    elif pos_total > 0 and neg_total > 0:
+        if loss_type == "pairwise_rank_loss":
+            per_item, max_inv, _ = pairwise_hinge(y, logits, margin)
+        else:
+            per_item, max_inv, _ = pairwise_logistic(y, logits)
+        item = per_item / max_inv
+    item = item * sw
+    what = F.normalize(w, dim=-1)
+    loss_norm = l_norm * (torch.cosh((w @ w).log()) - 1.0)
+    loss_data = l_data * (w @ (xlx @ w))
+    loss_query = l_query * ((1 - what @ qhat) / 2.0)
+    loss_labels = item.sum()
+    return loss_labels + loss_data + loss_norm + loss_query, (loss_norm, loss_data, loss_query, loss_labels)
+
+
+def multireg_prepare(X, y, img, q, xlx):
+    X = np.asarray(X, dtype=np.float32)
+    Xc = torch.from_numpy(X - X.mean(axis=0).reshape(1, -1))
+    _, inv, counts = np.unique(img, return_inverse=True, return_counts=True)
+    vec_weight = torch.from_numpy(1.0 / counts[inv].astype(np.float64))  # 1 / #vectors of the image
+    qhat = F.normalize(torch.from_numpy(np.asarray(q, dtype=np.float32)).reshape(-1), dim=-1)
+    return Xc, torch.from_numpy(np.asarray(y, dtype=np.float64)), vec_weight, qhat, torch.from_numpy(np.asarray(xlx)).float()
+
+
+def multireg_fit(X, y, img, q, xlx, *, loss_type, margin=0.2, l_norm=100.0, l_data=0.0, l_query=0.0,
+                 max_iter=200, lr=1.0):
+    """RegModule.fit -> (normalised coeff, raw weight)."""
+    Xc, yt, vw, qhat, M = multireg_prepare(X, y, img, q, xlx)
+    w = qhat.clone().requires_grad_(True)
+    opt = torch.optim.LBFGS([w], max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        loss, _ = multireg_loss(w, Xc, yt, vw, qhat, M, loss_type=loss_type, margin=margin, l_norm=l_norm,
+                                l_data=l_data, l_query=l_query)
+        loss.backward()
+        return loss
+
+    opt.step(closure)
+    raw = w.detach()
+    return F.normalize(raw, dim=-1).numpy().copy(), raw.numpy().copy()

@@ -67,9 +67,34 @@ _SIGNATURES = {
     "ssw_labelprop_destroy": (c_i32, [c_void_p]),
     "ssw_labelprop_run": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                                   ctypes.c_double, ctypes.c_double, c_i32, c_void_p, c_i32_p, c_i32_p]),
+    "ssw_fb_create": (c_i32, [c_i32, c_i32, c_void_pp]),
+    "ssw_fb_destroy": (c_i32, [c_void_p]),
+    "ssw_fb_set_data": (c_i32, [c_void_p, c_void_p, c_i64, c_i32]),
+    "ssw_fb_set_data_from_device": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i32]),
+    "ssw_fb_set_targets": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_fb_set_query": (c_i32, [c_void_p, c_void_p]),
+    "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),
+    "ssw_fb_get_mean": (c_i32, [c_void_p, c_void_p]),
+    "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssw_fb_scores": (c_i32, [c_void_p, c_void_p, c_i32, c_void_p]),
+    "ssw_fb_fit": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_i32_p, c_i32_p, c_void_p]),
     "ssw_index_profile": (c_i32, [c_void_p, c_i32]),
     "ssw_index_profile_read": (c_i32, [c_void_p, c_void_p, c_i32, c_i32_p]),
 }
+
+
+
+class FbObjective(ctypes.Structure):
+    """struct ssw_fb_objective"""
+    _fields_ = [("kind", c_i32), ("loss_type", c_i32), ("fit_intercept", c_i32), ("reg_kind", c_i32),
+                ("pos_weight", ctypes.c_float), ("reg_weight", ctypes.c_float), ("margin", ctypes.c_float),
+                ("reg_norm_lambda", ctypes.c_float), ("reg_data_lambda", ctypes.c_float),
+                ("reg_query_lambda", ctypes.c_float)]
+
+
+SSW_FB_LOGREG, SSW_FB_MULTIREG = 0, 1
+SSW_FB_LOSS_CE, SSW_FB_LOSS_PAIRWISE_HINGE, SSW_FB_LOSS_PAIRWISE_LOGISTIC = 0, 1, 2
+SSW_FB_REG_NONE, SSW_FB_REG_VECTOR, SSW_FB_REG_NORM, SSW_FB_REG_NORM1 = 0, 1, 2, 3
 
 _lib = None
 

@@ -1,0 +1,896 @@
+// feedback.hip -- online relevance-feedback update: fused loss + gradient kernels and the
+// L-BFGS (strong Wolfe) driver that turns labelled tile vectors into the next query vector
+// (gfx950 / MI355X).
+//
+// Replaces, for the two linear scorers the feedback loops fit every round:
+//   LogisticRegressionPT / LogisticRegModule     seesaw/logistic_regression.py:68-124,270-421
+//       mean_i BCEWithLogits(x_i.w + b, y_i; weight_i, pos_weight) + (lambda/n) R(w),
+//       R = (|w|-1)^2 + |w/|w| - q/|q||^2   (vector regulariser, :304-330)
+//   RegModule ("seesaw" / MultiReg)              seesaw/loops/multi_reg.py:24-134
+//       sum_i sw_i item_i + l_norm (cosh(log w.w) - 1) + l_data w'(X'LX)w + l_query (1 - w^.q^)/2,
+//       item = BCE (balanced re-weighting :90-105) | pairwise hinge (:106-112, rank_loss.py:63-95)
+//              | pairwise logistic (:113-119, rank_loss.py:34-61)
+//   torch.optim.LBFGS(line_search_fn="strong_wolfe") closure loop   seesaw/basic_trainer.py:11-69
+//
+// The reference evaluates the closure through Python autograd (with anomaly detection on)
+// up to 1.25 x max_iter times per refine; the math per evaluation is two skinny GEMVs
+// (n x 512, n = labelled tile vectors, up to ~10^4 with pseudo-labels) plus O(n^2) pairwise
+// terms.  Here one evaluation = 3-4 small kernels on rows that already sit in HBM:
+//   fb_logits   z = Xc w (+ b)                        wave per row, coalesced 16-B loads
+//   fb_pairwise per-item pairwise loss + dL/dz        one workgroup, z and targets in LDS
+//   fb_elem     per-item BCE loss + dL/dz             elementwise
+//   fb_grad     partial g = Xc' r per 32-row slab     thread per column, coalesced
+//   fb_final    fixed-order reduction of the partials + regulariser terms -> [loss, grad]
+// and the L-BFGS two-loop recursion / cubic-interpolation line search run on the host over
+// 513-float vectors (pure latency, no bandwidth).  Bound: launch/sync latency, not HBM --
+// nothing here is GEMM-shaped enough for MFMA.
+#include <cmath>
+#include <vector>
+
+#include "ssw_common.h"
+
+namespace ssw {
+namespace {
+
+constexpr int FB_SLAB = 32;          // rows per fb_grad workgroup
+constexpr int FB_MAX_PAIRWISE = 4096;  // items the one-workgroup pairwise kernel takes
+
+// ---- data preparation ---------------------------------------------------------------
+__global__ void k_fb_gather_rows(const float *__restrict__ X, const int64_t *__restrict__ rows,
+                                 int64_t n, int dim, float *__restrict__ out) {
+    const int64_t i = blockIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(X + rows[i] * dim);
+    float4 *dst = reinterpret_cast<float4 *>(out + i * dim);
+    for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) dst[c] = src[c];
+}
+
+// column means in f64 (fixed order), then subtract: StandardScaler(with_std=False) /
+// `X - X.mean(axis=0)` (logistic_regression.py:353-355, multi_reg.py:168-169)
+__global__ void k_fb_center(float *__restrict__ X, int64_t n, int dim, float *__restrict__ mu) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += (double)X[i * dim + c];
+    const float m = (float)(s / (double)n);
+    mu[c] = m;
+    for (int64_t i = 0; i < n; ++i) X[i * dim + c] -= m;
+}
+
+// ---- per-evaluation kernels -----------------------------------------------------------
+// z_i = <x_i, w> + b ; one wave per row
+__global__ __launch_bounds__(256) void k_fb_logits(const float *__restrict__ X,
+                                                   const float *__restrict__ w, int64_t n, int dim,
+                                                   int has_bias, float *__restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float4 *x4 = reinterpret_cast<const float4 *>(X + row * dim);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    float a = 0.f;
+    for (int c = lane; c < dim / 4; c += 64) {
+        const float4 xv = x4[c], wv = w4[c];
+        a = fmaf(xv.x, wv.x, a);
+        a = fmaf(xv.y, wv.y, a);
+        a = fmaf(xv.z, wv.z, a);
+        a = fmaf(xv.w, wv.w, a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) z[row] = a + (has_bias ? w[dim] : 0.f);
+}
+
+__device__ __forceinline__ float softplus_neg(float z) {  // log(1 + exp(-z)), stable
+    return log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f);
+}
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+
+// elementwise BCE-with-logits with pos_weight pw and per-item coefficient c_i:
+//   l = c [ (1-y) z + (1 + (pw-1) y) softplus(-z) ],  dl/dz = c [ (1-y) - (1 + (pw-1) y) sigmoid(-z) ]
+__global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__ y,
+                          const float *__restrict__ coef, float pw, int64_t n,
+                          float *__restrict__ item_loss, float *__restrict__ r) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float zi = z[i], yi = y[i], ci = coef[i];
+    const float lw = 1.f + (pw - 1.f) * yi;
+    item_loss[i] = ci * ((1.f - yi) * zi + lw * softplus_neg(zi));
+    r[i] = ci * ((1.f - yi) - lw * sigmoidf(-zi));
+}
+
+// pairwise losses over all ordered pairs (i, j), t_ij = sign(y_i - y_j), s_ij = z_i - z_j:
+//   hinge    : max(0, m - t_ij s_ij) - m [t_ij == 0]        (rank_loss.py:63-95)
+//   logistic : t_ij^2 log(1 + exp(-t_ij s_ij))              (rank_loss.py:34-61)
+// item_j = coef_j / max_inv_j * sum_i loss_ij, max_inv_j = #{i : t_ij != 0};
+// r_k = d(sum_j item_j)/dz_k.  One workgroup; z, y, c = coef/max_inv in LDS.
+template <int LOGISTIC>
+__global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ z,
+                                                      const float *__restrict__ y,
+                                                      const float *__restrict__ coef, float margin,
+                                                      int n, float *__restrict__ item_loss,
+                                                      float *__restrict__ r) {
+    extern __shared__ float sh[];
+    float *sz = sh, *sy = sh + n, *sc = sh + 2 * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        sz[i] = z[i];
+        sy[i] = y[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        int cnt = 0;
+        const float yj = sy[j];
+        for (int i = 0; i < n; ++i) cnt += (sy[i] != yj);
+        sc[j] = cnt > 0 ? coef[j] / (float)cnt : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const float zk = sz[k], yk = sy[k], ck = sc[k];
+        float loss_k = 0.f;  // column sum over i of loss_ik
+        float rk = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float d = sy[i] - yk;
+            if (d == 0.f) continue;
+            const float t = d > 0.f ? 1.f : -1.f;  // t_ik
+            const float s = sz[i] - zk;           // s_ik
+            // pair (i, k): contributes to item_k (column k) with weight ck; z_k enters with -1
+            // pair (k, i): t_ki = -t, s_ki = -s, contributes to item_i with weight sc[i]; z_k enters with +1
+            if (LOGISTIC) {
+                const float u = -t * s;  // -t_ik s_ik  (== -t_ki s_ki)
+                const float l = softplus_neg(-u);
+                loss_k += l;
+                const float sg = sigmoidf(u);  // d/du log(1+exp(u))
+                // d loss_ik / d z_k = sg * (-t) * (-1) = t sg ;  d loss_ki / d z_k = sg * (t)(+1)... see below
+                rk += ck * (t * sg) + sc[i] * (t * sg);
+            } else {
+                const float h = margin - t * s;
+                if (h >= 0.f) {  // torch's clamp(min=0) passes the gradient at the kink
+                    loss_k += h;
+                    // loss_ik = m - t (z_i - z_k): d/dz_k = +t ; loss_ki = m - (-t)(z_k - z_i) = m + t z_k - t z_i: d/dz_k = +t
+                    rk += ck * t + sc[i] * t;
+                }
+            }
+        }
+        item_loss[k] = ck * loss_k;
+        r[k] = rk;
+    }
+}
+
+// partial gradient of one slab of rows: thread c owns column c
+__global__ void k_fb_grad(const float *__restrict__ X, const float *__restrict__ r, int64_t n,
+                          int dim, float *__restrict__ partial /* [nslabs, dim] */) {
+    const int c = threadIdx.x + blockIdx.y * blockDim.x;
+    if (c >= dim) return;
+    const int64_t r0 = (int64_t)blockIdx.x * FB_SLAB;
+    const int64_t r1 = min(r0 + FB_SLAB, n);
+    float g = 0.f;
+    for (int64_t i = r0; i < r1; ++i) g = fmaf(r[i], X[i * dim + c], g);
+    partial[(int64_t)blockIdx.x * dim + c] = g;
+}
+
+struct FbObjDev {
+    int kind;          // 0 logreg, 1 multireg
+    int has_bias;
+    int reg_kind;      // logreg: 0 none, 1 vector, 2 norm (target 0), 3 norm1 (target 1)
+    float scale;       // multiplies the data loss and its gradient (1/n for logreg, 1 for multireg)
+    float reg_weight;  // logreg: lambda / n
+    float l_norm, l_data, l_query;  // multireg
+};
+
+// one workgroup of `dim` (<= 1024) threads: reduce partials in slab order, add the
+// regulariser terms, emit out[0] = loss, out[1 .. 1+P) = gradient, out[1+P ..] = parts
+__global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ partial, int nslabs,
+                                                   const float *__restrict__ item_loss,
+                                                   const float *__restrict__ r, int64_t n, int dim,
+                                                   const float *__restrict__ w,
+                                                   const float *__restrict__ qhat,
+                                                   const float *__restrict__ xlx, FbObjDev obj,
+                                                   float *__restrict__ out) {
+    __shared__ double red[1024];
+    __shared__ float sw_[1024];
+    __shared__ double scal[8];
+    const int c = threadIdx.x;
+    const bool act = c < dim;
+    const float wc = act ? w[c] : 0.f;
+    if (act) sw_[c] = wc;
+    // data gradient
+    float g = 0.f;
+    if (act)
+        for (int s = 0; s < nslabs; ++s) g += partial[(int64_t)s * dim + c];
+    g *= obj.scale;
+    // block reductions: |w|^2, w.qhat, data loss, sum r
+    auto block_sum = [&](double v) -> double {
+        red[c] = v;
+        __syncthreads();
+        for (int s = 512; s >= 1; s >>= 1) {
+            if (c < s) red[c] += red[c + s];
+            __syncthreads();
+        }
+        const double o = red[0];
+        __syncthreads();
+        return o;
+    };
+    const double ww = block_sum(act ? (double)wc * wc : 0.0);
+    const double wq = block_sum(act && qhat ? (double)wc * qhat[c] : 0.0);
+    double ls = 0.0, rs = 0.0;
+    for (int64_t i = c; i < n; i += 1024) {
+        ls += (double)item_loss[i];
+        rs += (double)r[i];
+    }
+    const double data_loss = block_sum(ls) * obj.scale;
+    const double rsum = block_sum(rs) * obj.scale;
+    const double norm = sqrt(ww);
+    const double nclamp = norm > 1e-12 ? norm : 1e-12;  // F.normalize eps
+    double reg_loss = 0.0, p_norm = 0.0, p_data = 0.0, p_query = 0.0;
+    float greg = 0.f;
+    if (obj.kind == 0) {
+        if (obj.reg_kind == 1) {
+            // (|w| - 1)^2 + |w^ - q^|^2 ; |w^ - q^|^2 = w^.w^ - 2 w^.q^ + q^.q^  (q^ unit)
+            const double what_c = wc / nclamp;
+            const double whq = wq / nclamp;
+            const double d2 = block_sum(act ? (what_c - qhat[c]) * (what_c - qhat[c]) : 0.0);
+            reg_loss = (norm - 1.0) * (norm - 1.0) + d2;
+            if (act) {
+                const double diff = what_c - qhat[c];
+                // J'(diff), J = (I - w^ w^')/|w| ; w^.diff = w^.w^ - w^.q^
+                const double wd = ww / (nclamp * nclamp) - whq;
+                greg = (float)(2.0 * (norm - 1.0) * (wc / nclamp) + 2.0 / nclamp * (diff - what_c * wd));
+            }
+        } else if (obj.reg_kind == 2 || obj.reg_kind == 3) {
+            const double target = obj.reg_kind == 3 ? 1.0 : 0.0;
+            reg_loss = (norm - target) * (norm - target);
+            if (act) greg = (float)(2.0 * (norm - target) * (wc / nclamp));
+        }
+        reg_loss *= obj.reg_weight;
+        greg *= obj.reg_weight;
+    } else {
+        // norm: l (cosh(log s) - 1), s = w.w ; d/dw = l (1 - 1/s^2) w
+        p_norm = obj.l_norm * (0.5 * (ww + 1.0 / ww) - 1.0);
+        // data: l w'Mw ; d/dw = l (M + M') w
+        double mw = 0.0, mtw = 0.0;
+        if (act && obj.l_data != 0.f && xlx) {
+            for (int k = 0; k < dim; ++k) {
+                mw += (double)xlx[(int64_t)c * dim + k] * sw_[k];
+                mtw += (double)xlx[(int64_t)k * dim + c] * sw_[k];
+            }
+        }
+        p_data = obj.l_data * block_sum(act ? (double)wc * mw : 0.0);
+        // query: l (1 - w^.q^)/2 ; d/dw = -l/2 (q^ - (w^.q^) w^)/|w|
+        const double whq = wq / nclamp;
+        p_query = obj.l_query * (1.0 - whq) * 0.5;
+        if (act) {
+            const double what_c = wc / nclamp;
+            greg = (float)(obj.l_norm * (1.0 - 1.0 / (ww * ww)) * wc + obj.l_data * (mw + mtw) -
+                           obj.l_query * 0.5 * ((qhat ? qhat[c] : 0.f) - whq * what_c) / nclamp);
+        }
+        reg_loss = p_norm + p_data + p_query;
+    }
+    if (act) out[1 + c] = g + greg;
+    if (c == 0) {
+        out[0] = (float)(data_loss + reg_loss);
+        out[1 + dim] = obj.has_bias ? (float)rsum : 0.f;
+        float *parts = out + 1 + dim + 1;
+        parts[0] = (float)p_norm;
+        parts[1] = (float)p_data;
+        parts[2] = (float)p_query;
+        parts[3] = (float)data_loss;
+        (void)scal;
+    }
+}
+
+}  // namespace
+}  // namespace ssw
+
+using namespace ssw;
+
+struct ssw_fb {
+    int device = 0;
+    int dim = 0;
+    int64_t n = 0, cap = 0;
+    float *X = nullptr;        // [cap, dim] centred rows
+    float *mu = nullptr;       // [dim]
+    float *y = nullptr, *coef = nullptr, *z = nullptr, *item = nullptr, *r = nullptr;  // [cap]
+    int64_t *rows = nullptr;   // gather staging
+    float *partial = nullptr;  // [nslabs(cap), dim]
+    float *w = nullptr;        // [dim + 1]
+    float *qhat = nullptr;     // [dim]
+    float *xlx = nullptr;      // [dim, dim]
+    bool has_q = false, has_xlx = false;
+    float *out = nullptr;      // device [1 + dim + 1 + 4]
+    float *out_host = nullptr;  // pinned mirror
+    float *w_host = nullptr;    // pinned staging
+    hipStream_t stream = nullptr;
+    // targets (host copies, for the objective set-up)
+    std::vector<float> y_host, sw_host;
+    // diagnostics of the last fit
+    int last_iters = 0, last_evals = 0;
+};
+
+static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
+    if (n <= fb->cap) return SSW_OK;
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    (void)hipFree(fb->X);
+    (void)hipFree(fb->y);
+    (void)hipFree(fb->coef);
+    (void)hipFree(fb->z);
+    (void)hipFree(fb->item);
+    (void)hipFree(fb->r);
+    (void)hipFree(fb->rows);
+    (void)hipFree(fb->partial);
+    fb->X = fb->y = fb->coef = fb->z = fb->item = fb->r = fb->partial = nullptr;
+    fb->rows = nullptr;
+    fb->cap = 0;
+    int64_t cap = 256;
+    while (cap < n) cap <<= 1;
+    const int64_t nslabs = (cap + FB_SLAB - 1) / FB_SLAB;
+    SSW_HIP_TRY(hipMalloc((void **)&fb->X, (size_t)cap * fb->dim * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->y, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->coef, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->z, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->item, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->r, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->rows, (size_t)cap * sizeof(int64_t)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->partial, (size_t)nslabs * fb->dim * sizeof(float)));
+    fb->cap = cap;
+    return SSW_OK;
+}
+
+static ssw_status fb_center(ssw_fb *fb, int center) {
+    if (center && fb->n > 0) {
+        hipLaunchKernelGGL(k_fb_center, dim3((fb->dim + 63) / 64), dim3(64), 0, fb->stream, fb->X, fb->n,
+                           fb->dim, fb->mu);
+        SSW_HIP_TRY(hipGetLastError());
+    } else {
+        SSW_HIP_TRY(hipMemsetAsync(fb->mu, 0, (size_t)fb->dim * sizeof(float), fb->stream));
+    }
+    return SSW_OK;
+}
+
+// effective per-item coefficients + pos_weight + data-loss scale for an objective
+static ssw_status fb_prepare(ssw_fb *fb, const ssw_fb_objective *o, FbObjDev *dev, float *pw_out,
+                             bool *pairwise_active) {
+    const int64_t n = fb->n;
+    std::vector<float> coef((size_t)n);
+    *pairwise_active = false;
+    memset(dev, 0, sizeof(*dev));
+    dev->kind = o->kind;
+    if (o->kind == SSW_FB_LOGREG) {
+        // mean over items of weight_i * bce(.; pos_weight)   (logistic_regression.py:98-105)
+        for (int64_t i = 0; i < n; ++i) coef[(size_t)i] = fb->sw_host.empty() ? 1.f : fb->sw_host[(size_t)i];
+        *pw_out = o->pos_weight;
+        dev->has_bias = o->fit_intercept ? 1 : 0;
+        dev->reg_kind = o->reg_kind;
+        dev->scale = n > 0 ? 1.f / (float)n : 0.f;
+        dev->reg_weight = o->reg_weight;
+        if (o->reg_kind == 1 && !fb->has_q) {
+            set_error("feedback: vector regulariser needs ssw_fb_set_query first");
+            return SSW_ERR_INVALID;
+        }
+    } else if (o->kind == SSW_FB_MULTIREG) {
+        dev->scale = 1.f;
+        dev->l_norm = o->reg_norm_lambda;
+        dev->l_data = o->reg_data_lambda;
+        dev->l_query = o->reg_query_lambda;
+        if (!fb->has_q) {
+            set_error("feedback: multireg needs ssw_fb_set_query first");
+            return SSW_ERR_INVALID;
+        }
+        if (o->reg_data_lambda != 0.f && !fb->has_xlx) {
+            set_error("feedback: reg_data_lambda != 0 needs ssw_fb_set_xlx first");
+            return SSW_ERR_INVALID;
+        }
+        // sample_weight bookkeeping of RegModule._step (multi_reg.py:85-105), in f32 like torch
+        float orig_sum = 0.f, pos_total = 0.f;
+        for (int64_t i = 0; i < n; ++i) {
+            const float s = fb->sw_host.empty() ? 1.f : fb->sw_host[(size_t)i];
+            coef[(size_t)i] = s;
+            orig_sum += s;
+            if (fb->y_host[(size_t)i] == 1.f) pos_total += s;
+        }
+        const float neg_total = orig_sum - pos_total;
+        *pw_out = 1.f;
+        if (o->loss_type == SSW_FB_LOSS_CE) {
+            const float positive_weight = o->pos_weight < 0.f ? (neg_total + 1.f) / (pos_total + 1.f) : o->pos_weight;
+            float new_sum = 0.f;
+            for (int64_t i = 0; i < n; ++i) {
+                if (fb->y_host[(size_t)i] == 1.f) coef[(size_t)i] *= positive_weight;
+                new_sum += coef[(size_t)i];
+            }
+            const float f = n > 0 ? orig_sum / new_sum : 0.f;
+            for (int64_t i = 0; i < n; ++i) coef[(size_t)i] *= f;
+        } else {
+            *pairwise_active = (pos_total > 0.f && neg_total > 0.f);
+            if (n > FB_MAX_PAIRWISE) {
+                set_error("feedback: pairwise losses take at most %d items, got %lld", FB_MAX_PAIRWISE, (long long)n);
+                return SSW_ERR_UNSUPPORTED;
+            }
+        }
+    } else {
+        set_error("feedback: unknown objective kind %d", o->kind);
+        return SSW_ERR_INVALID;
+    }
+    if (n > 0)
+        SSW_HIP_TRY(hipMemcpyAsync(fb->coef, coef.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+    // coef is a local: the copy must be staged before it goes out of scope
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    return SSW_OK;
+}
+
+// one closure evaluation at the parameters in fb->w_host; results land in fb->out_host
+static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev &dev, float pw,
+                          bool pairwise_active, int P) {
+    hipStream_t s = fb->stream;
+    const int64_t n = fb->n;
+    const int dim = fb->dim;
+    SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)P * sizeof(float), hipMemcpyHostToDevice, s));
+    int nslabs = 0;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->w, n, dim,
+                           dev.has_bias, fb->z);
+        const bool pairwise = o->kind == SSW_FB_MULTIREG && o->loss_type != SSW_FB_LOSS_CE;
+        if (!pairwise) {
+            hipLaunchKernelGGL(k_fb_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->z, fb->y, fb->coef,
+                               pw, n, fb->item, fb->r);
+        } else if (pairwise_active) {
+            const size_t lds = (size_t)3 * n * sizeof(float);
+            if (o->loss_type == SSW_FB_LOSS_PAIRWISE_LOGISTIC)
+                hipLaunchKernelGGL(k_fb_pairwise<1>, dim3(1), dim3(1024), lds, s, fb->z, fb->y, fb->coef, o->margin,
+                                   (int)n, fb->item, fb->r);
+            else
+                hipLaunchKernelGGL(k_fb_pairwise<0>, dim3(1), dim3(1024), lds, s, fb->z, fb->y, fb->coef, o->margin,
+                                   (int)n, fb->item, fb->r);
+        } else {  // only one class labelled so far: the label loss is identically 0 (multi_reg.py:107)
+            SSW_HIP_TRY(hipMemsetAsync(fb->item, 0, (size_t)n * sizeof(float), s));
+            SSW_HIP_TRY(hipMemsetAsync(fb->r, 0, (size_t)n * sizeof(float), s));
+        }
+        nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
+        const int tx = dim < 256 ? dim : 256;
+        hipLaunchKernelGGL(k_fb_grad, dim3((unsigned)nslabs, (unsigned)((dim + tx - 1) / tx)), dim3(tx), 0, s, fb->X,
+                           fb->r, n, dim, fb->partial);
+    }
+    hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim, fb->w,
+                       fb->has_q ? fb->qhat : (const float *)nullptr, fb->has_xlx ? fb->xlx : (const float *)nullptr,
+                       dev, fb->out);
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_HIP_TRY(hipMemcpyAsync(fb->out_host, fb->out, (size_t)(1 + dim + 1 + 4) * sizeof(float),
+                               hipMemcpyDeviceToHost, s));
+    SSW_HIP_TRY(hipStreamSynchronize(s));
+    fb->last_evals++;
+    return SSW_OK;
+}
+
+// ---- L-BFGS with strong-Wolfe line search ----------------------------------------------
+// Restatement of the algorithm torch.optim.LBFGS implements (minFunc's lbfgs / lswolfe with
+// cubic interpolation; defaults history 100, tolerance_grad 1e-7, tolerance_change 1e-9,
+// c1 1e-4, c2 0.9, max_ls 25), which is what the reference drives through
+// BasicTrainer.fit -> opt.step(closure) (basic_trainer.py:59-63).
+namespace {
+
+typedef std::vector<float> Vec;
+
+double vdot(const Vec &a, const Vec &b) {
+    double s = 0.0;
+    for (size_t i = 0; i < a.size(); ++i) s += (double)a[i] * b[i];
+    return (double)(float)s;
+}
+double vabsmax(const Vec &a) {
+    float m = 0.f;
+    for (float v : a) m = std::fmax(m, std::fabs(v));
+    return m;
+}
+
+double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2, bool has_bounds,
+                         double lo, double hi) {
+    double xmin = lo, xmax = hi;
+    if (!has_bounds) {
+        xmin = x1 <= x2 ? x1 : x2;
+        xmax = x1 <= x2 ? x2 : x1;
+    }
+    const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
+    const double d2sq = d1 * d1 - g1 * g2;
+    if (d2sq >= 0) {
+        const double d2 = std::sqrt(d2sq);
+        double mp;
+        if (x1 <= x2)
+            mp = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2));
+        else
+            mp = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2));
+        return std::fmin(std::fmax(mp, xmin), xmax);
+    }
+    return (xmin + xmax) / 2.0;
+}
+
+struct Evaluator {
+    ssw_fb *fb;
+    const ssw_fb_objective *o;
+    FbObjDev dev;
+    float pw;
+    bool pairwise_active;
+    int P;
+    ssw_status status = SSW_OK;
+    // f(x + t d) and its gradient
+    bool eval(const Vec &x, double t, const Vec &d, double *f, Vec *g) {
+        for (int i = 0; i < P; ++i) fb->w_host[i] = x[i] + (float)t * d[i];
+        status = fb_eval(fb, o, dev, pw, pairwise_active, P);
+        if (status != SSW_OK) return false;
+        *f = fb->out_host[0];
+        g->assign(fb->out_host + 1, fb->out_host + 1 + P);
+        if (!std::isfinite(*f)) {
+            set_error("feedback: loss diverged (%g) -- regression training failed with a nan", *f);
+            status = SSW_ERR_NUMERIC;  // logistic_regression.py:398-401
+            return false;
+        }
+        return true;
+    }
+};
+
+// returns false on evaluator failure
+bool strong_wolfe(Evaluator &E, const Vec &x, double t, const Vec &d, double f, const Vec &g, double gtd,
+                  double *f_out, Vec *g_out, double *t_out, int *evals, double c1 = 1e-4, double c2 = 0.9,
+                  double tol_change = 1e-9, int max_ls = 25) {
+    const double d_norm = vabsmax(d);
+    double f_new;
+    Vec g_new;
+    if (!E.eval(x, t, d, &f_new, &g_new)) return false;
+    int ls_evals = 1;
+    double gtd_new = vdot(g_new, d);
+    double t_prev = 0, f_prev = f, gtd_prev = gtd;
+    Vec g_prev = g;
+    bool done = false;
+    int ls_iter = 0;
+    double br[2] = {0, 0}, br_f[2] = {0, 0}, br_gtd[2] = {0, 0};
+    Vec br_g[2];
+    int nbr = 0;
+    while (ls_iter < max_ls) {
+        if (f_new > (f + c1 * t * gtd) || (ls_iter > 1 && f_new >= f_prev)) {
+            br[0] = t_prev; br[1] = t; br_f[0] = f_prev; br_f[1] = f_new;
+            br_g[0] = g_prev; br_g[1] = g_new; br_gtd[0] = gtd_prev; br_gtd[1] = gtd_new; nbr = 2;
+            break;
+        }
+        if (std::fabs(gtd_new) <= -c2 * gtd) {
+            br[0] = t; br_f[0] = f_new; br_g[0] = g_new; nbr = 1;
+            done = true;
+            break;
+        }
+        if (gtd_new >= 0) {
+            br[0] = t_prev; br[1] = t; br_f[0] = f_prev; br_f[1] = f_new;
+            br_g[0] = g_prev; br_g[1] = g_new; br_gtd[0] = gtd_prev; br_gtd[1] = gtd_new; nbr = 2;
+            break;
+        }
+        const double min_step = t + 0.01 * (t - t_prev), max_step = t * 10;
+        const double tmp = t;
+        t = cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, min_step, max_step);
+        t_prev = tmp; f_prev = f_new; g_prev = g_new; gtd_prev = gtd_new;
+        if (!E.eval(x, t, d, &f_new, &g_new)) return false;
+        ls_evals++;
+        gtd_new = vdot(g_new, d);
+        ls_iter++;
+    }
+    if (ls_iter == max_ls) {
+        br[0] = 0; br[1] = t; br_f[0] = f; br_f[1] = f_new; br_g[0] = g; br_g[1] = g_new; nbr = 2;
+        br_gtd[0] = gtd; br_gtd[1] = gtd_new;
+    }
+    bool insuf = false;
+    int low = 0, high = 0;
+    if (nbr == 2) {
+        low = br_f[0] <= br_f[1] ? 0 : 1;
+        high = 1 - low;
+    }
+    while (!done && ls_iter < max_ls) {
+        if (std::fabs(br[1] - br[0]) * d_norm < tol_change) break;
+        t = cubic_interpolate(br[0], br_f[0], br_gtd[0], br[1], br_f[1], br_gtd[1], false, 0, 0);
+        const double bmax = std::fmax(br[0], br[1]), bmin = std::fmin(br[0], br[1]);
+        const double eps = 0.1 * (bmax - bmin);
+        if (std::fmin(bmax - t, t - bmin) < eps) {
+            if (insuf || t >= bmax || t <= bmin) {
+                t = (std::fabs(t - bmax) < std::fabs(t - bmin)) ? bmax - eps : bmin + eps;
+                insuf = false;
+            } else {
+                insuf = true;
+            }
+        } else {
+            insuf = false;
+        }
+        if (!E.eval(x, t, d, &f_new, &g_new)) return false;
+        ls_evals++;
+        gtd_new = vdot(g_new, d);
+        ls_iter++;
+        if (f_new > (f + c1 * t * gtd) || f_new >= br_f[low]) {
+            br[high] = t; br_f[high] = f_new; br_g[high] = g_new; br_gtd[high] = gtd_new;
+            low = br_f[0] <= br_f[1] ? 0 : 1;
+            high = 1 - low;
+        } else {
+            if (std::fabs(gtd_new) <= -c2 * gtd) {
+                done = true;
+            } else if (gtd_new * (br[high] - br[low]) >= 0) {
+                br[high] = br[low]; br_f[high] = br_f[low]; br_g[high] = br_g[low]; br_gtd[high] = br_gtd[low];
+            }
+            br[low] = t; br_f[low] = f_new; br_g[low] = g_new; br_gtd[low] = gtd_new;
+        }
+    }
+    *t_out = br[low];
+    *f_out = br_f[low];
+    *g_out = br_g[low];
+    *evals = ls_evals;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+ssw_status ssw_fb_destroy(ssw_fb *fb) {
+    if (!fb) return SSW_OK;
+    DeviceGuard guard(fb->device);
+    if (fb->stream) (void)hipStreamSynchronize(fb->stream);
+    (void)hipFree(fb->X);
+    (void)hipFree(fb->mu);
+    (void)hipFree(fb->y);
+    (void)hipFree(fb->coef);
+    (void)hipFree(fb->z);
+    (void)hipFree(fb->item);
+    (void)hipFree(fb->r);
+    (void)hipFree(fb->rows);
+    (void)hipFree(fb->partial);
+    (void)hipFree(fb->w);
+    (void)hipFree(fb->qhat);
+    (void)hipFree(fb->xlx);
+    (void)hipFree(fb->out);
+    if (fb->out_host) (void)hipHostFree(fb->out_host);
+    if (fb->w_host) (void)hipHostFree(fb->w_host);
+    if (fb->stream) (void)hipStreamDestroy(fb->stream);
+    delete fb;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
+    SSW_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    if (dim <= 0 || dim % 4 != 0 || dim > 1024) {
+        set_error("feedback: dim=%d unsupported (multiple of 4, <= 1024)", dim);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", device);
+        return SSW_ERR_HIP;
+    }
+    ssw_fb *fb = new (std::nothrow) ssw_fb();
+    if (!fb) return SSW_ERR_NOMEM;
+    fb->device = device;
+    fb->dim = dim;
+    const size_t outn = (size_t)(1 + dim + 1 + 4);
+    if (hipStreamCreateWithFlags(&fb->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&fb->mu, (size_t)dim * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&fb->w, (size_t)(dim + 1) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&fb->qhat, (size_t)dim * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&fb->xlx, (size_t)dim * dim * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&fb->out, outn * sizeof(float)) != hipSuccess ||
+        hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&fb->w_host, (size_t)(dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        set_error("feedback: allocation failed");
+        ssw_fb_destroy(fb);
+        return SSW_ERR_NOMEM;
+    }
+    *out = fb;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_set_data(ssw_fb *fb, const float *X_host, int64_t n, int32_t center) {
+    SSW_REQUIRE(fb != nullptr && n >= 0 && (n == 0 || X_host != nullptr), "bad argument");
+    DeviceGuard guard(fb->device);
+    SSW_TRY(fb_reserve(fb, n));
+    fb->n = n;
+    if (n > 0)
+        SSW_HIP_TRY(hipMemcpyAsync(fb->X, X_host, (size_t)n * fb->dim * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+    SSW_TRY(fb_center(fb, center));
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int64_t n_matrix_rows,
+                                       const int64_t *rows_host, int64_t n, int32_t center) {
+    SSW_REQUIRE(fb != nullptr && dev_matrix != nullptr && n >= 0 && (n == 0 || rows_host != nullptr), "bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        SSW_REQUIRE(rows_host[i] >= 0 && rows_host[i] < n_matrix_rows, "row %lld outside [0, %lld)",
+                    (long long)rows_host[i], (long long)n_matrix_rows);
+    DeviceGuard guard(fb->device);
+    SSW_TRY(fb_reserve(fb, n));
+    fb->n = n;
+    if (n > 0) {
+        SSW_HIP_TRY(hipMemcpyAsync(fb->rows, rows_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, fb->stream));
+        hipLaunchKernelGGL(k_fb_gather_rows, dim3((unsigned)n), dim3(128), 0, fb->stream, dev_matrix, fb->rows, n,
+                           fb->dim, fb->X);
+        SSW_HIP_TRY(hipGetLastError());
+    }
+    SSW_TRY(fb_center(fb, center));
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_set_targets(ssw_fb *fb, const float *y_host, const float *sample_weight_or_null) {
+    SSW_REQUIRE(fb != nullptr && (fb->n == 0 || y_host != nullptr), "bad argument");
+    DeviceGuard guard(fb->device);
+    const int64_t n = fb->n;
+    fb->y_host.assign(y_host, y_host + n);
+    if (sample_weight_or_null)
+        fb->sw_host.assign(sample_weight_or_null, sample_weight_or_null + n);
+    else
+        fb->sw_host.clear();
+    for (int64_t i = 0; i < n; ++i)
+        SSW_REQUIRE(std::isfinite(y_host[i]), "target %lld is not finite", (long long)i);
+    if (n > 0) {
+        SSW_HIP_TRY(hipMemcpyAsync(fb->y, fb->y_host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+        SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    }
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_set_query(ssw_fb *fb, const float *q_host) {
+    SSW_REQUIRE(fb != nullptr && q_host != nullptr, "bad argument");
+    DeviceGuard guard(fb->device);
+    double nn = 0;
+    for (int i = 0; i < fb->dim; ++i) nn += (double)q_host[i] * q_host[i];
+    SSW_REQUIRE(nn > 0 && std::isfinite(nn), "query vector has zero or non-finite norm");
+    const double inv = 1.0 / std::fmax(std::sqrt(nn), 1e-12);
+    std::vector<float> qh((size_t)fb->dim);
+    for (int i = 0; i < fb->dim; ++i) qh[(size_t)i] = (float)(q_host[i] * inv);  // F.normalize
+    SSW_HIP_TRY(hipMemcpy(fb->qhat, qh.data(), (size_t)fb->dim * sizeof(float), hipMemcpyHostToDevice));
+    fb->has_q = true;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_set_xlx(ssw_fb *fb, const float *xlx_host) {
+    SSW_REQUIRE(fb != nullptr && xlx_host != nullptr, "bad argument");
+    DeviceGuard guard(fb->device);
+    SSW_HIP_TRY(hipMemcpy(fb->xlx, xlx_host, (size_t)fb->dim * fb->dim * sizeof(float), hipMemcpyHostToDevice));
+    fb->has_xlx = true;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_get_mean(ssw_fb *fb, float *out_mu_host) {
+    SSW_REQUIRE(fb != nullptr && out_mu_host != nullptr, "bad argument");
+    DeviceGuard guard(fb->device);
+    SSW_HIP_TRY(hipMemcpy(out_mu_host, fb->mu, (size_t)fb->dim * sizeof(float), hipMemcpyDeviceToHost));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_lossgrad(ssw_fb *fb, const ssw_fb_objective *obj, const float *w_host, float *out_loss,
+                           float *out_grad, float *out_parts4_or_null) {
+    SSW_REQUIRE(fb && obj && w_host && out_loss && out_grad, "NULL argument");
+    DeviceGuard guard(fb->device);
+    const int P = fb->dim + ((obj->kind == SSW_FB_LOGREG && obj->fit_intercept) ? 1 : 0);
+    FbObjDev dev;
+    float pw = 1.f;
+    bool pa = false;
+    SSW_TRY(fb_prepare(fb, obj, &dev, &pw, &pa));
+    memcpy(fb->w_host, w_host, (size_t)P * sizeof(float));
+    if (P == fb->dim) fb->w_host[fb->dim] = 0.f;
+    SSW_TRY(fb_eval(fb, obj, dev, pw, pa, fb->dim + 1));
+    *out_loss = fb->out_host[0];
+    memcpy(out_grad, fb->out_host + 1, (size_t)P * sizeof(float));
+    if (out_parts4_or_null) memcpy(out_parts4_or_null, fb->out_host + 1 + fb->dim + 1, 4 * sizeof(float));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_scores(ssw_fb *fb, const float *w_host, int32_t has_bias, float *out_logits) {
+    SSW_REQUIRE(fb && w_host && (fb->n == 0 || out_logits), "NULL argument");
+    DeviceGuard guard(fb->device);
+    if (fb->n == 0) return SSW_OK;
+    memcpy(fb->w_host, w_host, (size_t)(fb->dim + (has_bias ? 1 : 0)) * sizeof(float));
+    SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)(fb->dim + 1) * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+    hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((fb->n + 3) / 4)), dim3(256), 0, fb->stream, fb->X, fb->w, fb->n,
+                       fb->dim, has_bias, fb->z);
+    SSW_HIP_TRY(hipMemcpyAsync(out_logits, fb->z, (size_t)fb->n * sizeof(float), hipMemcpyDeviceToHost, fb->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, int32_t max_iter, float lr,
+                      int32_t *out_iters, int32_t *out_evals, float *out_final_loss) {
+    SSW_REQUIRE(fb && obj && w_inout, "NULL argument");
+    SSW_REQUIRE(max_iter >= 1, "max_iter < 1");
+    DeviceGuard guard(fb->device);
+    const int P = fb->dim + ((obj->kind == SSW_FB_LOGREG && obj->fit_intercept) ? 1 : 0);
+    Evaluator E;
+    E.fb = fb;
+    E.o = obj;
+    E.P = fb->dim + 1;  // the device always sees dim+1 parameters; slot dim is the (maybe unused) bias
+    SSW_TRY(fb_prepare(fb, obj, &E.dev, &E.pw, &E.pairwise_active));
+    fb->last_evals = 0;
+    const int history = 100;
+    const double tol_grad = 1e-7, tol_change = 1e-9;
+    const int max_eval = max_iter * 5 / 4;
+    Vec x(E.P, 0.f), d(E.P, 0.f), g, prev_g, zero(E.P, 0.f);
+    for (int i = 0; i < P; ++i) {
+        SSW_REQUIRE(std::isfinite(w_inout[i]), "initial weight %d is not finite", i);
+        x[i] = w_inout[i];
+    }
+    double loss;
+    if (!E.eval(x, 0.0, zero, &loss, &g)) return E.status;
+    if (P == fb->dim) g[fb->dim] = 0.f;
+    int current_evals = 1, n_iter = 0;
+    double t = 0, prev_loss = loss, H_diag = 1.0;
+    std::vector<Vec> old_dirs, old_stps;
+    std::vector<double> ro;
+    bool opt_cond = vabsmax(g) <= tol_grad;
+    while (!opt_cond && n_iter < max_iter) {
+        n_iter++;
+        if (n_iter == 1) {
+            for (int i = 0; i < E.P; ++i) d[i] = -g[i];
+            H_diag = 1.0;
+        } else {
+            Vec yv(E.P), sv(E.P);
+            for (int i = 0; i < E.P; ++i) {
+                yv[i] = g[i] - prev_g[i];
+                sv[i] = d[i] * (float)t;
+            }
+            const double ys = vdot(yv, sv);
+            if (ys > 1e-10) {
+                if ((int)old_dirs.size() == history) {
+                    old_dirs.erase(old_dirs.begin());
+                    old_stps.erase(old_stps.begin());
+                    ro.erase(ro.begin());
+                }
+                old_dirs.push_back(yv);
+                old_stps.push_back(sv);
+                ro.push_back(1.0 / ys);
+                H_diag = ys / vdot(yv, yv);
+            }
+            const int m = (int)old_dirs.size();
+            std::vector<double> al((size_t)m);
+            Vec q(E.P);
+            for (int i = 0; i < E.P; ++i) q[i] = -g[i];
+            for (int i = m - 1; i >= 0; --i) {
+                al[(size_t)i] = vdot(old_stps[(size_t)i], q) * ro[(size_t)i];
+                for (int j = 0; j < E.P; ++j) q[j] -= (float)al[(size_t)i] * old_dirs[(size_t)i][j];
+            }
+            for (int j = 0; j < E.P; ++j) d[j] = q[j] * (float)H_diag;
+            for (int i = 0; i < m; ++i) {
+                const double be = vdot(old_dirs[(size_t)i], d) * ro[(size_t)i];
+                for (int j = 0; j < E.P; ++j) d[j] += (float)(al[(size_t)i] - be) * old_stps[(size_t)i][j];
+            }
+        }
+        prev_g = g;
+        prev_loss = loss;
+        if (n_iter == 1) {
+            double gs = 0;
+            for (float v : g) gs += std::fabs(v);
+            t = std::fmin(1.0, 1.0 / gs) * lr;
+        } else {
+            t = lr;
+        }
+        const double gtd = vdot(g, d);
+        if (gtd > -tol_change) break;
+        double f_new, t_new;
+        Vec g_new;
+        int ls_evals = 0;
+        if (!strong_wolfe(E, x, t, d, loss, g, gtd, &f_new, &g_new, &t_new, &ls_evals)) return E.status;
+        loss = f_new;
+        g = g_new;
+        if (P == fb->dim) g[fb->dim] = 0.f;
+        t = t_new;
+        for (int i = 0; i < E.P; ++i) x[i] += (float)t * d[i];
+        opt_cond = vabsmax(g) <= tol_grad;
+        current_evals += ls_evals;
+        if (n_iter == max_iter) break;
+        if (current_evals >= max_eval) break;
+        if (opt_cond) break;
+        double dm = 0;
+        for (int i = 0; i < E.P; ++i) dm = std::fmax(dm, std::fabs((double)d[i] * t));
+        if (dm <= tol_change) break;
+        if (std::fabs(loss - prev_loss) < tol_change) break;
+    }
+    for (int i = 0; i < P; ++i) {
+        if (!std::isfinite(x[i])) {
+            set_error("feedback: weights diverged");
+            return SSW_ERR_NUMERIC;
+        }
+        w_inout[i] = x[i];
+    }
+    fb->last_iters = n_iter;
+    if (out_iters) *out_iters = n_iter;
+    if (out_evals) *out_evals = fb->last_evals;
+    if (out_final_loss) *out_final_loss = (float)loss;
+    return SSW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""LogisticRegressionPT: linear relevance scorer with a query-vector regulariser, fitted by
+L-BFGS -- the reference's interface (seesaw/logistic_regression.py:270-421) over the HIP
+feedback engine (loss + gradient kernels and the L-BFGS driver in libseesaw_hip.so)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import FbObjective
+from .feedback import FeedbackEngine
+
+
+def _default_linear_init(dim: int, fit_intercept: bool):
+    """nn.Linear(dim, 1)'s default initialisation (what LogisticRegModule starts from,
+    logistic_regression.py:71), drawn from torch's global generator so torch.manual_seed
+    governs it exactly as in the reference."""
+    import torch
+    lin = torch.nn.Linear(dim, 1, bias=fit_intercept)
+    w = lin.weight.detach().numpy().reshape(-1).copy()
+    b = lin.bias.detach().numpy().reshape(-1).copy() if fit_intercept else np.zeros(0, np.float32)
+    return np.concatenate([w, b]).astype(np.float32)
+
+
+class LogisticRegressionPT:
+    def __init__(self, *, class_weights, scale, reg_lambda, regularizer_vector, fit_intercept, verbose=False,
+                 max_iter=100, lr=1.0, device: int = 0, **kwargs):
+        """regularizer_vector: ndarray -> pull the direction towards that vector; 'norm' /
+        'norm1' -> only a norm penalty; None -> no regulariser."""
+        assert scale in ["centered", None]
+        self.class_weights = class_weights
+        self.scale = scale
+        self.reg_lambda = reg_lambda
+        self.verbose = verbose
+        self.fit_intercept = bool(fit_intercept)
+        self.max_iter = int(max_iter)
+        self.lr = float(lr)
+        self.kwargs = kwargs
+        self.mu_ = None
+        self.coef_ = None        # [dim] (+1 with intercept) f32 -- the fitted parameters
+        self.losses_ = None
+        self.regularizer_vector = None
+        if isinstance(regularizer_vector, np.ndarray):
+            v = regularizer_vector.reshape(-1).astype(np.float32)
+            self.regularizer_vector = v / max(float(np.linalg.norm(v)), 1e-12)
+            self.regularization_type = "vector"
+        elif isinstance(regularizer_vector, str):
+            assert regularizer_vector in ("norm", "norm1")
+            self.regularization_type = regularizer_vector
+        else:
+            assert regularizer_vector is None
+            self.regularization_type = None
+        self._device = device
+        self._engine = None
+        self._dim = None
+
+    # ---- helpers ------------------------------------------------------------------------
+    def _objective(self, n_examples: int, pos_weight: float) -> FbObjective:
+        reg_kind = {None: _lib.SSW_FB_REG_NONE, "vector": _lib.SSW_FB_REG_VECTOR, "norm": _lib.SSW_FB_REG_NORM,
+                    "norm1": _lib.SSW_FB_REG_NORM1}[self.regularization_type]
+        return FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=int(self.fit_intercept),
+                           reg_kind=reg_kind, pos_weight=float(pos_weight),
+                           reg_weight=float(self.reg_lambda) / n_examples, margin=0.0,
+                           reg_norm_lambda=0.0, reg_data_lambda=0.0, reg_query_lambda=0.0)
+
+    def _ensure_engine(self, dim: int):
+        if self._engine is None or self._dim != dim:
+            self._engine = FeedbackEngine(dim, device=self._device)
+            self._dim = dim
+            if self.regularizer_vector is not None:
+                self._engine.set_query(self.regularizer_vector)
+
+    # ---- reference interface ------------------------------------------------------------
+    def fit(self, X, y, sample_weights=None, w0: np.ndarray = None, index=None, rows=None):
+        """X [n, dim] (or `index` + `rows` to gather the vectors on the device), y [n] or [n,1]."""
+        y = np.asarray(y, dtype=np.float64).reshape(-1)
+        n_examples = y.shape[0]
+        dim = X.shape[1] if X is not None else index.dim
+        self._ensure_engine(dim)
+        center = self.scale == "centered"
+        if X is not None:
+            self._engine.set_data(X, center=center)
+        else:
+            self._engine.set_data_from_index(index, rows, center=center)
+        self.mu_ = self._engine.mean()
+        if self.class_weights == "balanced":
+            npos, nneg = int((y == 1).sum()), int((y == 0).sum())
+            pos_weight = max(nneg, 1) / max(npos, 1)
+        else:
+            pos_weight = float(self.class_weights)
+        if self.coef_ is None:
+            start = _default_linear_init(dim, self.fit_intercept) if w0 is None else np.asarray(w0, np.float32).reshape(-1)
+        else:  # warm start, as the reference (which has not implemented it for 'balanced')
+            assert self.class_weights != "balanced", "implement this case"
+            start = self.coef_
+        self._engine.set_targets(y, sample_weights)
+        obj = self._objective(n_examples, pos_weight)
+        try:
+            w, info = self._engine.fit(obj, start, max_iter=self.max_iter, lr=self.lr)
+        except _lib.SeesawHipError as e:
+            if e.status == -5:
+                raise ValueError("regression training failed with a nan") from e
+            raise
+        if math.isnan(info["loss"]) or math.isinf(info["loss"]):
+            raise ValueError("regression training failed with a nan")
+        self.coef_ = w
+        self.losses_ = [{"k": "total_loss", "loss": info["loss"]}]
+        self.info_ = info
+        if self.verbose:
+            print(f"regression converged after {info['n_iter']} iterations. final_loss={info['loss']}")
+
+    def get_coeff(self):
+        assert self.coef_ is not None
+        return self.coef_[: self._dim].reshape(1, -1).copy()
+
+    def get_intercept(self):
+        b = self.coef_[self._dim] if self.fit_intercept else 0.0
+        return np.array([-(self.coef_[: self._dim] @ self.mu_) + b], dtype=np.float32)
+
+    def predict_proba(self, X):
+        X = np.asarray(X, dtype=np.float32)
+        if self.scale == "centered":
+            X = X - self.mu_.reshape(1, -1)
+        z = X @ self.coef_[: self._dim] + (self.coef_[self._dim] if self.fit_intercept else 0.0)
+        return (1.0 / (1.0 + np.exp(-z))).reshape(-1, 1).astype(np.float32)

@@ -1,0 +1,135 @@
+"""GPU parity of the relevance-feedback update (ssw_fb_* through seesaw_amd.feedback /
+seesaw_amd.logistic_regression / seesaw_amd.loops.multi_reg) against values captured from the
+reference (tests/golden/logreg.npz, multireg.npz) and the torch-CPU oracle.
+Tolerance: BASELINE.json north_star -- logits / rank scores within 1e-4 (f32)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+# fitted coefficients: L-BFGS stops on tolerances; the reference's own run-to-run spread (row
+# shuffling in its DataLoader) is 1.56e-4 in rank scores on the flattest golden case, so
+# fits are held to 2.5e-4 while single loss/gradient evaluations are held to 1e-4.
+FIT_TOL = 2.5e-4
+
+
+def _multireg_obj(lt, data_lam, query_lam):
+    from seesaw_amd import _lib
+    code = {"ce_loss": 0, "pairwise_rank_loss": 1, "pairwise_logistic_loss": 2}[lt]
+    return _lib.FbObjective(kind=_lib.SSW_FB_MULTIREG, loss_type=code, fit_intercept=0, reg_kind=0, pos_weight=-1.0,
+                            reg_weight=0.0, margin=0.2, reg_norm_lambda=100.0, reg_data_lambda=data_lam,
+                            reg_query_lambda=query_lam)
+
+
+def test_multireg_lossgrad_vs_reference_golden():
+    from seesaw_amd.feedback import FeedbackEngine
+    g = np.load(os.path.join(GOLDEN, "multireg.npz"))
+    eng = FeedbackEngine(512)
+    eng.set_xlx(g["xlx"])
+    for c in range(int(g["n_cases"])):
+        X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
+        _, inv, counts = np.unique(img, return_inverse=True, return_counts=True)
+        eng.set_data(X, center=True)
+        eng.set_targets(y, 1.0 / counts[inv])
+        eng.set_query(q)
+        obj = _multireg_obj(str(g[f"c{c}_loss_type"]), float(g[f"c{c}_data_lam"]), float(g[f"c{c}_query_lam"]))
+        w0 = q / np.linalg.norm(q)
+        loss, grad, parts = eng.lossgrad(obj, w0)
+        ref_loss, ref_grad, ref_parts = float(g[f"c{c}_loss0"]), g[f"c{c}_grad0"], g[f"c{c}_parts0"]
+        assert abs(loss - ref_loss) <= TOL * max(1.0, abs(ref_loss)), (c, loss, ref_loss)
+        assert np.abs(grad - ref_grad).max() <= TOL * max(1.0, np.abs(ref_grad).max()), c
+        assert np.allclose(parts, ref_parts, rtol=1e-4, atol=1e-5), (c, parts, ref_parts)
+
+
+def test_multireg_fit_vs_reference_golden():
+    from seesaw_amd.loops.multi_reg import RegModule
+    g = np.load(os.path.join(GOLDEN, "multireg.npz"))
+    import pandas as pd
+    for c in range(int(g["n_cases"])):
+        X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
+        mod = RegModule(dim=512, xlx_matrix=g["xlx"], qvec=q, label_loss_type=str(g[f"c{c}_loss_type"]),
+                        rank_loss_margin=0.2, reg_data_lambda=float(g[f"c{c}_data_lam"]), reg_norm_lambda=100.0,
+                        use_qvec_norm=None, reg_query_lambda=float(g[f"c{c}_query_lam"]), verbose=False,
+                        max_iter=200, pos_weight="balanced", lr=1.0)
+        mod.fit(X, y, pd.DataFrame({"dbidx": img, "ys": y}))
+        coeff = mod.get_coeff()
+        ref = g[f"c{c}_coeff"]
+        assert np.abs(X @ (coeff - ref)).max() < FIT_TOL, (c, np.abs(X @ (coeff - ref)).max())
+        assert np.abs(coeff - ref).max() < 5e-4, c
+        assert abs(np.linalg.norm(coeff) - 1) < 1e-5
+
+
+def test_logreg_fit_vs_reference_golden():
+    from seesaw_amd.logistic_regression import LogisticRegressionPT
+    g = np.load(os.path.join(GOLDEN, "logreg.npz"))
+    for c in range(int(g["n_cases"])):
+        X, y, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_q"]
+        cw = float(g[f"c{c}_cw"])
+        sw = g[f"c{c}_sw"]
+        model = LogisticRegressionPT(class_weights="balanced" if cw < 0 else cw, scale="centered",
+                                     reg_lambda=float(g[f"c{c}_lam"]), regularizer_vector=q, fit_intercept=False,
+                                     max_iter=200, lr=1.0)
+        model.fit(X, y.reshape(-1, 1), None if sw.size == 0 else sw.reshape(-1, 1), w0=g[f"c{c}_w0"].reshape(-1))
+        coeff, ref = model.get_coeff(), g[f"c{c}_coeff"]
+        assert coeff.shape == (1, 512)
+        Xc = X - X.mean(axis=0)
+        assert np.abs(Xc @ (coeff - ref).reshape(-1)).max() < FIT_TOL, (c, np.abs(Xc @ (coeff - ref).reshape(-1)).max())
+        assert np.abs(coeff - ref).max() < 5e-4, c
+        assert np.abs(model.predict_proba(X).reshape(-1) - g[f"c{c}_proba"]).max() < FIT_TOL
+
+
+def test_logreg_lossgrad_vs_oracle_with_intercept_and_pseudo_labels(oracle):
+    import torch
+    from oracle import feedback_oracle as fo
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    rng = np.random.default_rng(0)
+    n = 3000
+    X = oracle.synth_rows(77, 0, n, 512)
+    y = rng.uniform(0, 1, n)            # soft pseudo-labels (PseudoLR, loops/util.py:4-23)
+    y[:50] = (rng.uniform(size=50) > 0.5)
+    sw = np.ones(n)
+    sw[:50] = 3.0
+    q = oracle.synth_query(4)
+    w = (rng.standard_normal(513) * 0.05).astype(np.float32)
+    eng = FeedbackEngine(512)
+    eng.set_data(X, center=True)
+    eng.set_targets(y, sw)
+    eng.set_query(q)
+    obj = _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=1, reg_kind=_lib.SSW_FB_REG_VECTOR,
+                           pos_weight=2.5, reg_weight=1.0 / n, margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                           reg_query_lambda=0)
+    loss, grad, _ = eng.lossgrad(obj, w)
+    Xc = torch.from_numpy(X - X.astype(np.float64).mean(0).astype(np.float32))
+    wt = torch.tensor(w[:512], requires_grad=True)
+    bt = torch.tensor(w[512:], requires_grad=True)
+    import torch.nn.functional as F
+    qhat = F.normalize(torch.from_numpy(q).reshape(1, -1)).reshape(-1)
+    ref = fo.logreg_loss(wt, bt, Xc, torch.from_numpy(y), torch.from_numpy(sw).reshape(-1, 1), 2.5, 1.0 / n, qhat)
+    ref.backward()
+    assert abs(loss - ref.item()) < 1e-5
+    assert np.abs(grad[:512] - wt.grad.numpy()).max() < 1e-6
+    assert abs(grad[512] - bt.grad.item()) < 1e-6
+
+
+def test_fit_from_resident_index_rows(oracle):
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.logistic_regression import LogisticRegressionPT
+    X = oracle.synth_rows(5, 0, 4000, 512)
+    idx = DeviceIndex.from_numpy(X)
+    rows = np.arange(0, 4000, 37)
+    rng = np.random.default_rng(3)
+    y = (rng.uniform(size=rows.shape[0]) > 0.7).astype(np.float64)
+    q = oracle.synth_query(8)
+    w0 = (rng.standard_normal(512) * 0.04).astype(np.float32)
+    a = LogisticRegressionPT(class_weights="balanced", scale="centered", reg_lambda=1.0, regularizer_vector=q,
+                             fit_intercept=False, max_iter=50)
+    a.fit(X[rows], y, w0=w0)
+    b = LogisticRegressionPT(class_weights="balanced", scale="centered", reg_lambda=1.0, regularizer_vector=q,
+                             fit_intercept=False, max_iter=50)
+    b.fit(None, y, w0=w0, index=idx, rows=rows)
+    assert np.array_equal(a.get_coeff(), b.get_coeff())
+    idx.close()
