@@ -95,6 +95,11 @@ ssw_status ssw_index_scan(ssw_index *idx, const float *q_host, float *out_scores
 /* same, q already on the device, nothing copied back, no synchronisation. */
 ssw_status ssw_index_scan_dev(ssw_index *idx, const float *q_dev);
 
+/* replace the resident per-row scores with caller-supplied ones ([n_rows] f32, -inf = skip the
+ * row); a following ssw_index_topk(q_host = NULL) then ranks images by them.  Used to rank by
+ * label-propagation scores (KnnProp2.next_batch, seesaw/loops/graph_based.py:88-109). */
+ssw_status ssw_index_load_scores(ssw_index *idx, const float *scores_host);
+
 /* Top-k distinct images by their best-scoring row, skipping excluded images:
  * _get_top_exact + _get_top_dbidxs (multiscale_index.py:170-199).  Order: score
  * descending, ties by ascending image position.  q_host==NULL reuses the resident

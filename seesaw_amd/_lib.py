@@ -53,6 +53,7 @@ _SIGNATURES = {
     "ssw_index_set_row2image": (c_i32, [c_void_p, c_void_p, c_i64]),
     "ssw_index_scan": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_index_scan_dev": (c_i32, [c_void_p, c_void_p]),
+    "ssw_index_load_scores": (c_i32, [c_void_p, c_void_p]),
     "ssw_index_topk": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p,
                                c_void_p, c_i32_p]),
     "ssw_index_set_excluded": (c_i32, [c_void_p, c_void_p, c_i64]),

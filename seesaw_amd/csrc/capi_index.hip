@@ -369,6 +369,17 @@ ssw_status ssw_index_scan(ssw_index *idx, const float *q_host, float *out_scores
     return SSW_OK;
 }
 
+ssw_status ssw_index_load_scores(ssw_index *idx, const float *scores_host) {
+    SSW_REQUIRE(idx != nullptr && (idx->n == 0 || scores_host != nullptr), "NULL argument");
+    DeviceGuard guard(idx->device);
+    if (idx->n > 0) {
+        SSW_HIP_TRY(hipMemcpyAsync(idx->scores, scores_host, (size_t)idx->n * sizeof(float),
+                                   hipMemcpyHostToDevice, idx->stream));
+        SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    }
+    return SSW_OK;
+}
+
 ssw_status ssw_index_set_excluded(ssw_index *idx, const int64_t *excluded_images, int64_t n_excluded) {
     SSW_REQUIRE(idx != nullptr, "idx is NULL");
     SSW_REQUIRE(n_excluded == 0 || excluded_images != nullptr, "excluded_images is NULL");

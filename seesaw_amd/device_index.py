@@ -131,6 +131,12 @@ class DeviceIndex:
         c = cnt.value
         return imgs[:c], scs[:c], rows[:c]
 
+    def load_scores(self, scores: np.ndarray):
+        """overwrite the resident per-row scores (f32; -inf rows are never selected)."""
+        s = np.ascontiguousarray(scores, dtype=np.float32)
+        assert s.shape == (self.n_rows,)
+        _lib.call("ssw_index_load_scores", self._h, _ptr(s))
+
     def gather_scores(self, rows: np.ndarray) -> np.ndarray:
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         out = np.empty(rows.shape[0], dtype=np.float32)

@@ -189,6 +189,22 @@ class MultiscaleIndex(AccessMethod):
         df.attrs["best_rows"] = best_rows
         return df
 
+    def topk_from_scores(self, row_scores: np.ndarray, *, topk_dbidx, exclude_dbidx=None, skip_rows=None):
+        """same selection as _query_prelim but ranking by caller-supplied per-row scores
+        (label-propagation output); `skip_rows` (bool mask) drops rows, e.g. labelled vectors."""
+        s = np.asarray(row_scores, dtype=np.float32).copy()
+        if skip_rows is not None:
+            s[skip_rows] = -np.inf
+        excl_pos = self._excluded_positions(exclude_dbidx)
+        self._dev.load_scores(s)
+        self._resident_q = None
+        pos, scores, best_rows = self._dev.topk(None, max(1, min(int(topk_dbidx), self._dbidx.shape[0])), excluded=excl_pos)
+        keep = np.isfinite(scores)  # images whose every row was skipped do not take part
+        df = pd.DataFrame({"dbidx": self._dbidx[pos[keep]], "max_score": scores[keep]})
+        df.attrs["positions"] = pos[keep]
+        df.attrs["best_rows"] = best_rows[keep]
+        return df
+
     def _candidate_rows(self, positions: np.ndarray) -> np.ndarray:
         positions = np.sort(np.asarray(positions, dtype=np.int64))
         return np.concatenate([np.arange(self._row_start[p], self._row_start[p + 1]) for p in positions]) \

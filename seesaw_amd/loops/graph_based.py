@@ -1,0 +1,102 @@
+"""KnnProp2: rank by label propagation over the k-NN graph (seesaw/loops/graph_based.py:18-121),
+plus the weight-matrix / X'LX lookup shared with MultiReg and PseudoLR."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+from pydantic import BaseModel
+
+from ..bitmap import BitMap
+from ..indices.multiscale.multiscale_index import rescore_candidates
+from ..knn_graph import KNNGraph, get_weight_matrix, rbf_kernel
+from ..research.knn_methods import LabelPropagationRanker2
+from .loop_base import LoopBase
+
+_CACHE = {}  # process-local stand-in for the reference's Ray-backed `_cache_closure`
+
+
+class WeightMatrixOptions(BaseModel):
+    knn_path: str
+    knn_k: int
+    edist: float
+    self_edges: bool
+    normalized_weights: bool
+    symmetric: bool
+    xlx_matrix: bool = False
+
+
+def compute_xlx(laplacian, X_vectors: np.ndarray) -> np.ndarray:
+    """X' (L / trace L) X -- the database-alignment regulariser of MultiReg
+    (graph_based.py:45-49).  One-off per index, cached."""
+    L = laplacian / laplacian.diagonal().sum()
+    return np.asarray(X_vectors.T @ (L @ X_vectors))
+
+
+def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vectors=None, knng: KNNGraph = None):
+    key = opts.model_dump_json()
+    if opts.xlx_matrix:
+        assert opts.symmetric and not opts.self_edges
+    if use_cache and key in _CACHE:
+        return _CACHE[key]
+    print(f"init weight matrix {opts=}")
+    graph = (knng if knng is not None else KNNGraph.from_file(opts.knn_path)).restrict_k(k=opts.knn_k)
+    wm = get_weight_matrix(graph.knn_df, kfun=rbf_kernel(opts.edist), self_edges=opts.self_edges,
+                           normalized=opts.normalized_weights, symmetric=opts.symmetric, laplacian=opts.xlx_matrix)
+    if opts.xlx_matrix:
+        assert X_vectors is not None
+        wm = compute_xlx(wm, X_vectors)
+    if use_cache:
+        _CACHE[key] = wm
+    return wm
+
+
+def get_weight_matrix_from_index(idx, weight_matrix_options, xlx_matrix=False):
+    opts = WeightMatrixOptions(**weight_matrix_options)
+    opts.xlx_matrix = xlx_matrix
+    knng = getattr(idx, "knng", {}).get(opts.knn_path) if isinstance(getattr(idx, "knng", None), dict) else None
+    if knng is None:
+        opts.knn_path = os.path.normpath(os.path.abspath(os.path.realpath(idx.get_knng_path(name=opts.knn_path))))
+    else:  # in-memory graph attached to the index (synthetic datasets): key the cache by identity
+        opts.knn_path = f"mem:{id(idx)}:{opts.knn_path}"
+    use_cache = opts.knn_path.find("subset") == -1
+    return lookup_weight_matrix(opts, use_cache=use_cache, X_vectors=idx.vectors, knng=knng)
+
+
+def get_label_prop(q, label_prop_params):
+    W = get_weight_matrix_from_index(q.index, label_prop_params["matrix_options"])
+    params = {k: v for k, v in label_prop_params.items() if k != "matrix_options"}
+    return LabelPropagationRanker2(weight_matrix=W, device=getattr(q.index, "device", 0), **params)
+
+
+class KnnProp2(LoopBase):
+    def __init__(self, gdm, q, params, knn_model):
+        super().__init__(gdm, q, params)
+        self.state.knn_model = knn_model
+
+    @staticmethod
+    def from_params(gdm, q, p):
+        return KnnProp2(gdm, q, p, get_label_prop(q, p.interactive_options))
+
+    def set_text_vec(self, tvec):
+        super().set_text_vec(tvec)
+        self.state.knn_model.set_base_scores(self.q.index.score(tvec))
+
+    def next_batch(self):
+        """next images by propagated score: unlabelled vectors only, distinct non-returned
+        images, then the usual per-image aggregation (graph_based.py:88-109)."""
+        model, p, q = self.state.knn_model, self.params, self.q
+        scores = model.current_scores()
+        cand = q.index.topk_from_scores(scores, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned,
+                                        skip_rows=model.is_labeled > 0)
+        rows = q.index._candidate_rows(cand.attrs["positions"])
+        fullmeta = q.index.vector_meta.iloc[rows].assign(score=np.asarray(scores)[rows])
+        ans = rescore_candidates(fullmeta, topk=p.batch_size, **p.dict())
+        q.returned.update(np.asarray(ans["dbidxs"], dtype=np.int64))
+        return ans
+
+    def refine(self, change=None):
+        pos, neg = self.q.getXy(get_positions=True)
+        idxs = np.concatenate([pos, neg])
+        labels = np.concatenate([np.ones_like(pos), np.zeros_like(neg)])
+        self.state.knn_model.update(idxs, labels)

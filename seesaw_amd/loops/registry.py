@@ -1,0 +1,27 @@
+"""name -> loop class (seesaw/loops/registry.py:7-37).  The active-search planners
+(`active_search`, `lknn`) and `multi_reg_neg` of the reference are outside the accelerated
+hot path and are not registered."""
+
+
+def build_loop_from_params(gdm, q, params):
+    from .graph_based import KnnProp2
+    from .log_reg import LogReg2
+    from .multi_reg import MultiReg
+    from .point_based import Plain
+    from .pseudo_lr import PseudoLR
+    from .random_results import RandomResults
+    from .rocchio_update import RocchioUpdate
+
+    cls_dict = {
+        "knn_prop2": KnnProp2,
+        "plain": Plain,
+        "log_reg2": LogReg2,
+        "pseudo_lr": PseudoLR,
+        "multi_reg": MultiReg,
+        "rocchio_update": RocchioUpdate,
+        "random": RandomResults,
+    }
+    cls = cls_dict.get(params.interactive)
+    if cls is None:
+        raise KeyError(f"loop '{params.interactive}' is not part of the accelerated path; have {sorted(cls_dict)}")
+    return cls.from_params(gdm, q, params)

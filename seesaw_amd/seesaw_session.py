@@ -1,0 +1,154 @@
+"""Session: one user's search -- text query, batches of results, labels back, refine.
+
+Interface of seesaw/seesaw_session.py:12-245 (`set_text`, `next`, `update_state`, `refine`,
+`get_state`, `make_session`); control flow only, every numeric step is in the index / loop.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .basic_types import ActivationData, BenchParams, Box, Imdata, SessionParams, SessionState, is_image_accepted
+from .bitmap import BitMap
+from .indices.interface import AccessMethod
+from .labeldb import LabelDB
+from .loops.registry import build_loop_from_params
+
+
+class Session:
+    def __init__(self, gdm, dataset, hdb: AccessMethod, params: SessionParams, _y: np.ndarray = None):
+        self.gdm = gdm
+        self.dataset = dataset
+        self.acc_indices = []
+        self.acc_activations = []
+        self.seen = BitMap([])
+        self.accepted = BitMap([])
+        self.params = params
+        self.init_q = None
+        self.timing = []
+        self.image_timing = {}
+        self.index = hdb
+        self.q = hdb.new_query()
+        if _y is not None:
+            from .calibration import GroundTruthCalibrator
+            assert self.index.vectors.shape[0] == _y.shape[0]
+            self.q._calibrator = GroundTruthCalibrator(self.index.vectors, _y)
+        self.label_db = LabelDB()  # optional prefill from ground truth (annotation_category)
+        if params.annotation_category is not None:
+            box_data, _ = dataset.load_ground_truth()
+            df = box_data[box_data.category == params.annotation_category]
+            if df.shape[0] == 0:
+                print(f"warning, no entries found for category {params.annotation_category}")
+            self.label_db.fill(df)
+        self.loop = build_loop_from_params(gdm, self.q, params=params)
+        self.action_log = []
+        self._last_change = None
+        self._log("init")
+
+    def get_totals(self):
+        return {"seen": len(self.seen), "accepted": len(self.accepted)}
+
+    def get_method_stats(self):
+        return self.loop.get_stats()
+
+    def _log(self, message: str):
+        self.action_log.append({"logger": "server", "time": time.time(), "message": message,
+                                "seen": len(self.seen), "accepted": len(self.accepted)})
+
+    def next(self):
+        self._log("next.start")
+        start = time.time()
+        r = self.loop.next_batch_external()
+        self.timing.append(time.time() - start)
+        self.acc_indices.append(r["dbidxs"])
+        self.acc_activations.append(r["activations"])
+        self._log("next.end")
+        return r["dbidxs"]
+
+    def set_text(self, key):
+        self._log("set_text")
+        self.init_q = key
+        self.loop.state.curr_str = key
+        vec = self.index.string2vec(string=key)
+        self.loop.state.tvec = vec
+        self.loop.set_text_vec(vec)
+
+    def update_state(self, state: SessionState):
+        self._update_labeldb(state)
+        self._log("update_state.end")
+        if self._check_reversals():
+            self.loop.set_reversals()
+
+    def _check_reversals(self):
+        """a reversal = some rejected image shown before an accepted one."""
+        if len(self.accepted) == 0 or len(self.accepted) == len(self.seen):
+            return False
+        rejected_before = False
+        for batch in self.acc_indices:
+            for idx in np.asarray(batch).reshape(-1):
+                if int(idx) not in self.accepted:
+                    rejected_before = True
+                elif rejected_before:
+                    return True
+        return False
+
+    def refine(self):
+        self._log("refine.start")
+        self.loop.refine_external(self._last_change)
+        self._log("refine.end")
+
+    def get_state(self) -> SessionState:
+        gdata = []
+        last = len(self.acc_indices) - 1
+        for i, (indices, accs) in enumerate(zip(self.acc_indices, self.acc_activations)):
+            prefill = (self.params.annotation_category is not None) and (i == last)
+            gdata.append(self.get_panel_data(idxbatch=indices, activation_batch=accs, prefill=prefill))
+        return SessionState(action_log=self.action_log, gdata=gdata, timing=self.timing, reference_categories=[],
+                            params=self.params, query_string=self.loop.state.curr_str)
+
+    def get_panel_data(self, *, idxbatch, activation_batch=None, prefill=False):
+        urls = self.dataset.get_urls(idxbatch)
+        out = []
+        for i, (url, dbidx) in enumerate(zip(urls, idxbatch)):
+            dbidx = int(dbidx)
+            boxes = (self.label_db if prefill else self.q.label_db).get(dbidx, format="box")
+            activations = None
+            if activation_batch is not None and len(activation_batch):
+                activations = []
+                for row in activation_batch[i].to_dict(orient="records"):
+                    score = row.pop("score")
+                    activations.append(ActivationData(box=Box(**{k: row[k] for k in ("x1", "y1", "x2", "y2")}), score=score))
+            out.append(Imdata(url=url, dbidx=dbidx, boxes=boxes, activations=activations,
+                              timing=self.image_timing.get(dbidx, [])))
+        return out
+
+    def _update_labeldb(self, state: SessionState):
+        # rebuilt from scratch every time: the user may have un-accepted an image
+        self.action_log = state.action_log
+        old_accepted, old_seen = self.accepted.copy(), self.seen.copy()
+        self.accepted.clear()
+        self.seen.clear()
+        for batch in state.gdata:
+            for imdata in batch:
+                self.image_timing[imdata.dbidx] = imdata.timing
+                self.seen.add(imdata.dbidx)
+                if is_image_accepted(imdata):
+                    self.accepted.add(imdata.dbidx)
+                self.q.label_db.put(imdata.dbidx, imdata.boxes)
+        delta_accepted = self.accepted - old_accepted
+        delta_seen = self.seen - old_seen
+        self._last_change = [(idx, 1 if idx in delta_accepted else 0) for idx in delta_seen.union(delta_accepted)]
+
+
+def make_session(gdm, p: SessionParams, b: BenchParams = None):
+    ds = gdm.get_dataset(p.index_spec.d_name)
+    if p.index_spec.c_name is not None:
+        ds = ds.load_subset(p.index_spec.c_name)
+    _y = None
+    if p.pass_ground_truth:
+        _, gt = ds.load_ground_truth()
+        _y = gt[b.ground_truth_category]
+    idx = ds.load_index(p.index_spec.i_name, options=p.index_options)
+    session = Session(gdm, ds, idx, p, _y=_y)
+    return {"session": session, "dataset": ds}

@@ -1,0 +1,119 @@
+"""GPU end-to-end: Session + benchmark_loop over the synthetic datasets for every registered
+feedback loop (BASELINE configs C1 and C5-shape).  Checks the invariants the reference's
+benchmark_loop asserts (every id inside the subset, never repeated: seesaw_bench.py:316-320),
+that feedback helps, and the summary round trip of BenchRunner.run_loop."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(interactive, options=None, batch_size=1, start_policy="after_first_batch"):
+    from seesaw_amd.basic_types import IndexSpec, SessionParams
+    return SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale", c_name=None), interactive=interactive,
+                         interactive_options=options, batch_size=batch_size, shortlist_size=50,
+                         agg_method="plain_score", aug_larger="greater", start_policy=start_policy,
+                         index_options={"use_vec_index": False})
+
+
+MATRIX = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+LOOPS = {
+    "plain": None,
+    "rocchio_update": dict(rocchio_alpha=1.0, rocchio_beta=0.5, rocchio_gamma=0.25, verbose=False),
+    "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
+                      reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200, pos_weight="balanced",
+                      lr=1.0, matrix_options=MATRIX),
+    "multi_reg_data": dict(label_loss_type="pairwise_rank_loss", rank_loss_margin=0.2, use_qvec_norm=None,
+                           reg_data_lambda=1000.0, reg_norm_lambda=100.0, reg_query_lambda=10.0, verbose=False,
+                           max_iter=100, pos_weight="balanced", lr=1.0, matrix_options=MATRIX),
+    "knn_prop2": dict(matrix_options=MATRIX, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                      calib_b=-0.4, prior_weight=1.0),
+    "pseudo_lr": dict(switch_over=True, real_sample_weight=1.0, sample_size=2000,
+                      log_reg_params=dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1,
+                                          fit_intercept=False),
+                      label_prop_params=dict(matrix_options=MATRIX, normalize_scores=False,
+                                             sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4, prior_weight=1.0)),
+    "log_reg2": dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1, fit_intercept=False),
+}
+
+
+@pytest.fixture(scope="module")
+def lvis():
+    from seesaw_amd.synthetic import GlobalDataManager, make_lvis_shape
+    ds = make_lvis_shape(n_images=600, seed=3, knn_k=10)
+    return GlobalDataManager().add(ds), ds
+
+
+@pytest.mark.parametrize("name", list(LOOPS))
+def test_benchmark_loop_all_loops(lvis, name):
+    from seesaw_amd.basic_types import BenchParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import make_session
+    gdm, ds = lvis
+    interactive = "multi_reg" if name.startswith("multi_reg") else name
+    p = _params(interactive, LOOPS[name])
+    b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=5)
+    np.random.seed(0)
+    ret = make_session(gdm, p, b=b)
+    boxes, qgt = ds.load_ground_truth()
+    out = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+    assert 0 < out["nseen"] <= 25 and out["nfound"] >= 1
+    assert len(out["latencies"]) in (out["nseen"], out["nseen"] - 1)
+    state = ret["session"].get_state()
+    shown = [im.dbidx for batch in state.gdata for im in batch]
+    assert len(shown) == len(set(shown)) == out["nseen"]
+    # the simulated user's verdicts agree with the ground truth
+    positives = set(boxes[boxes.category == "c1"].dbidx.tolist())
+    from seesaw_amd.basic_types import is_image_accepted
+    for batch in state.gdata:
+        for im in batch:
+            assert is_image_accepted(im) == (im.dbidx in positives)
+
+
+def test_c1_plain_top100(tmp_path):
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
+    from seesaw_amd.seesaw_bench import BenchRunner, add_stats, get_all_session_summaries
+    from seesaw_amd.synthetic import GlobalDataManager, make_c1
+    gdm = GlobalDataManager().add(make_c1())
+    p = SessionParams(index_spec=IndexSpec(d_name="c1", i_name="coarse"), interactive="plain", batch_size=100,
+                      shortlist_size=100, agg_method="plain_score", start_policy="from_start")
+    b = BenchParams(name="baseline", ground_truth_category="c0", qstr="a c0", n_batches=3, max_results=None)
+    runner = BenchRunner(None, str(tmp_path), redirect_output=True, gdm=gdm)
+    out_dir = runner.run_loop(b, p)
+    summary = json.load(open(os.path.join(out_dir, "summary.json")))
+    res = summary["result"]
+    assert res["nimages"] == 10000 and res["ntotal"] == 100
+    assert res["run_info"]["nseen"] == 300 and res["run_info"]["nfound"] > 30
+    assert len(res["latencies"]) == 2
+    df = add_stats(get_all_session_summaries(str(tmp_path), force_recompute=True))
+    assert df.shape[0] == 1 and df.nseen.iloc[0] == 300 and 0 < df.average_precision.iloc[0] <= 1
+
+
+def test_feedback_beats_plain(lvis):
+    """on a hard query (text vector only weakly aligned) the multi_reg loop finds the
+    positives in fewer batches than no feedback."""
+    from seesaw_amd.basic_types import BenchParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import make_session
+    gdm, ds = lvis
+    ds.embedding.noise = 1.6
+    ds.embedding.string_cache.clear()
+    seen = {}
+    try:
+        for name in ("plain", "multi_reg"):
+            p = _params(name, LOOPS[name])
+            b = BenchParams(name=name, ground_truth_category="c2", qstr="a c2", n_batches=60, max_results=6)
+            ret = make_session(gdm, p, b=b)
+            boxes, _ = ds.load_ground_truth()
+            out = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+            seen[name] = (out["nseen"], out["nfound"])
+    finally:
+        ds.embedding.noise = 0.35
+        ds.embedding.string_cache.clear()
+    assert seen["multi_reg"][1] >= seen["plain"][1]
+    assert seen["multi_reg"][0] <= seen["plain"][0]
