@@ -79,22 +79,26 @@ __global__ __launch_bounds__(256) void k_fb_logits(const float *__restrict__ X,
     if (lane == 0) z[row] = a + (has_bias ? w[dim] : 0.f);
 }
 
-__device__ __forceinline__ float softplus_neg(float z) {  // log(1 + exp(-z)), stable
-    return log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f);
+// The reference's label losses are evaluated in f64 (its targets are float64, so torch
+// promotes: logistic_regression.py:393, multi_reg.py:170) while logits and gradients stay
+// f32.  L-BFGS stops on |loss - prev_loss| < 1e-9, which an f32 loss cannot resolve, so the
+// per-item losses are f64 here too; dL/dz is rounded to f32 like torch's.
+__device__ __forceinline__ double softplus_neg(double z) {  // log(1 + exp(-z)), stable
+    return log1p(exp(-fabs(z))) + fmax(-z, 0.0);
 }
-__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
+__device__ __forceinline__ double sigmoidd(double z) { return 1.0 / (1.0 + exp(-z)); }
 
 // elementwise BCE-with-logits with pos_weight pw and per-item coefficient c_i:
 //   l = c [ (1-y) z + (1 + (pw-1) y) softplus(-z) ],  dl/dz = c [ (1-y) - (1 + (pw-1) y) sigmoid(-z) ]
 __global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__ y,
                           const float *__restrict__ coef, float pw, int64_t n,
-                          float *__restrict__ item_loss, float *__restrict__ r) {
+                          double *__restrict__ item_loss, float *__restrict__ r) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float zi = z[i], yi = y[i], ci = coef[i];
-    const float lw = 1.f + (pw - 1.f) * yi;
-    item_loss[i] = ci * ((1.f - yi) * zi + lw * softplus_neg(zi));
-    r[i] = ci * ((1.f - yi) - lw * sigmoidf(-zi));
+    const double zi = z[i], yi = y[i], ci = coef[i];
+    const double lw = 1.0 + ((double)pw - 1.0) * yi;
+    item_loss[i] = ci * ((1.0 - yi) * zi + lw * softplus_neg(zi));
+    r[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
 }
 
 // pairwise losses over all ordered pairs (i, j), t_ij = sign(y_i - y_j), s_ij = z_i - z_j:
@@ -106,7 +110,7 @@ template <int LOGISTIC>
 __global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ z,
                                                       const float *__restrict__ y,
                                                       const float *__restrict__ coef, float margin,
-                                                      int n, float *__restrict__ item_loss,
+                                                      int n, double *__restrict__ item_loss,
                                                       float *__restrict__ r) {
     extern __shared__ float sh[];
     float *sz = sh, *sy = sh + n, *sc = sh + 2 * n;
@@ -124,33 +128,32 @@ __global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ 
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const float zk = sz[k], yk = sy[k], ck = sc[k];
-        float loss_k = 0.f;  // column sum over i of loss_ik
-        float rk = 0.f;
+        double loss_k = 0.0;  // column sum over i of loss_ik
+        double rk = 0.0;
         for (int i = 0; i < n; ++i) {
             const float d = sy[i] - yk;
             if (d == 0.f) continue;
-            const float t = d > 0.f ? 1.f : -1.f;  // t_ik
-            const float s = sz[i] - zk;           // s_ik
+            const double t = d > 0.f ? 1.0 : -1.0;  // t_ik
+            const double s = (double)(sz[i] - zk);  // s_ik (f32 difference, as torch forms it)
             // pair (i, k): contributes to item_k (column k) with weight ck; z_k enters with -1
             // pair (k, i): t_ki = -t, s_ki = -s, contributes to item_i with weight sc[i]; z_k enters with +1
             if (LOGISTIC) {
-                const float u = -t * s;  // -t_ik s_ik  (== -t_ki s_ki)
-                const float l = softplus_neg(-u);
-                loss_k += l;
-                const float sg = sigmoidf(u);  // d/du log(1+exp(u))
+                const double u = -t * s;  // -t_ik s_ik  (== -t_ki s_ki)
+                loss_k += log(1.0 + exp(u));  // the reference's unguarded form (rank_loss.py:48)
+                const double sg = sigmoidd(u);  // d/du log(1+exp(u))
                 // d loss_ik / d z_k = sg * (-t) * (-1) = t sg ;  d loss_ki / d z_k = sg * (t)(+1)... see below
                 rk += ck * (t * sg) + sc[i] * (t * sg);
             } else {
-                const float h = margin - t * s;
-                if (h >= 0.f) {  // torch's clamp(min=0) passes the gradient at the kink
+                const double h = (double)margin - t * s;
+                if (h >= 0.0) {  // torch's clamp(min=0) passes the gradient at the kink
                     loss_k += h;
                     // loss_ik = m - t (z_i - z_k): d/dz_k = +t ; loss_ki = m - (-t)(z_k - z_i) = m + t z_k - t z_i: d/dz_k = +t
                     rk += ck * t + sc[i] * t;
                 }
             }
         }
-        item_loss[k] = ck * loss_k;
-        r[k] = rk;
+        item_loss[k] = (double)ck * loss_k;
+        r[k] = (float)rk;
     }
 }
 
@@ -178,12 +181,12 @@ struct FbObjDev {
 // one workgroup of `dim` (<= 1024) threads: reduce partials in slab order, add the
 // regulariser terms, emit out[0] = loss, out[1 .. 1+P) = gradient, out[1+P ..] = parts
 __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ partial, int nslabs,
-                                                   const float *__restrict__ item_loss,
+                                                   const double *__restrict__ item_loss,
                                                    const float *__restrict__ r, int64_t n, int dim,
                                                    const float *__restrict__ w,
                                                    const float *__restrict__ qhat,
                                                    const float *__restrict__ xlx, FbObjDev obj,
-                                                   float *__restrict__ out) {
+                                                   float *__restrict__ out, double *__restrict__ out_loss) {
     __shared__ double red[1024];
     __shared__ float sw_[1024];
     __shared__ double scal[8];
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
     const double wq = block_sum(act && qhat ? (double)wc * qhat[c] : 0.0);
     double ls = 0.0, rs = 0.0;
     for (int64_t i = c; i < n; i += 1024) {
-        ls += (double)item_loss[i];
+        ls += item_loss[i];
         rs += (double)r[i];
     }
     const double data_loss = block_sum(ls) * obj.scale;
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
     if (act) out[1 + c] = g + greg;
     if (c == 0) {
         out[0] = (float)(data_loss + reg_loss);
+        *out_loss = data_loss + reg_loss;
         out[1 + dim] = obj.has_bias ? (float)rsum : 0.f;
         float *parts = out + 1 + dim + 1;
         parts[0] = (float)p_norm;
@@ -287,7 +291,9 @@ struct ssw_fb {
     int64_t n = 0, cap = 0;
     float *X = nullptr;        // [cap, dim] centred rows
     float *mu = nullptr;       // [dim]
-    float *y = nullptr, *coef = nullptr, *z = nullptr, *item = nullptr, *r = nullptr;  // [cap]
+    float *y = nullptr, *coef = nullptr, *z = nullptr, *r = nullptr;  // [cap]
+    double *item = nullptr;    // [cap] per-item label losses (f64)
+    double *loss_dev = nullptr, *loss_host = nullptr;  // total loss in f64
     int64_t *rows = nullptr;   // gather staging
     float *partial = nullptr;  // [nslabs(cap), dim]
     float *w = nullptr;        // [dim + 1]
@@ -315,7 +321,8 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
-    fb->X = fb->y = fb->coef = fb->z = fb->item = fb->r = fb->partial = nullptr;
+    fb->X = fb->y = fb->coef = fb->z = fb->r = fb->partial = nullptr;
+    fb->item = nullptr;
     fb->rows = nullptr;
     fb->cap = 0;
     int64_t cap = 256;
@@ -325,7 +332,7 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     SSW_HIP_TRY(hipMalloc((void **)&fb->y, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->coef, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->z, (size_t)cap * sizeof(float)));
-    SSW_HIP_TRY(hipMalloc((void **)&fb->item, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->item, (size_t)cap * sizeof(double)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->r, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->rows, (size_t)cap * sizeof(int64_t)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->partial, (size_t)nslabs * fb->dim * sizeof(float)));
@@ -438,7 +445,7 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
                 hipLaunchKernelGGL(k_fb_pairwise<0>, dim3(1), dim3(1024), lds, s, fb->z, fb->y, fb->coef, o->margin,
                                    (int)n, fb->item, fb->r);
         } else {  // only one class labelled so far: the label loss is identically 0 (multi_reg.py:107)
-            SSW_HIP_TRY(hipMemsetAsync(fb->item, 0, (size_t)n * sizeof(float), s));
+            SSW_HIP_TRY(hipMemsetAsync(fb->item, 0, (size_t)n * sizeof(double), s));
             SSW_HIP_TRY(hipMemsetAsync(fb->r, 0, (size_t)n * sizeof(float), s));
         }
         nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
@@ -448,10 +455,11 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     }
     hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim, fb->w,
                        fb->has_q ? fb->qhat : (const float *)nullptr, fb->has_xlx ? fb->xlx : (const float *)nullptr,
-                       dev, fb->out);
+                       dev, fb->out, fb->loss_dev);
     SSW_HIP_TRY(hipGetLastError());
     SSW_HIP_TRY(hipMemcpyAsync(fb->out_host, fb->out, (size_t)(1 + dim + 1 + 4) * sizeof(float),
                                hipMemcpyDeviceToHost, s));
+    SSW_HIP_TRY(hipMemcpyAsync(fb->loss_host, fb->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
     SSW_HIP_TRY(hipStreamSynchronize(s));
     fb->last_evals++;
     return SSW_OK;
@@ -511,7 +519,7 @@ struct Evaluator {
         for (int i = 0; i < P; ++i) fb->w_host[i] = x[i] + (float)t * d[i];
         status = fb_eval(fb, o, dev, pw, pairwise_active, P);
         if (status != SSW_OK) return false;
-        *f = fb->out_host[0];
+        *f = fb->loss_host[0];
         g->assign(fb->out_host + 1, fb->out_host + 1 + P);
         if (!std::isfinite(*f)) {
             set_error("feedback: loss diverged (%g) -- regression training failed with a nan", *f);
@@ -634,6 +642,8 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->qhat);
     (void)hipFree(fb->xlx);
     (void)hipFree(fb->out);
+    (void)hipFree(fb->loss_dev);
+    if (fb->loss_host) (void)hipHostFree(fb->loss_host);
     if (fb->out_host) (void)hipHostFree(fb->out_host);
     if (fb->w_host) (void)hipHostFree(fb->w_host);
     if (fb->stream) (void)hipStreamDestroy(fb->stream);
@@ -664,6 +674,8 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipMalloc((void **)&fb->qhat, (size_t)dim * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->xlx, (size_t)dim * dim * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->out, outn * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&fb->loss_dev, sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&fb->w_host, (size_t)(dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("feedback: allocation failed");
@@ -765,7 +777,7 @@ ssw_status ssw_fb_lossgrad(ssw_fb *fb, const ssw_fb_objective *obj, const float 
     memcpy(fb->w_host, w_host, (size_t)P * sizeof(float));
     if (P == fb->dim) fb->w_host[fb->dim] = 0.f;
     SSW_TRY(fb_eval(fb, obj, dev, pw, pa, fb->dim + 1));
-    *out_loss = fb->out_host[0];
+    *out_loss = (float)fb->loss_host[0];
     memcpy(out_grad, fb->out_host + 1, (size_t)P * sizeof(float));
     if (out_parts4_or_null) memcpy(out_parts4_or_null, fb->out_host + 1 + fb->dim + 1, 4 * sizeof(float));
     return SSW_OK;
