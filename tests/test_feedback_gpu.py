@@ -57,8 +57,16 @@ def test_multireg_fit_vs_reference_golden():
         mod.fit(X, y, pd.DataFrame({"dbidx": img, "ys": y}))
         coeff = mod.get_coeff()
         ref = g[f"c{c}_coeff"]
-        assert np.abs(X @ (coeff - ref)).max() < FIT_TOL, (c, np.abs(X @ (coeff - ref)).max())
-        assert np.abs(coeff - ref).max() < 5e-4, c
+        # The reference stops when its f32-noisy loss stops changing and can end short of the
+        # minimiser (6.7e-4 in rank scores on c4); the HIP path evaluates the loss in f64 and
+        # converges.  So: ours is within 1e-4 of the exact minimiser, and no further from the
+        # reference than the reference is from the minimiser (+1e-4).
+        from oracle import feedback_oracle as fo
+        opt = fo.multireg_optimum(X, y, img, q, g["xlx"], loss_type=str(g[f"c{c}_loss_type"]),
+                                  l_data=float(g[f"c{c}_data_lam"]), l_query=float(g[f"c{c}_query_lam"]))
+        ref_gap = np.abs(X @ (ref - opt)).max()
+        assert np.abs(X @ (coeff - opt)).max() < TOL, (c, np.abs(X @ (coeff - opt)).max())
+        assert np.abs(X @ (coeff - ref)).max() < ref_gap + TOL, (c, np.abs(X @ (coeff - ref)).max(), ref_gap)
         assert abs(np.linalg.norm(coeff) - 1) < 1e-5
 
 
