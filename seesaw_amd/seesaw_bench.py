@@ -186,8 +186,19 @@ def process_single_result(result_path):
     return process_dict(obj)
 
 
+def _have_parquet() -> bool:
+    try:
+        import pyarrow  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
 def get_all_session_summaries(base_dir, force_recompute=False, parallel=True):
-    sumpath = base_dir + "/summary.parquet"
+    """summary of every session under base_dir, cached as summary.parquet like the reference
+    (pickle when no parquet engine is installed)."""
+    parquet = _have_parquet()
+    sumpath = base_dir + ("/summary.parquet" if parquet else "/summary.pkl")
     if not os.path.exists(sumpath) or force_recompute:
         rows = [process_single_result(os.path.dirname(p)) for p in
                 glob.glob(base_dir + "/**/summary.json", recursive=True)]
@@ -195,8 +206,8 @@ def get_all_session_summaries(base_dir, force_recompute=False, parallel=True):
         for col in ("method_stats",):
             if col in df:
                 df[col] = df[col].map(lambda v: None if not v else json.dumps(v))
-        df.to_parquet(sumpath)
-    return pd.read_parquet(sumpath)
+        df.to_parquet(sumpath) if parquet else df.to_pickle(sumpath)
+    return pd.read_parquet(sumpath) if parquet else pd.read_pickle(sumpath)
 
 
 def get_param_hash(dstr):
