@@ -81,7 +81,7 @@ def test_c1_plain_top100(tmp_path):
     gdm = GlobalDataManager().add(make_c1())
     p = SessionParams(index_spec=IndexSpec(d_name="c1", i_name="coarse"), interactive="plain", batch_size=100,
                       shortlist_size=100, agg_method="plain_score", start_policy="from_start")
-    b = BenchParams(name="baseline", ground_truth_category="c0", qstr="a c0", n_batches=3, max_results=None)
+    b = BenchParams(name="baseline", ground_truth_category="c0", qstr="a c0", n_batches=3, max_results=100)
     runner = BenchRunner(None, str(tmp_path), redirect_output=True, gdm=gdm)
     out_dir = runner.run_loop(b, p)
     summary = json.load(open(os.path.join(out_dir, "summary.json")))
