@@ -92,8 +92,9 @@ class ShardedTopK:
         self.send_count.copy_(local_count)
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.all_keys, self.send_keys, group=self.group)
-            dist.all_gather_into_tensor(self.all_counts, self.send_count, group=self.group)
+            # flat (concatenating) form: accepted by both RCCL and gloo
+            dist.all_gather_into_tensor(self.all_keys.view(-1), self.send_keys, group=self.group)
+            dist.all_gather_into_tensor(self.all_counts.view(-1), self.send_count, group=self.group)
         else:
             self.all_keys[0] = self.send_keys
             self.all_counts[0] = self.send_count[0]

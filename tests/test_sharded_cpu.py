@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the row-sharded top-k exchange (partition, global id
+offsetting, all_gather, merge) -- the N > 1 path of bench.py -- with each rank's local scan
+replaced by the CPU oracle (the HIP kernels need a GPU; the collective logic does not)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _encode(scores, ids):
+    """composite keys exactly as the select kernels emit them."""
+    u = np.ascontiguousarray(scores, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    neg = (u & np.uint64(0x80000000)) != 0
+    o = np.where(neg, ~u & np.uint64(0xFFFFFFFF), u | np.uint64(0x80000000))
+    return (o << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(ids, dtype=np.uint64))
+
+
+def _merge_on_cpu(device, stream, keys, counts, k, out_keys, out_count):
+    """stand-in for ssw_topk_merge_dev: same contract (descending u64 order)."""
+    lists = [keys[r, : int(counts[r])].numpy().view(np.uint64) for r in range(keys.shape[0])]
+    allk = np.sort(np.concatenate(lists))[::-1][:k]
+    out_keys[: allk.shape[0]] = torch.from_numpy(allk.view(np.int64).copy())
+    out_count[0] = allk.shape[0]
+
+
+def _worker(rank, world, port, n_total, k, tmpdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import seesaw_oracle as orc
+    from seesaw_amd.device_index import decode_keys
+    from seesaw_amd.sharded import ShardedTopK, shard_bounds
+    lo, hi = shard_bounds(n_total, world, rank)
+    X = orc.synth_rows(9, lo, hi - lo, 512)          # this rank's slice of the global index
+    q = orc.synth_query(1)
+    local_scores = orc.scores_kernel_order(X, q)
+    ids, sc, _ = orc.topk_images_tiebreak(local_scores, None, hi - lo, [], k)
+    keys = torch.zeros(4096, dtype=torch.int64)
+    keys[: ids.shape[0]] = torch.from_numpy(_encode(sc, ids).view(np.int64).copy())
+    count = torch.tensor([ids.shape[0]], dtype=torch.int32)
+    x = ShardedTopK(rank=rank, world=world, device=torch.device("cpu"), image_offset=lo, k_max=128, merge=_merge_on_cpu)
+    out_keys, out_count = x.exchange(keys, count, k)
+    c = int(out_count.item())
+    imgs, scores = decode_keys(out_keys[:c].numpy().view(np.uint64))
+    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), imgs=imgs, scores=scores)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,k", [(5000, 50), (301, 100)])
+def test_two_rank_exchange_matches_single_index(tmp_path, oracle, n_total, k):
+    port = 29500 + (os.getpid() + n_total) % 2000
+    mp.spawn(_worker, args=(2, port, n_total, k, str(tmp_path)), nprocs=2, join=True)
+    X = oracle.synth_rows(9, 0, n_total, 512)
+    q = oracle.synth_query(1)
+    ref_ids, ref_sc, _ = oracle.topk_images_tiebreak(oracle.scores_kernel_order(X, q), None, n_total, [], k)
+    for r in range(2):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(g["imgs"], ref_ids), r            # every rank holds the global answer
+        assert np.array_equal(g["scores"].view(np.uint32), ref_sc.view(np.uint32))
