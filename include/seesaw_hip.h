@@ -230,6 +230,35 @@ ssw_status ssw_fb_scores(ssw_fb *fb, const float *w_host, int32_t has_bias, floa
 ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, int32_t max_iter,
                       float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss);
 
+/* ------------------------------------------------------------------------- */
+/* CLIP ViT-B/32 image / text towers (bf16 MFMA forward)                       */
+/* replaces: transformers.CLIPModel.get_text_features                          */
+/*               seesaw/models/embeddings.py:441-455 (HGWrapper.from_string)   */
+/*           get_image_features + F.normalize                                  */
+/*               seesaw/models/model.py:50-57 (HGFaceWrapper.forward),         */
+/*               seesaw/indices/multiscale/multiscale_tools.py:187-202          */
+/* ------------------------------------------------------------------------- */
+typedef struct ssw_clip ssw_clip;
+
+/* weight_blob: 72-byte header ("SSWCLIP1", then int32 v_hidden, v_layers, v_heads, v_mlp,
+ * image, patch, t_hidden, t_layers, t_heads, t_mlp, t_max_positions, vocab, eos_token_id,
+ * projection_dim, float layer_norm_eps, int32 reserved) followed by the f32 tensors of a
+ * transformers.CLIPModel state_dict in the order seesaw_amd/models/clip.py::pack_clip_weights
+ * writes them.  GEMM weights are converted to bf16 on the device. */
+ssw_status ssw_clip_create(int32_t device, const void *weight_blob, size_t bytes, ssw_clip **out);
+ssw_status ssw_clip_destroy(ssw_clip *clip);
+/* pixel_values [b, 3, image, image] f32 (already CLIP-normalised) -> [b, projection_dim] f32;
+ * normalize != 0 L2-normalises every row (HGFaceWrapper). */
+ssw_status ssw_clip_embed_image(ssw_clip *clip, const float *nchw_host, int32_t b, int32_t normalize,
+                                float *out_host);
+/* same with device pointers, enqueued on hip_stream (NULL: the handle's stream), no sync. */
+ssw_status ssw_clip_embed_image_dev(ssw_clip *clip, void *hip_stream, const float *nchw_dev, int32_t b,
+                                    int32_t normalize, float *out_dev);
+/* input_ids [b, seq_len] int32 (BOS ... EOS [pad]); the feature is taken at the first EOS. */
+ssw_status ssw_clip_embed_text(ssw_clip *clip, const int32_t *ids_host, int32_t b, int32_t seq_len,
+                               int32_t normalize, float *out_host);
+ssw_status ssw_clip_sync(ssw_clip *clip);
+
 #ifdef __cplusplus
 }
 #endif
