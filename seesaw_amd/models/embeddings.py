@@ -1,0 +1,103 @@
+"""Embedding front ends with the reference's XEmbedding interface
+(seesaw/models/embeddings.py:427-466): `from_string(string=...) -> [1, 512]`,
+`from_image(preprocessed_image=...) -> [B, 512]`, backed by the HIP CLIP towers."""
+from __future__ import annotations
+
+import os
+import zlib
+
+import numpy as np
+
+from .clip import ClipModel
+
+
+class HashTokenizer:
+    """Deterministic stand-in used when no CLIP vocabulary files are available (as in the
+    build image): words hash into the id range; sequence = [BOS, ids..., EOS]."""
+
+    def __init__(self, vocab_size: int, bos: int = 49406, eos: int = 49407, max_len: int = 77):
+        self.vocab_size, self.bos, self.eos, self.max_len = vocab_size, bos, eos, max_len
+
+    def __call__(self, text: str) -> np.ndarray:
+        words = text.lower().split()[: self.max_len - 2]
+        ids = [zlib.crc32(w.encode()) % (self.bos - 1) for w in words]
+        return np.array([[self.bos] + ids + [self.eos]], dtype=np.int32)
+
+
+def _device_index(device) -> int:
+    if isinstance(device, str):
+        return int(device.split(":")[-1]) if ":" in device else 0
+    return int(device)
+
+
+class HGWrapper:
+    """text side (HGWrapper.from_string): un-normalised text features, cached per string."""
+
+    def __init__(self, path=None, device=0, num_cpus=1, model: ClipModel = None, tokenizer=None):
+        self.model = model if model is not None else load_clip(path, device=_device_index(device))
+        self.tokenizer = tokenizer or _load_tokenizer(path, self.model)
+        self.string_cache = {}
+
+    def ready(self):
+        return True
+
+    def from_string(self, *, string=None, str_vec=None, numpy=True):
+        if str_vec is not None:
+            return str_vec
+        if string not in self.string_cache:
+            ids = self.tokenizer(string)
+            self.string_cache[string] = self.model.embed_text(ids, normalize=False).reshape(1, -1)
+        return self.string_cache[string]
+
+    def from_image(self, *, preprocessed_image=None, image=None, img_vec=None, numpy=True, pooled=True):
+        if img_vec is not None:
+            return img_vec
+        x = preprocessed_image
+        x = x.detach().cpu().float().numpy() if hasattr(x, "detach") else np.asarray(x, dtype=np.float32)
+        return self.model.embed_image(x, normalize=True)
+
+
+class ImageEmbedding:
+    """image side (seesaw/models/model.py:67-89 with add_slide=False): L2-normalised features."""
+
+    def __init__(self, device=0, jit_path=None, add_slide=False, model: ClipModel = None):
+        assert not add_slide, "sliding-window pooling is not part of the accelerated path"
+        self.model = model if model is not None else load_clip(jit_path, device=_device_index(device))
+
+    def __call__(self, *, preprocessed_image):
+        return self.forward(preprocessed_image=preprocessed_image)
+
+    def forward(self, *, preprocessed_image):
+        x = preprocessed_image
+        x = x.detach().cpu().float().numpy() if hasattr(x, "detach") else np.asarray(x, dtype=np.float32)
+        return self.model.embed_image(x, normalize=True)
+
+
+def _load_tokenizer(path, model: ClipModel):
+    if path and os.path.exists(os.path.join(str(path), "vocab.json")):
+        import transformers
+        tok = transformers.CLIPTokenizer.from_pretrained(path)
+        return lambda s: np.asarray(tok(s, return_tensors="np")["input_ids"], dtype=np.int32)
+    return HashTokenizer(model.vocab_size, eos=model.eos_token_id, max_len=model.max_positions)
+
+
+_CLIP_CACHE = {}
+
+
+def load_clip(path=None, device: int = 0) -> ClipModel:
+    """HF CLIP directory (config + weights) -> ClipModel; None / missing -> seeded random init."""
+    key = (path, device)
+    if key not in _CLIP_CACHE:
+        if path and os.path.isdir(str(path)) and os.path.exists(os.path.join(str(path), "config.json")):
+            import transformers
+            hf = transformers.CLIPModel.from_pretrained(path).eval()
+            _CLIP_CACHE[key] = ClipModel.from_hf(hf, device=device)
+        else:
+            _CLIP_CACHE[key] = ClipModel.random_init(device=device)
+    return _CLIP_CACHE[key]
+
+
+def load_embedding(model_path=None, device: int = 0):
+    if model_path is None:
+        return None
+    return HGWrapper(model_path, device=device)
