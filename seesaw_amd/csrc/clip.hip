@@ -182,65 +182,138 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// attention of one (batch, head): S <= 80 tokens, head_dim 64, whole head in LDS, f32 math
+// attention: one WAVE per (batch, head); S <= 16*NT tokens, head_dim 64.
+//   scores  = Q K^T      16x16x32 MFMA, Q / K fragments straight from global (both are
+//                        K-contiguous rows of the fused qkv buffer, i.e. the same "NT" operand
+//                        form as the GEMM) -> the whole S x S score block lives in accumulators
+//   softmax   in registers (f32): row max / sum by xor-shuffles over the 16 lanes of a row
+//   out     = P V        P goes through a 16-row LDS tile (C layout -> A fragments), V is
+//                        transposed once per head into LDS so its fragments are key-contiguous
 // qkv [R, 3D] bf16 (q | k | v), out [R, D] bf16
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 80;
 
-__global__ __launch_bounds__(256) void attention_head(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
-                                                      int D, int H, float scale, int causal) {
-    __shared__ float sQ[ATT_MAX_S][64];
-    __shared__ float sK[ATT_MAX_S][65];
-    __shared__ float sV[ATT_MAX_S][64];
-    __shared__ float sP[ATT_MAX_S][ATT_MAX_S + 1];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int t = threadIdx.x;
+template <int NT>
+__global__ __launch_bounds__(256) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
+                                                      int D, int H, float scale, int causal, int n_heads) {
+    constexpr int KP = ((NT * 16 + 31) / 32) * 32;  // keys padded to the MFMA K step
+    constexpr int LDP = KP + 8;                     // LDS row stride (bf16)
+    __shared__ __attribute__((aligned(16))) bf16 sVt[4][64 * LDP];
+    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hid_raw = blockIdx.x * 4 + wave;
+    const bool live = hid_raw < n_heads;
+    const int hid = live ? hid_raw : n_heads - 1;
+    const int b = hid / H, h = hid % H;
+    const int fr = lane & 15, fq = lane >> 4;
     const bf16 *base = qkv + (int64_t)b * S * 3 * D + h * 64;
-    for (int i = t; i < S * 64; i += 256) {
-        const int s = i >> 6, d = i & 63;
-        const bf16 *row = base + (int64_t)s * 3 * D;
-        sQ[s][d] = (float)row[d];
-        sK[s][d] = (float)row[D + d];
-        sV[s][d] = (float)row[2 * D + d];
-    }
-    __syncthreads();
-    for (int i = t; i < S * S; i += 256) {
-        const int qi = i / S, kj = i % S;
-        float a = 0.f;
-        if (causal && kj > qi) {
-            a = -INFINITY;
+    bf16 *vt = sVt[wave], *pt = sP[wave];
+
+    // V^T into LDS: vt[d][key]; keys >= S are zero
+    for (int c = lane; c < KP * 8; c += 64) {
+        const int key = c >> 3, d0 = (c & 7) * 8;
+        bf16x8 v;
+        if (key < S) {
+            v = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + 2 * D + d0);
         } else {
-#pragma unroll 16
-            for (int d = 0; d < 64; ++d) a = fmaf(sQ[qi][d], sK[kj][d], a);
-            a *= scale;
-        }
-        sP[qi][kj] = a;
-    }
-    __syncthreads();
-    const int lane = t & 63, wave = t >> 6;
-    for (int qi = wave; qi < S; qi += 4) {
-        float m = -INFINITY;
-        for (int j = lane; j < S; j += 64) m = fmaxf(m, sP[qi][j]);
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        float sum = 0.f;
-        for (int j = lane; j < S; j += 64) {
-            const float e = __expf(sP[qi][j] - m);
-            sP[qi][j] = e;
-            sum += e;
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-        const float inv = 1.f / sum;
-        for (int j = lane; j < S; j += 64) sP[qi][j] *= inv;
+        for (int j = 0; j < 8; ++j) vt[(d0 + j) * LDP + key] = v[j];
+    }
+    // K fragments for every key tile (rows clamped: masked below)
+    bf16x8 kf[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int key = min(j * 16 + fr, S - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            kf[j][ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + D + ks * 32 + fq * 8);
     }
     __syncthreads();
-    bf16 *obase = out + (int64_t)b * S * D + h * 64;
-    for (int i = t; i < S * 64; i += 256) {
-        const int qi = i >> 6, d = i & 63;
-        float a = 0.f;
-        for (int j = 0; j < S; ++j) a = fmaf(sP[qi][j], sV[j][d], a);
-        obase[(int64_t)qi * D + d] = to_bf16(a);
+
+    for (int i = 0; i < NT; ++i) {
+        if (i * 16 >= S) break;  // wave-uniform
+        const int qrow_f = min(i * 16 + fr, S - 1);
+        bf16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qrow_f * 3 * D + ks * 32 + fq * 8);
+        f32x4 sc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[j][ks], sc[j], 0, 0, 0);
+        }
+        // this lane holds scores[query = 16 i + 4 fq + r][key = 16 j + fr]
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int key = j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = i * 16 + fq * 4 + r;
+                float v = sc[j][r] * scale;
+                if (key >= S || (causal && key > q)) v = -INFINITY;
+                sc[j][r] = v;
+                mx[r] = fmaxf(mx[r], v);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(sc[j][r] - mx[r]);  // key 0 is never masked, so mx is finite
+                sc[j][r] = e;
+                sum[r] += e;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) sum[r] += __shfl_xor(sum[r], off, 64);
+        // P (unnormalised, bf16) -> LDS tile [16 queries][KP keys]
+        __syncthreads();  // the previous iteration's reads of pt are done
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[(fq * 4 + r) * LDP + j * 16 + fr] = to_bf16(sc[j][r]);
+        if (KP > NT * 16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[(fq * 4 + r) * LDP + NT * 16 + fr] = (bf16)0.f;
+        }
+        __syncthreads();
+        // out tile = P V
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[fr * LDP + ks * 32 + fq * 8]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(&vt[(dt * 16 + fr) * LDP + ks * 32 + fq * 8]);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = i * 16 + fq * 4 + r;
+                if (q < S) {
+                    const float inv = 1.f / sum[r];
+                    bf16 *orow = out + ((int64_t)b * S + q) * D + h * 64;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + fr] = to_bf16(o[dt][r] * inv);
+                }
+            }
+        }
     }
 }
 
@@ -508,8 +581,14 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h, (const int *)nullptr, R, D,
                            ly.ln1w, ly.ln1b, eps, c->xn);
         SSW_TRY(gemm<EPI_BF16_BIAS>(s, c->xn, ly.wqkv, ly.bqkv, nullptr, c->qkv, R, 3 * D, D));
-        hipLaunchKernelGGL(attention_head, dim3(B * tw.H), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H,
-                           1.0f / sqrtf((float)(D / tw.H)), causal);
+        const int n_heads = B * tw.H;
+        const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
+        if (S <= 64)
+            hipLaunchKernelGGL(attention_mfma<4>, dim3((n_heads + 3) / 4), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H,
+                               att_scale, causal, n_heads);
+        else
+            hipLaunchKernelGGL(attention_mfma<5>, dim3((n_heads + 3) / 4), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H,
+                               att_scale, causal, n_heads);
         SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->att, ly.wo, ly.bo, h, h2, R, D, D));
         hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h2, (const int *)nullptr, R, D,
                            ly.ln2w, ly.ln2b, eps, c->xn);
