@@ -56,6 +56,98 @@ def cpu_baseline(local_index, k, sample_rows, n_queries):
     }
 
 
+def feedback_loop_extras(device: int, full_images: int):
+    """seesaw_bench feedback-loop iterations / s (1 / mean(latencies), seesaw_bench.py:310,352)
+    on the LVIS-shape synthetic datasets (BASELINE config C5), HIP path next to the CPU oracle
+    (numpy / scipy / torch-CPU, the reference's own expressions) in the same run."""
+    import numpy as np
+    from oracle import cpu_loop
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import make_session
+    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
+
+    matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    loops = {
+        "plain": None,
+        "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
+                          reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200,
+                          pos_weight="balanced", lr=1.0, matrix_options=matrix),
+        "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                          calib_b=-0.4, prior_weight=1.0),
+    }
+    out = {}
+    import contextlib
+    import io
+    for tag, n_images, knn_k, names in (("lvis_1109x13", 1109, 10, ("plain", "multi_reg", "knn_prop2")),
+                                        (f"full_{full_images}x13", full_images, 0, ("plain", "multi_reg"))):
+        ds = make_dataset("lvis", n_images=n_images, tiles_per_image=13, n_categories=2, positive_frac=0.05,
+                          seed=11, knn_k=knn_k, device=device)
+        ds.embedding.noise = 1.2  # a mediocre text query, so the loop runs all its rounds
+        gdm = GlobalDataManager().add(ds)
+        boxes, _ = ds.load_ground_truth()
+        res = {"vectors": int(ds.vectors.shape[0])}
+        for name in names:
+            p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale"), interactive=name,
+                              interactive_options=loops[name], batch_size=1, shortlist_size=50,
+                              agg_method="plain_score", aug_larger="greater", start_policy="after_first_batch",
+                              index_options={"use_vec_index": False})
+            b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ret = make_session(gdm, p, b=b)
+                for _ in range(2):  # first session warms kernels / allocations, second is reported
+                    ret = make_session(gdm, p, b=b)
+                    np.random.seed(0)
+                    g = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+                qvec = ds.load_index().string2vec("a c1")
+                c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=30,
+                                         max_results=10 ** 6, knn_df=ds.knn_graph().restrict_k(k=10).knn_df if knn_k else None)
+            res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])), "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])),
+                         "cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])), "cpu_ms_per_iter": 1e3 * float(np.mean(c["latencies"])),
+                         "iters": len(g["latencies"]), "hip_nfound": g["nfound"], "cpu_nfound": c["nfound"]}
+        out[tag] = res
+        idx = ds.load_index()
+        idx._dev.close()
+    return out
+
+
+def clip_extras(device: int):
+    """CLIP ViT-B/32 (random-init weights, bf16 MFMA): tiles / s and achieved fraction of the
+    dense bf16 MFMA peak (BASELINE config C3; 8.818 GFLOP per tile)."""
+    import numpy as np
+    import torch
+    from seesaw_amd.models.clip import ClipModel
+    m = ClipModel.random_init(seed=1234, device=device)
+    dev = torch.device("cuda", device)
+    B = 200
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    o = torch.empty(B, 512, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(2):
+        m.embed_image_dev(x.data_ptr(), B, o.data_ptr(), True, s)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        m.embed_image_dev(x.data_ptr(), B, o.data_ptr(), True, s)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / n
+    tf = B * 8.818 / dt / 1e3
+    ids = np.random.default_rng(0).integers(0, 49405, (16, 77)).astype(np.int32)
+    ids[:, 0], ids[:, -1] = 49406, 49407
+    m.embed_text(ids)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.embed_text(ids)
+    dtt = (time.perf_counter() - t0) / n
+    m.close()
+    return {"image_batch": B, "image_ms_per_batch": dt * 1e3, "tiles_per_s": B / dt, "tflops": tf,
+            "mfma_peak_tflops": 2500.0, "frac_of_bf16_dense_peak": tf / 2500.0,
+            "text_batch": 16, "text_len": 77, "text_ms_per_batch_host_io": dtt * 1e3, "texts_per_s": 16 / dtt,
+            "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +159,8 @@ def main():
     ap.add_argument("--cpu-rows", type=float, default=2e6)
     ap.add_argument("--cpu-queries", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the feedback-loop and CLIP sections")
+    ap.add_argument("--loop-images", type=int, default=120000, help="images of the full-size feedback-loop dataset")
     args = ap.parse_args()
 
     import numpy as np
@@ -179,6 +273,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(index.local, k, int(args.cpu_rows), args.cpu_queries)
         else:
             out["cpu_baseline"] = None
+        index.close()
+        if world == 1 and not args.no_extras:
+            extras = {}
+            for key, fn in (("feedback_loop", lambda: feedback_loop_extras(local_rank, args.loop_images)),
+                            ("clip", lambda: clip_extras(local_rank))):
+                try:
+                    extras[key] = fn()
+                except Exception as e:  # the headline metric above stands on its own
+                    extras[key] = {"error": f"{type(e).__name__}: {e}"}
+            out["extras"] = extras
         print(json.dumps(out), flush=True)
     index.close()
     if dist is not None:
