@@ -87,15 +87,14 @@ def rescore_candidates(fullmeta: pd.DataFrame, topk: int, **kwargs):
     dbidxs, dbscores, activations = [], [], []
     plain = kwargs.get("agg_method") == "plain_score"
     if plain and fullmeta.shape[0]:
-        # vectorised form of the per-frame loop: first maximal row of every image
+        # vectorised form of the per-frame loop: first maximal row of every image; only the
+        # `topk` winners get an activation frame built
         d = fullmeta.dbidx.values
         s = fullmeta.score.values
         order = np.lexsort((np.arange(d.shape[0]), -s, d))
         firsts = order[np.concatenate(([True], d[order][1:] != d[order][:-1]))]
-        for i in firsts:
-            dbidxs.append(d[i])
-            dbscores.append(s[i])
-            activations.append(fullmeta.iloc[[i]][_ACT_COLS])
+        top = firsts[np.argsort(-s[firsts].astype(np.float64), kind="stable")[:topk]]
+        return {"dbidxs": d[top].astype("int"), "activations": [fullmeta.iloc[[i]][_ACT_COLS] for i in top]}
     else:
         for dbidx, frame_meta in fullmeta.groupby("dbidx"):
             tup = score_frame2(frame_meta, **kwargs)
@@ -128,6 +127,8 @@ class MultiscaleIndex(AccessMethod):
         row_dbidx = np.asarray(self.vector_meta.dbidx.values, dtype=np.int64)
         assert np.all(np.diff(row_dbidx) >= 0), "rows must be sorted by dbidx (vectors.sorted.cached)"
         self._row_dbidx = row_dbidx
+        self._box = np.stack([self.vector_meta[c].values for c in ("x1", "y1", "x2", "y2")], axis=1) \
+            if all(c in self.vector_meta for c in ("x1", "y1", "x2", "y2")) else np.zeros((row_dbidx.shape[0], 4), np.float32)
         self._dbidx, self._row2pos = np.unique(row_dbidx, return_inverse=True)
         self._row_start = np.concatenate(([0], np.cumsum(np.bincount(self._row2pos))))
         self.all_indices = FrozenBitMap(self._dbidx) - self.excluded
@@ -205,6 +206,15 @@ class MultiscaleIndex(AccessMethod):
         df.attrs["best_rows"] = best_rows[keep]
         return df
 
+    def _activations_from_best(self, candidate_df: pd.DataFrame, topk: int):
+        rows = np.asarray(candidate_df.attrs["best_rows"][:topk], dtype=np.int64)
+        scores = candidate_df.max_score.values[:topk]
+        acts = []
+        for r, sc in zip(rows, scores):
+            acts.append(pd.DataFrame({"x1": [self._box[r, 0]], "y1": [self._box[r, 1]], "x2": [self._box[r, 2]],
+                                      "y2": [self._box[r, 3]], "dbidx": [self._row_dbidx[r]], "score": [sc]}))
+        return {"dbidxs": candidate_df.dbidx.values[:topk].astype("int"), "activations": acts}
+
     def _candidate_rows(self, positions: np.ndarray) -> np.ndarray:
         positions = np.sort(np.asarray(positions, dtype=np.int64))
         return np.concatenate([np.arange(self._row_start[p], self._row_start[p + 1]) for p in positions]) \
@@ -220,6 +230,11 @@ class MultiscaleIndex(AccessMethod):
                                           force_exact=force_exact)
         if isinstance(candidate_df, tuple):  # nothing left to return
             return {"dbidxs": np.zeros(0, dtype="int"), "activations": []}
+        if vector2 is None and kwargs.get("agg_method") == "plain_score":
+            # the per-image max and the tile attaining it came back with the selection, and the
+            # shortlist is already in (score desc, dbidx asc) order -- the order rescore_candidates
+            # would produce -- so the stage-2 gather is not needed
+            return self._activations_from_best(candidate_df, topk)
         ilocs = self._candidate_rows(candidate_df.attrs["positions"])
         scores = self._dev.gather_scores(ilocs)  # tile scores of the scan that just ran
         if vector2 is not None:
@@ -257,8 +272,51 @@ class BoxFeedbackQuery(InteractiveQuery):
         remaining = np.asarray(self.all_dbidx - self.returned, dtype=np.int64)
         return {"dbidxs": np.random.permutation(remaining)[:batch_size].astype("int"), "activations": None}
 
+    def _matched_fast(self, target_description=None) -> pd.DataFrame:
+        """match_labels_to_vectors without the per-image pandas joins: for every seen image the
+        max IoU of each of its tiles with the image's accepted boxes; results are cached per
+        (image, label content) because earlier rounds' labels do not change."""
+        idx = self.index
+        cache = self.__dict__.setdefault("_match_cache", {})
+        rows_all, iou_all = [], []
+        for dbidx in self.label_db.get_seen():
+            boxes = self.label_db.ldata[int(dbidx)] or []
+            if target_description is not None:
+                sel = [b for b in boxes if b.description == target_description]
+            else:
+                sel = [b for b in boxes if b.marked_accepted]
+            key = (int(dbidx), tuple((b.x1, b.y1, b.x2, b.y2) for b in sel))
+            hit = cache.get(key)
+            if hit is None:
+                pos = int(np.searchsorted(idx._dbidx, dbidx))
+                if pos >= idx._dbidx.shape[0] or idx._dbidx[pos] != dbidx:
+                    continue
+                rows = np.arange(idx._row_start[pos], idx._row_start[pos + 1])
+                miou = np.zeros(rows.shape[0])
+                if sel:
+                    t = idx._box[rows].astype(np.float64)
+                    g = np.array([[b.x1, b.y1, b.x2, b.y2] for b in sel], dtype=np.float32).astype(np.float64)
+                    w = np.clip(np.minimum(t[:, None, 2], g[None, :, 2]) - np.maximum(t[:, None, 0], g[None, :, 0]), 0, None)
+                    h = np.clip(np.minimum(t[:, None, 3], g[None, :, 3]) - np.maximum(t[:, None, 1], g[None, :, 1]), 0, None)
+                    inter = w * h
+                    union = ((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1]))[:, None] + \
+                            ((g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1]))[None, :] - inter
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        iou = np.where(inter > 0, inter / union, 0.0)
+                    miou = iou.max(axis=1)
+                hit = cache[key] = (rows, miou)
+            rows_all.append(hit[0])
+            iou_all.append(hit[1])
+        if not rows_all:
+            return pd.DataFrame({"dbidx": np.zeros(0, np.int64), "ys": np.zeros(0), "max_iou": np.zeros(0)},
+                                index=pd.Index(np.zeros(0, dtype=np.int64)))
+        rows = np.concatenate(rows_all)
+        miou = np.concatenate(iou_all)
+        return pd.DataFrame({"dbidx": idx._row_dbidx[rows], "ys": (miou > 0).astype("float"), "max_iou": miou},
+                            index=pd.Index(rows))
+
     def getXy(self, get_positions=False, target_description=None):
-        matched = match_labels_to_vectors(self.label_db, self.index.vector_meta, target_description=target_description)
+        matched = self._matched_fast(target_description=target_description)
         if get_positions:
             return matched.index[matched.ys > 0].values, matched.index[matched.ys == 0].values
         return matched[["dbidx", "ys", "max_iou"]]

@@ -89,9 +89,12 @@ class KnnProp2(LoopBase):
         scores = model.current_scores()
         cand = q.index.topk_from_scores(scores, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned,
                                         skip_rows=model.is_labeled > 0)
-        rows = q.index._candidate_rows(cand.attrs["positions"])
-        fullmeta = q.index.vector_meta.iloc[rows].assign(score=np.asarray(scores)[rows])
-        ans = rescore_candidates(fullmeta, topk=p.batch_size, **p.dict())
+        if p.agg_method == "plain_score":  # best tile per image came back with the selection
+            ans = q.index._activations_from_best(cand, p.batch_size)
+        else:
+            rows = q.index._candidate_rows(cand.attrs["positions"])
+            fullmeta = q.index.vector_meta.iloc[rows].assign(score=np.asarray(scores)[rows])
+            ans = rescore_candidates(fullmeta, topk=p.batch_size, **p.dict())
         q.returned.update(np.asarray(ans["dbidxs"], dtype=np.int64))
         return ans
 

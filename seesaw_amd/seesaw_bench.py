@@ -40,7 +40,7 @@ def category2query(dataset_name: str, cat: str) -> str:
 def fill_imdata(imdata: Imdata, box_data: pd.DataFrame, b: BenchParams) -> Imdata:
     """the simulated user: mark the ground-truth boxes of the target category."""
     imdata = imdata.copy()
-    rows = box_data[box_data.dbidx == imdata.dbidx]
+    rows = box_data[box_data.dbidx.values == imdata.dbidx]
     boxes = []
     if rows.shape[0] > 0:
         feedback = rows[rows.category == b.ground_truth_category].assign(marked_accepted=True)
@@ -73,7 +73,9 @@ def benchmark_loop(*, session: Session, subset: FrozenBitMap, box_data: pd.DataF
             seen_dbidxs.add(idx)
         if len(idxbatch) == 0:
             break
-        s = copy.deepcopy(session.get_state())
+        # get_state() builds fresh Imdata records every call and fill_imdata works on a copy,
+        # so the reference's deepcopy of the whole state (seesaw_bench.py:325) is not needed
+        s = session.get_state()
         last_batch = s.gdata[-1]
         for j, imdata in enumerate(last_batch):
             last_batch[j] = fill_imdata(imdata, box_data, b)

@@ -104,23 +104,40 @@ class Session:
         for i, (indices, accs) in enumerate(zip(self.acc_indices, self.acc_activations)):
             prefill = (self.params.annotation_category is not None) and (i == last)
             gdata.append(self.get_panel_data(idxbatch=indices, activation_batch=accs, prefill=prefill))
-        return SessionState(action_log=self.action_log, gdata=gdata, timing=self.timing, reference_categories=[],
-                            params=self.params, query_string=self.loop.state.curr_str)
+        return SessionState.model_construct(action_log=self.action_log, gdata=gdata, timing=self.timing,
+                                            reference_categories=[], params=self.params,
+                                            query_string=self.loop.state.curr_str)
+
+    def _static_panel(self, idxbatch, activation_batch):
+        """url + activation records of one batch: they never change once returned, so they are
+        converted from the index's DataFrames once (the reference redoes it for every batch on
+        every get_state, seesaw_session.py:153-186)."""
+        key = id(idxbatch)
+        cache = self.__dict__.setdefault("_panel_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            urls = self.dataset.get_urls(idxbatch)
+            acts = []
+            for i in range(len(idxbatch)):
+                if activation_batch is None or len(activation_batch) == 0:
+                    acts.append(None)
+                    continue
+                a = []
+                for row in activation_batch[i].to_dict(orient="records"):
+                    a.append(ActivationData(box=Box(x1=row["x1"], y1=row["y1"], x2=row["x2"], y2=row["y2"]),
+                                            score=row["score"]))
+                acts.append(a)
+            hit = cache[key] = (idxbatch, urls, acts)  # keeps idxbatch alive so its id stays unique
+        return hit[1], hit[2]
 
     def get_panel_data(self, *, idxbatch, activation_batch=None, prefill=False):
-        urls = self.dataset.get_urls(idxbatch)
+        urls, acts = self._static_panel(idxbatch, activation_batch)
+        db = self.label_db if prefill else self.q.label_db
         out = []
-        for i, (url, dbidx) in enumerate(zip(urls, idxbatch)):
+        for url, dbidx, activations in zip(urls, idxbatch, acts):
             dbidx = int(dbidx)
-            boxes = (self.label_db if prefill else self.q.label_db).get(dbidx, format="box")
-            activations = None
-            if activation_batch is not None and len(activation_batch):
-                activations = []
-                for row in activation_batch[i].to_dict(orient="records"):
-                    score = row.pop("score")
-                    activations.append(ActivationData(box=Box(**{k: row[k] for k in ("x1", "y1", "x2", "y2")}), score=score))
-            out.append(Imdata(url=url, dbidx=dbidx, boxes=boxes, activations=activations,
-                              timing=self.image_timing.get(dbidx, [])))
+            out.append(Imdata.model_construct(url=url, dbidx=dbidx, boxes=db.get(dbidx, format="box"),
+                                              activations=activations, timing=self.image_timing.get(dbidx, [])))
         return out
 
     def _update_labeldb(self, state: SessionState):
