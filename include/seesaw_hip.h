@@ -141,6 +141,11 @@ ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *
                               int32_t n_lists, int32_t list_stride, const int32_t *dev_counts,
                               int32_t k, uint64_t *dev_keys_out, int32_t *dev_count_out);
 
+/* tuning hook (tools/sweep_scan.py): pick the scan kernel's schedule variant for dim=512
+ * (0 u4, 1 u4+nt, 2 u8, 3 u8+nt, 4 u2+nt; -1 = default) and cap its resident blocks per CU
+ * (0 = no cap, -1 = default).  All variants produce identical bits. */
+ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu);
+
 /* per-launch device time of the dominant (scan) kernel, measured with HIP events
  * on the handle's stream.  enable=1 starts recording one event pair per scan
  * launch (up to 4096 launches); ssw_index_profile_read synchronises and returns

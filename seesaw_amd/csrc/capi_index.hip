@@ -530,6 +530,11 @@ ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *
                              dev_count_out, (hipStream_t)hip_stream);
 }
 
+ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu) {
+    tune_scan(variant, blocks_per_cu);
+    return SSW_OK;
+}
+
 ssw_status ssw_index_profile(ssw_index *idx, int32_t enable) {
     SSW_REQUIRE(idx != nullptr, "idx is NULL");
     DeviceGuard guard(idx->device);

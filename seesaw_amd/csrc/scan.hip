@@ -11,9 +11,11 @@
 //
 // Work decomposition (64-wide wavefronts):
 //   * one wave owns a BATCH of 64 consecutive rows (128 KiB contiguous at dim=512) and
-//     walks it in GROUPS of U rows (U = 4 at dim=512); the loads of group g+1 are
-//     issued before group g is reduced (register double buffer), so with 16-20 waves
-//     per CU there are >= 128 KiB of loads in flight per CU.
+//     walks it in GROUPS of U rows (U = 2 at dim=512); the loads of group g+1 are
+//     issued before group g is reduced (register double buffer).  Loads are non-temporal
+//     (`global_load_dwordx4 ... nt`): the index is read once per query and must not churn
+//     L2 / Infinity Cache.  One 4-wave workgroup per CU turned out to be the fastest
+//     residency (see the schedule note below).
 //   * lane l accumulates, for one row, two fmaf chains over the elements it loaded
 //     (float4 v[c] = X[row, 256*c + 4*l .. +3], c < dim/256):
 //         a0 = fma(v[c].x, q.x, a0); a1 = fma(v[c].y, q.y, a1);
@@ -36,6 +38,8 @@
 //
 // Grid: persistent, (#CUs x resident blocks per CU) blocks of 256 threads; waves
 // stride over the batches.
+#include <cstdlib>
+
 #include "ssw_common.h"
 
 namespace ssw {
@@ -47,12 +51,22 @@ struct RowFrag {
     float4 v[C];
 };
 
-template <int C>
+// NT: non-temporal loads (`global_load_dwordx4 ... nt`): the index is streamed once per query
+// and is far larger than L2 / Infinity Cache, so it should not displace anything.
+template <int C, bool NT = false>
 __device__ __forceinline__ RowFrag<C> load_row(const float4 *__restrict__ X4, int row, int lane) {
     RowFrag<C> r;
     const float4 *p = X4 + (int64_t)row * (C * 64) + lane;
 #pragma unroll
-    for (int c = 0; c < C; ++c) r.v[c] = p[c * 64];
+    for (int c = 0; c < C; ++c) {
+        if (NT) {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + c * 64));
+            r.v[c] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            r.v[c] = p[c * 64];
+        }
+    }
     return r;
 }
 
@@ -97,14 +111,14 @@ struct Group {
     RowFrag<C> r[U];
 };
 
-template <int C, int U>
+template <int C, int U, bool NT>
 __device__ __forceinline__ void load_group(Group<C, U> &g, const float4 *__restrict__ X4,
                                            int first_row, int last, int lane) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) g.r[u] = load_row<C>(X4, min(first_row + u, last), lane);
+    for (int u = 0; u < U; ++u) g.r[u] = load_row<C, NT>(X4, min(first_row + u, last), lane);
 }
 
-template <int C, int U>
+template <int C, int U, bool NT>
 __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restrict__ X,
                                                          const float *__restrict__ q,
                                                          float *__restrict__ scores, int n) {
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restric
 
     const int my_group = lane / U;
     Group<C, U> cur, nxt;
-    load_group<C, U>(cur, X4, gwave << 6, last, lane);
+    load_group<C, U, NT>(cur, X4, gwave << 6, last, lane);
     for (int b = gwave; b < nbatches; b += nwaves) {
         const int row0 = b << 6;
         const int nb = b + nwaves;
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restric
         for (int g = 0; g < GPB; ++g) {
             // request group g+1 (or the first group of this wave's next batch) ...
             const int nrow = (g + 1 < GPB) ? row0 + (g + 1) * U : next0;
-            load_group<C, U>(nxt, X4, nrow, last, lane);
+            load_group<C, U, NT>(nxt, X4, nrow, last, lane);
             // ... then finish group g
             float acc[U];
 #pragma unroll
@@ -163,26 +177,37 @@ __global__ __launch_bounds__(256) void score_rows_kernel(const float *__restrict
     RowFrag<C> qf;
 #pragma unroll
     for (int c = 0; c < C; ++c) qf.v[c] = reinterpret_cast<const float4 *>(q)[c * 64 + lane];
-    const RowFrag<C> x = load_row<C>(X4, (int)rows[w], lane);
+    const RowFrag<C> x = load_row<C, false>(X4, (int)rows[w], lane);
     float v = dot_frag<C>(x, qf);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
     if (lane == 0) out[w] = v;
 }
 
-template <int C, int U>
+// Schedule (measured on MI355X, interleaved A/B in one process, tools/sweep_scan.py):
+// non-temporal loads are worth +4...7 %, and with them FEWER resident waves stream faster --
+// at 100 M rows u2+nt with one block per CU reads 6.70 TB/s, u4 (default policy, 8 waves/SIMD)
+// 6.17 TB/s; 1 M rows: 6.66 vs 5.65 TB/s.  All variants produce identical bits.
+int g_scan_variant = -1;        // tuning hook (ssw_tune_scan): -1 = default (u2 + nt)
+int g_scan_blocks_per_cu = -1;  // -1 = default (1 per CU for dim 512), 0 = as many as fit
+
+template <int C, int U, bool NT>
 ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t n, int device,
                          hipStream_t stream) {
-    static int blocks_per_cu[16] = {0};
+    static int max_blocks_per_cu[16] = {0};
     int dev_slot = device & 15;
-    if (blocks_per_cu[dev_slot] == 0) {
+    if (max_blocks_per_cu[dev_slot] == 0) {
         int nb = 0;
-        SSW_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_scores_kernel<C, U>,
+        SSW_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, scan_scores_kernel<C, U, NT>,
                                                                  256, 0));
         if (nb < 1) nb = 1;
         if (nb > 8) nb = 8;
-        blocks_per_cu[dev_slot] = nb;
+        max_blocks_per_cu[dev_slot] = nb;
     }
+    int blocks_per_cu[16];
+    blocks_per_cu[dev_slot] = max_blocks_per_cu[dev_slot];
+    const int cap = g_scan_blocks_per_cu < 0 ? (C == 2 ? 1 : 2) : g_scan_blocks_per_cu;
+    if (cap >= 1 && cap < blocks_per_cu[dev_slot]) blocks_per_cu[dev_slot] = cap;
     if (n >= (int64_t)0x7fff0000) {
         set_error("scan: n=%lld rows exceeds the 2^31 row limit of one index shard", (long long)n);
         return SSW_ERR_UNSUPPORTED;
@@ -192,7 +217,7 @@ ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t 
     const int64_t need = (nbatches + 3) / 4;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((scan_scores_kernel<C, U>), dim3((unsigned)grid), dim3(256), 0, stream, X,
+    hipLaunchKernelGGL((scan_scores_kernel<C, U, NT>), dim3((unsigned)grid), dim3(256), 0, stream, X,
                        q, scores, (int)n);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -204,10 +229,20 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
                        int device, hipStream_t stream) {
     if (n <= 0) return SSW_OK;
     switch (dim) {
-        case 256: return launch_scan_t<1, 8>(X, q_dev, scores, n, device, stream);
-        case 512: return launch_scan_t<2, 4>(X, q_dev, scores, n, device, stream);
-        case 768: return launch_scan_t<3, 2>(X, q_dev, scores, n, device, stream);
-        case 1024: return launch_scan_t<4, 2>(X, q_dev, scores, n, device, stream);
+        case 256: return launch_scan_t<1, 8, true>(X, q_dev, scores, n, device, stream);
+        case 512: {
+            // variants differ in schedule only (rows per group, load policy); numerics are identical
+            switch (g_scan_variant) {
+                case 0: return launch_scan_t<2, 4, false>(X, q_dev, scores, n, device, stream);
+                case 2: return launch_scan_t<2, 8, false>(X, q_dev, scores, n, device, stream);
+                case 3: return launch_scan_t<2, 8, true>(X, q_dev, scores, n, device, stream);
+                case 4: return launch_scan_t<2, 2, true>(X, q_dev, scores, n, device, stream);
+                case 1: return launch_scan_t<2, 4, true>(X, q_dev, scores, n, device, stream);
+                default: return launch_scan_t<2, 2, true>(X, q_dev, scores, n, device, stream);
+            }
+        }
+        case 768: return launch_scan_t<3, 2, true>(X, q_dev, scores, n, device, stream);
+        case 1024: return launch_scan_t<4, 2, true>(X, q_dev, scores, n, device, stream);
         default:
             set_error("scan: dim=%d unsupported (need a multiple of 256, <= 1024)", dim);
             return SSW_ERR_UNSUPPORTED;
@@ -229,6 +264,11 @@ ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *
     }
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
+}
+
+void tune_scan(int variant, int blocks_per_cu) {
+    g_scan_variant = variant;
+    g_scan_blocks_per_cu = blocks_per_cu;
 }
 
 }  // namespace ssw

@@ -92,6 +92,7 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
                        int device, hipStream_t stream);
 ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *rows_dev, int64_t n,
                              int32_t dim, float *out, hipStream_t stream);
+void tune_scan(int variant, int blocks_per_cu);
 // rng.hip: synthetic unit-norm rows.
 ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
                               hipStream_t stream);
