@@ -88,6 +88,7 @@ struct ssw_index {
     float *gather_out = nullptr;
     int64_t gather_cap = 0;
     PinnedStage rows_stage;
+    void *res_host = nullptr;  // pinned result mirror
     float *q2_dev = nullptr;  // second query vector (score_rows)
     PinnedStage q2_stage;
     // profiling of the scan kernel
@@ -234,6 +235,7 @@ ssw_status ssw_index_destroy(ssw_index *idx) {
     (void)hipFree(idx->gather_out);
     (void)hipFree(idx->q2_dev);
     idx->rows_stage.release();
+    if (idx->res_host) (void)hipHostFree(idx->res_host);
     idx->q2_stage.release();
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -412,6 +414,23 @@ ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_cou
     return SSW_OK;
 }
 
+// one pinned block receives [count, overflow][keys k][best k] with async copies and a single sync
+static ssw_status fetch_results(ssw_index *idx, int32_t k, int32_t *count, bool *overflow) {
+    const size_t need = 16 + (size_t)SSW_MAX_TOPK * (sizeof(uint64_t) + sizeof(uint32_t));
+    if (!idx->res_host) SSW_HIP_TRY(hipHostMalloc((void **)&idx->res_host, need, hipHostMallocDefault));
+    char *h = reinterpret_cast<char *>(idx->res_host);
+    SSW_HIP_TRY(hipMemcpyAsync(h, idx->ws.out_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(h + 16, idx->ws.out_keys, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               idx->stream));
+    SSW_HIP_TRY(hipMemcpyAsync(h + 16 + (size_t)SSW_MAX_TOPK * sizeof(uint64_t), idx->ws.out_best,
+                               (size_t)k * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(h);
+    *count = hdr[0];
+    *overflow = hdr[1] != 0;
+    return SSW_OK;
+}
+
 ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, float *out_scores,
                                 int64_t *out_best_rows, int32_t *out_count) {
     SSW_REQUIRE(idx != nullptr && out_count != nullptr, "NULL argument");
@@ -420,30 +439,25 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
     if (idx->n_images == 0) return SSW_OK;
     DeviceGuard guard(idx->device);
     SSW_TRY(ensure_ws(idx));
+    int32_t count = 0;
     bool overflow = false;
-    SSW_TRY(select_check_overflow(idx->ws, idx->stream, &overflow));
-    if (overflow) {
+    SSW_TRY(fetch_results(idx, k, &count, &overflow));
+    if (overflow) {  // massive exact ties: rerun the selection on the deep path
         const float *values = idx->has_map ? idx->ws.img_score : idx->scores;
         const uint32_t *best = idx->has_map ? idx->ws.img_best : nullptr;
         SSW_TRY(launch_select_topk_deep(idx->ws, values, idx->n_images, best, k, idx->device,
                                         idx->stream));
+        SSW_TRY(fetch_results(idx, k, &count, &overflow));
     }
-    int32_t count = 0;
-    std::vector<uint64_t> keys((size_t)k);
-    std::vector<uint32_t> best((size_t)k);
-    SSW_HIP_TRY(hipMemcpyAsync(&count, idx->ws.out_count, sizeof(int32_t), hipMemcpyDeviceToHost,
-                               idx->stream));
-    SSW_HIP_TRY(hipMemcpyAsync(keys.data(), idx->ws.out_keys, (size_t)k * sizeof(uint64_t),
-                               hipMemcpyDeviceToHost, idx->stream));
-    SSW_HIP_TRY(hipMemcpyAsync(best.data(), idx->ws.out_best, (size_t)k * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, idx->stream));
-    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    const char *h = reinterpret_cast<const char *>(idx->res_host);
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(h + 16);
+    const uint32_t *best = reinterpret_cast<const uint32_t *>(h + 16 + (size_t)SSW_MAX_TOPK * sizeof(uint64_t));
     if (count > k) count = k;
     for (int32_t i = 0; i < count; ++i) {
-        const uint64_t key = keys[(size_t)i];
+        const uint64_t key = keys[i];
         if (out_images) out_images[i] = (int64_t)(0xffffffffu - (uint32_t)(key & 0xffffffffull));
         if (out_scores) out_scores[i] = ord_to_f32((uint32_t)(key >> 32));
-        if (out_best_rows) out_best_rows[i] = (int64_t)best[(size_t)i];
+        if (out_best_rows) out_best_rows[i] = (int64_t)best[i];
     }
     *out_count = count;
     return SSW_OK;

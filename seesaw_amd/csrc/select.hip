@@ -254,7 +254,8 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t *s, int p, int t) {
 // length is *ncand_ptr) -> k largest, sorted descending.
 __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ keys_in, int n_lists,
                                                 int list_stride, const int32_t *__restrict__ counts,
-                                                const uint32_t *__restrict__ ncand_ptr, int k,
+                                                const uint32_t *__restrict__ ncand_ptr,
+                                                const uint32_t *__restrict__ state_or_null, int k,
                                                 const uint32_t *__restrict__ best_src,
                                                 uint64_t *__restrict__ keys_out,
                                                 int32_t *__restrict__ count_out,
@@ -287,7 +288,12 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
             best_out[i] = best_src ? best_src[id] : id;
         }
     }
-    if (t == 0) *count_out = out;
+    if (t == 0) {
+        count_out[0] = out;
+        // overflow of the fast path (more candidates than the final sort takes), for the host
+        if (state_or_null)
+            count_out[1] = (state_or_null[ST_OVERFLOW] != 0 || state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP) ? 1 : 0;
+    }
 }
 
 __global__ void k_gather_f32(const float *__restrict__ src, const int64_t *__restrict__ idx,
@@ -407,20 +413,12 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, (int)k);
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
-                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (int)k,
+                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
                        best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
 
-
-ssw_status select_check_overflow(SelectWorkspace &ws, hipStream_t stream, bool *overflow) {
-    uint32_t st[ST_WORDS];
-    SSW_HIP_TRY(hipMemcpyAsync(st, ws.state, sizeof(st), hipMemcpyDeviceToHost, stream));
-    SSW_HIP_TRY(hipStreamSynchronize(stream));
-    *overflow = st[ST_OVERFLOW] != 0 || st[ST_NCAND] > (uint32_t)FINAL_CAP;
-    return SSW_OK;
-}
 
 ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,
                                    const uint32_t *best_rows_or_null, int32_t k, int device,
@@ -456,7 +454,7 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
     hipLaunchKernelGGL(k_collect_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state,
                        ws.cand, threshold);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
-                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (int)k,
+                       0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
                        best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -474,8 +472,9 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
         return SSW_ERR_INVALID;
     }
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,
-                       (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr, (int)k,
-                       (const uint32_t *)nullptr, keys_out, count_out, (uint32_t *)nullptr);
+                       (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, (int)k, (const uint32_t *)nullptr, keys_out, count_out,
+                       (uint32_t *)nullptr);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

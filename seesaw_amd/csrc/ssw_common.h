@@ -129,9 +129,8 @@ ssw_status launch_image_max(const float *scores, const int64_t *row_start, int64
 ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t m,
                               const uint32_t *best_rows_or_null, int32_t k, int device,
                               hipStream_t stream);
-// the fast path flags a 24-bit prefix bin with more candidates than the final sort can
-// take (massive exact ties); the caller then reruns the selection on the deep path.
-ssw_status select_check_overflow(SelectWorkspace &ws, hipStream_t stream, bool *overflow);
+// the fast path flags (out_count[1]) a 24-bit prefix bin with more candidates than the final
+// sort can take (massive exact ties); the caller then reruns the selection on the deep path.
 ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,
                                    const uint32_t *best_rows_or_null, int32_t k, int device,
                                    hipStream_t stream);
