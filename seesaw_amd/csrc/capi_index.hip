@@ -414,20 +414,21 @@ ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_cou
     return SSW_OK;
 }
 
-// one pinned block receives [count, overflow][keys k][best k] with async copies and a single sync
+// one pinned block receives the packed result [count, overflow, k, 0][keys k][best k]:
+// one async copy, one synchronisation
 static ssw_status fetch_results(ssw_index *idx, int32_t k, int32_t *count, bool *overflow) {
-    const size_t need = 16 + (size_t)SSW_MAX_TOPK * (sizeof(uint64_t) + sizeof(uint32_t));
-    if (!idx->res_host) SSW_HIP_TRY(hipHostMalloc((void **)&idx->res_host, need, hipHostMallocDefault));
-    char *h = reinterpret_cast<char *>(idx->res_host);
-    SSW_HIP_TRY(hipMemcpyAsync(h, idx->ws.out_count, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, idx->stream));
-    SSW_HIP_TRY(hipMemcpyAsync(h + 16, idx->ws.out_keys, (size_t)k * sizeof(uint64_t), hipMemcpyDeviceToHost,
+    const size_t cap = 16 + (size_t)SSW_MAX_TOPK * 12;
+    if (!idx->res_host) SSW_HIP_TRY(hipHostMalloc((void **)&idx->res_host, cap, hipHostMallocDefault));
+    SSW_HIP_TRY(hipMemcpyAsync(idx->res_host, idx->ws.packed, 16 + (size_t)k * 12, hipMemcpyDeviceToHost,
                                idx->stream));
-    SSW_HIP_TRY(hipMemcpyAsync(h + 16 + (size_t)SSW_MAX_TOPK * sizeof(uint64_t), idx->ws.out_best,
-                               (size_t)k * sizeof(uint32_t), hipMemcpyDeviceToHost, idx->stream));
     SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
-    const int32_t *hdr = reinterpret_cast<const int32_t *>(h);
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(idx->res_host);
     *count = hdr[0];
     *overflow = hdr[1] != 0;
+    if (hdr[2] != k) {
+        set_error("topk_fetch: k=%d does not match the k=%d of the selection that produced the result", k, hdr[2]);
+        return SSW_ERR_INVALID;
+    }
     return SSW_OK;
 }
 
@@ -451,7 +452,7 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
     }
     const char *h = reinterpret_cast<const char *>(idx->res_host);
     const uint64_t *keys = reinterpret_cast<const uint64_t *>(h + 16);
-    const uint32_t *best = reinterpret_cast<const uint32_t *>(h + 16 + (size_t)SSW_MAX_TOPK * sizeof(uint64_t));
+    const uint32_t *best = reinterpret_cast<const uint32_t *>(h + 16 + (size_t)k * sizeof(uint64_t));
     if (count > k) count = k;
     for (int32_t i = 0; i < count; ++i) {
         const uint64_t key = keys[i];

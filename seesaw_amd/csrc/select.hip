@@ -259,7 +259,8 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
                                                 const uint32_t *__restrict__ best_src,
                                                 uint64_t *__restrict__ keys_out,
                                                 int32_t *__restrict__ count_out,
-                                                uint32_t *__restrict__ best_out) {
+                                                uint32_t *__restrict__ best_out,
+                                                unsigned char *__restrict__ packed_or_null) {
     extern __shared__ uint64_t s[];  // FINAL_CAP entries
     const int t = threadIdx.x;
     int n = 0;
@@ -280,19 +281,33 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
     __syncthreads();
     bitonic_sort_desc(s, p, t);
     const int out = min(k, n);
+    // packed mirror for the host: [count, overflow, k, 0][keys x k][best x k], one D2H copy
+    uint64_t *pk_keys = packed_or_null ? reinterpret_cast<uint64_t *>(packed_or_null + 16) : nullptr;
+    uint32_t *pk_best = packed_or_null ? reinterpret_cast<uint32_t *>(packed_or_null + 16 + (size_t)k * 8) : nullptr;
     for (int i = t; i < out; i += 1024) {
         const uint64_t key = s[i];
         keys_out[i] = key;
+        if (pk_keys) pk_keys[i] = key;
         if (best_out != nullptr) {
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
-            best_out[i] = best_src ? best_src[id] : id;
+            const uint32_t br = best_src ? best_src[id] : id;
+            best_out[i] = br;
+            if (pk_best) pk_best[i] = br;
         }
     }
     if (t == 0) {
-        count_out[0] = out;
         // overflow of the fast path (more candidates than the final sort takes), for the host
-        if (state_or_null)
-            count_out[1] = (state_or_null[ST_OVERFLOW] != 0 || state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP) ? 1 : 0;
+        const int ovf = (state_or_null && (state_or_null[ST_OVERFLOW] != 0 ||
+                                           state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
+        count_out[0] = out;
+        if (state_or_null) count_out[1] = ovf;
+        if (packed_or_null) {
+            int32_t *hdr = reinterpret_cast<int32_t *>(packed_or_null);
+            hdr[0] = out;
+            hdr[1] = ovf;
+            hdr[2] = k;
+            hdr[3] = 0;
+        }
     }
 }
 
@@ -309,7 +324,9 @@ ssw_status dev_alloc(T **p, size_t count) {
 }
 
 int grid_for(int64_t m, int device) {
-    int64_t g = (m + 255) / 256;
+    // >= 4096 elements per workgroup: zeroing / flushing the 4096-bin LDS histogram is the
+    // fixed cost of a block (at 1 M images 2048 blocks spent most of k_hist on it)
+    int64_t g = (m + 4095) / 4096;
     const int64_t cap = (int64_t)num_cus(device) * 8;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -326,6 +343,7 @@ ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, b
     SSW_TRY(dev_alloc(&ws.out_keys, SSW_MAX_TOPK));
     SSW_TRY(dev_alloc(&ws.out_count, 4));
     SSW_TRY(dev_alloc(&ws.out_best, SSW_MAX_TOPK));
+    SSW_TRY(dev_alloc(&ws.packed, 16 + (size_t)SSW_MAX_TOPK * 12));
     if (has_map) {
         SSW_TRY(dev_alloc(&ws.img_score, n_images));
         SSW_TRY(dev_alloc(&ws.img_best, n_images));
@@ -344,6 +362,7 @@ void select_free(SelectWorkspace &ws) {
     (void)hipFree(ws.out_keys);
     (void)hipFree(ws.out_count);
     (void)hipFree(ws.out_best);
+    (void)hipFree(ws.packed);
     (void)hipFree(ws.img_score);
     (void)hipFree(ws.img_best);
     (void)hipFree(ws.excl_bits);
@@ -414,7 +433,7 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -455,7 +474,7 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
                        ws.cand, threshold);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -474,7 +493,7 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,
                        (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr, (int)k, (const uint32_t *)nullptr, keys_out, count_out,
-                       (uint32_t *)nullptr);
+                       (uint32_t *)nullptr, (unsigned char *)nullptr);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

@@ -107,6 +107,7 @@ struct SelectWorkspace {
     uint64_t *out_keys = nullptr;   // [SSW_MAX_TOPK]
     int32_t *out_count = nullptr;   // [1]
     uint32_t *out_best = nullptr;   // [SSW_MAX_TOPK]
+    unsigned char *packed = nullptr;  // [16 + 12 k] host mirror layout: header, keys[k], best[k]
     float *img_score = nullptr;     // [n_images]   (only when row2image is set)
     uint32_t *img_best = nullptr;   // [n_images]
     uint32_t *excl_bits = nullptr;  // [(n_images+31)/32]

@@ -26,6 +26,7 @@ def main():
         gbs = n * 2048 / (ms * 1e-3) / 1e9
         print(f"n={n}: scan kernel {np.median(ms):.4f} ms median (min {ms.min():.4f}) -> "
               f"{np.median(gbs):.0f} GB/s median, {gbs.max():.0f} best; host wall/scan {wall*1e3:.3f} ms", flush=True)
+        idx.topk(q, 100)  # first call allocates the select workspace
         t0 = time.perf_counter()
         for _ in range(20):
             idx.topk(q, 100)
