@@ -261,7 +261,7 @@ def main():
                 "parallelism": f"row-shard x{world}",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "scan_scores_kernel<2,4>",
+                "bound": "hbm", "kernel": "scan_scores_kernel<2,2,nt>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": avg_ms, "launches": int(len(scan_ms)),
