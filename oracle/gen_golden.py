@@ -375,8 +375,94 @@ def gen_multireg():
     save("multireg", **out)
 
 
+def gen_bench_loop():
+    """(vii) the reference's own Session + benchmark_loop (seesaw_session.py, seesaw_bench.py:278-355)
+    over its own MultiscaleIndex and loops, on the synthetic LVIS-shape dataset of
+    seesaw_amd.synthetic (data only: vectors, tile boxes, ground truth).  Captured: the dbidx
+    returned in every round, nfound / nseen.  Ray-backed caches are bypassed by handing the
+    loops the weight matrices directly (they are built by the reference's get_weight_matrix)."""
+    import pandas as pd
+    from seesaw_amd.synthetic import make_dataset
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    sess = R.ref("seesaw.seesaw_session")
+    bench = R.ref("seesaw.seesaw_bench")
+    bt = R.ref("seesaw.basic_types")
+    kg = R.ref("seesaw.knn_graph")
+    mreg = R.ref("seesaw.loops.multi_reg")
+    gb = R.ref("seesaw.loops.graph_based")
+    pr = sys.modules["pyroaring"]
+
+    ds = make_dataset("lvis", n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=21, knn_k=10,
+                      signal=0.17)
+    ds.embedding.noise = 1.0  # a mediocre text query: hits and misses alternate, feedback matters
+    knn_df = ds.knn_graph().restrict_k(k=10).knn_df
+    W = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
+    L = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True,
+                             laplacian=True)
+    xlx = np.asarray(ds.vectors.T @ ((L / L.diagonal().sum()) @ ds.vectors))
+
+    def fake_wm(idx, options, xlx_matrix=False):
+        return xlx if xlx_matrix else W
+
+    mreg.get_weight_matrix_from_index = fake_wm
+    gb.get_weight_matrix_from_index = fake_wm
+
+    class FakeDataset:
+        def __init__(self, d):
+            self.d = d
+            self.file_meta = d.file_meta
+            self.paths = d.paths
+
+        def load_ground_truth(self):
+            return self.d.load_ground_truth()
+
+        def get_urls(self, idxbatch):
+            return self.d.get_urls(idxbatch)
+
+    matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    variants = {
+        "plain": None,
+        "rocchio_update": dict(rocchio_alpha=1.0, rocchio_beta=0.5, rocchio_gamma=0.25, verbose=False),
+        "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
+                          reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200,
+                          pos_weight="balanced", lr=1.0, matrix_options=matrix),
+        "multi_reg_data": dict(label_loss_type="pairwise_rank_loss", rank_loss_margin=0.2, use_qvec_norm=None,
+                               reg_data_lambda=1000.0, reg_norm_lambda=100.0, reg_query_lambda=10.0, verbose=False,
+                               max_iter=100, pos_weight="balanced", lr=1.0, matrix_options=matrix),
+        "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                          calib_b=-0.4, prior_weight=1.0),
+    }
+    boxes, _ = ds.load_ground_truth()
+    out = {"names": np.array(list(variants))}
+    import contextlib
+    import io
+    for name, opts in variants.items():
+        interactive = "multi_reg" if name.startswith("multi_reg") else name
+        index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+        p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="multiscale", c_name=None),
+                             interactive=interactive, interactive_options=opts, batch_size=1, shortlist_size=50,
+                             agg_method="plain_score", aug_larger="greater",
+                             # the reference's KnnProp2 never sets curr_qvec, so it only runs from_start
+                             start_policy="from_start" if name == "knn_prop2" else "after_first_batch",
+                             index_options={"use_vec_index": False})
+        b = bt.BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
+        np.random.seed(0)
+        import torch
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            session = sess.Session(None, FakeDataset(ds), index, p)
+            res = bench.benchmark_loop(session=session, subset=pr.BitMap(ds.file_meta.index.values), box_data=boxes,
+                                       b=b, p=p)
+        shown = np.array([int(a[0]) for a in session.acc_indices], dtype=np.int64)
+        out[f"{name}_shown"] = shown
+        out[f"{name}_nfound"] = np.asarray(res["nfound"])
+        out[f"{name}_nseen"] = np.asarray(res["nseen"])
+        print(name, res["nfound"], res["nseen"], shown[:12])
+    save("bench_loop", **out)
+
+
 FAMILIES = {"scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
-            "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg}
+            "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(FAMILIES)

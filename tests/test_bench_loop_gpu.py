@@ -117,3 +117,33 @@ def test_feedback_beats_plain(lvis):
         ds.embedding.string_cache.clear()
     assert seen["multi_reg"][1] >= seen["plain"][1]
     assert seen["multi_reg"][0] <= seen["plain"][0] + 3
+
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["plain", "rocchio_update", "multi_reg", "multi_reg_data", "knn_prop2"])
+def test_benchmark_loop_sequence_matches_reference(name):
+    """The dbidx returned in every round, nfound and nseen equal what the REFERENCE's own
+    Session + benchmark_loop + MultiscaleIndex + loops produced on the same synthetic dataset
+    (tests/golden/bench_loop.npz, captured by oracle/gen_golden.py::gen_bench_loop)."""
+    from seesaw_amd.basic_types import BenchParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import make_session
+    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
+    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
+    ds = make_dataset("lvis", n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=21, knn_k=10,
+                      signal=0.17)
+    ds.embedding.noise = 1.0
+    gdm = GlobalDataManager().add(ds)
+    interactive = "multi_reg" if name.startswith("multi_reg") else name
+    p = _params(interactive, LOOPS[name], start_policy="from_start" if name == "knn_prop2" else "after_first_batch")
+    b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
+    ret = make_session(gdm, p, b=b)
+    boxes, _ = ds.load_ground_truth()
+    out = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+    shown = np.array([int(a[0]) for a in ret["session"].acc_indices])
+    ref = g[f"{name}_shown"]
+    assert np.array_equal(shown, ref), (shown.tolist(), ref.tolist())
+    assert out["nfound"] == int(g[f"{name}_nfound"]) and out["nseen"] == int(g[f"{name}_nseen"])
