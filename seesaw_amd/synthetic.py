@@ -16,6 +16,8 @@ call (`get_dataset`, `load_index`, `load_ground_truth`, `load_subset`, `get_urls
 """
 from __future__ import annotations
 
+import zlib
+
 import numpy as np
 import pandas as pd
 
@@ -42,7 +44,7 @@ class SyntheticEmbedding:
         if string in self.string_cache:
             return self.string_cache[string]
         key = string[2:] if string.startswith("a ") else string
-        rng = np.random.default_rng(abs(hash((self.seed, string))) % (1 << 32))
+        rng = np.random.default_rng(zlib.crc32(f"{self.seed}:{string}".encode()))  # stable across processes
         base = self.directions.get(key)
         noise = _unit(rng.standard_normal(self.dim))
         vec = noise if base is None else base + self.noise * noise
