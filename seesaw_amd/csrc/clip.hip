@@ -47,44 +47,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
                                                     int M, int N, int K) {
-    // Persistent: the grid is (#CUs x resident blocks); every workgroup walks its share of the
-    // output tiles and the (tile, k-slab) sequence is ONE software pipeline, so the first slab
-    // of the next tile is already in flight while the current tile's epilogue stores -- with
-    // K = 768 (12 slabs) a per-tile prologue would otherwise cost as much as the tile's MFMAs.
-    // Tile order: workgroups that share an XCD (blockIdx % 8) take neighbouring tiles of the
-    // same row block, so the A rows they all read stay in that XCD's L2.
     __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * LDS_STRIDE];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
-    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
-    const int n_tiles = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    // XCD-aware slot: blocks b, b+8, b+16, ... (same XCD) get consecutive slots
-    const int per_xcd = (G + 7) / 8;
-    const int slot = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int nk = K / BK;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-    const int srow = t >> 3, scol = (t & 7) * 8;  // staging chunk (row, 8 bf16) ; +32 rows per chunk
-    const int lds_off = srow * LDS_STRIDE + scol;
-    const int fr = lane & 15, fq = lane >> 4;
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread (chunk c = t + 256 i:
+    // row c/8, 8 bf16 at column (c%8)*8); kept in registers across the MFMA block
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-
-#define SSW_LOAD_TILES(tile_, k0_)                                                              \
-    {                                                                                           \
-        const int tm_ = ((tile_) / tiles_n) * BM, tn_ = ((tile_) % tiles_n) * BN;               \
-        const bf16 *ap_ = A + (k0_) + scol;                                                     \
-        ra0 = *reinterpret_cast<const uint4 *>(ap_ + (int64_t)min(tm_ + srow, M - 1) * K);      \
-        ra1 = *reinterpret_cast<const uint4 *>(ap_ + (int64_t)min(tm_ + srow + 32, M - 1) * K); \
-        ra2 = *reinterpret_cast<const uint4 *>(ap_ + (int64_t)min(tm_ + srow + 64, M - 1) * K); \
-        ra3 = *reinterpret_cast<const uint4 *>(ap_ + (int64_t)min(tm_ + srow + 96, M - 1) * K); \
-        const bf16 *wp_ = W + (int64_t)(tn_ + srow) * K + (k0_) + scol;                         \
-        rb0 = *reinterpret_cast<const uint4 *>(wp_);                                            \
-        rb1 = *reinterpret_cast<const uint4 *>(wp_ + (int64_t)32 * K);                          \
-        rb2 = *reinterpret_cast<const uint4 *>(wp_ + (int64_t)64 * K);                          \
-        rb3 = *reinterpret_cast<const uint4 *>(wp_ + (int64_t)96 * K);                          \
-    }
+    const int srow = t >> 3, scol = (t & 7) * 8;  // chunk i adds 32 rows
+    const bf16 *a_ptr0 = A + (int64_t)min(m0 + srow, M - 1) * K + scol;
+    const bf16 *a_ptr1 = A + (int64_t)min(m0 + srow + 32, M - 1) * K + scol;
+    const bf16 *a_ptr2 = A + (int64_t)min(m0 + srow + 64, M - 1) * K + scol;
+    const bf16 *a_ptr3 = A + (int64_t)min(m0 + srow + 96, M - 1) * K + scol;
+    const bf16 *w_ptr = W + (int64_t)(n0 + srow) * K + scol;
+    const int64_t w_step = (int64_t)32 * K;
+    const int lds_off = srow * LDS_STRIDE + scol;
+#define SSW_LOAD_TILES(k0)                                                   \
+    ra0 = *reinterpret_cast<const uint4 *>(a_ptr0 + (k0));                   \
+    ra1 = *reinterpret_cast<const uint4 *>(a_ptr1 + (k0));                   \
+    ra2 = *reinterpret_cast<const uint4 *>(a_ptr2 + (k0));                   \
+    ra3 = *reinterpret_cast<const uint4 *>(a_ptr3 + (k0));                   \
+    rb0 = *reinterpret_cast<const uint4 *>(w_ptr + (k0));                    \
+    rb1 = *reinterpret_cast<const uint4 *>(w_ptr + w_step + (k0));           \
+    rb2 = *reinterpret_cast<const uint4 *>(w_ptr + 2 * w_step + (k0));       \
+    rb3 = *reinterpret_cast<const uint4 *>(w_ptr + 3 * w_step + (k0));
 #define SSW_STORE_TILES(buf)                                                                  \
     *reinterpret_cast<uint4 *>(&sA[buf][lds_off]) = ra0;                                      \
     *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 32 * LDS_STRIDE]) = ra1;                    \
@@ -95,89 +84,80 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
     *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 64 * LDS_STRIDE]) = rb2;                    \
     *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 96 * LDS_STRIDE]) = rb3;
 
-    int tile = slot;
-    if (tile >= n_tiles) return;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    SSW_LOAD_TILES(tile, 0)
+    const int nk = K / BK;
+    SSW_LOAD_TILES(0)
     SSW_STORE_TILES(0)
     __syncthreads();
-    int buf = 0;
-    const int stride = 8 * per_xcd;
-    while (true) {
-        for (int kt = 0; kt < nk; ++kt) {
-            // next slab: same tile, or the first slab of this workgroup's next tile
-            const bool last_k = (kt + 1 == nk);
-            const int ntile = last_k ? tile + stride : tile;
-            const bool have_next = ntile < n_tiles;
-            if (have_next) SSW_LOAD_TILES(ntile, last_k ? 0 : (kt + 1) * BK)
-#pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks) {
-                bf16x8 a[4], b[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][(wm * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
-                    b[i] = *reinterpret_cast<const bf16x8 *>(&sB[buf][(wn * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            if (have_next) {
-                // the other buffer was last read one step ago, before the barrier that ended that step
-                if (buf == 0) {
-                    SSW_STORE_TILES(1)
-                } else {
-                    SSW_STORE_TILES(0)
-                }
-            }
-            __syncthreads();
-            buf ^= 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {  // global loads fly while this tile is multiplied
+            const int k0 = (kt + 1) * BK;
+            SSW_LOAD_TILES(k0)
         }
-        // epilogue of `tile` (the next tile's first slab is already staged / in flight)
-        {
-            const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = n0 + wn * 64 + j * 16 + fr;
-                    const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
-                        if (row < M) {
-                            float v = acc[i][j][r] + bv;
-                            const int64_t o = (int64_t)row * N + col;
-                            if (EPI == EPI_BF16_BIAS_GELU) v = v / (1.f + __expf(-1.702f * v));  // quick_gelu
-                            if (EPI == EPI_F32_BIAS_RESIDUAL) v += residual[o];
-                            if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU)
-                                reinterpret_cast<bf16 *>(Cout)[o] = to_bf16(v);
-                            else
-                                reinterpret_cast<float *>(Cout)[o] = v;
-                        }
-                    }
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][(wm * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
+                b[i] = *reinterpret_cast<const bf16x8 *>(&sB[buf][(wn * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        tile += stride;
-        if (tile >= n_tiles) break;
+        if (kt + 1 < nk) {
+            // the other buffer was last read one iteration ago, before the barrier below
+            if (buf == 0) {
+                SSW_STORE_TILES(1)
+            } else {
+                SSW_STORE_TILES(0)
+            }
+            __syncthreads();
+        }
     }
 #undef SSW_LOAD_TILES
 #undef SSW_STORE_TILES
+
+    // epilogue: lane holds C[row = fq*4 + r][col = fr] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fr;
+            const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                const int64_t o = (int64_t)row * N + col;
+                if (EPI == EPI_BF16_BIAS_GELU) v = v / (1.f + __expf(-1.702f * v));  // quick_gelu
+                if (EPI == EPI_F32_BIAS_RESIDUAL) v += residual[o];
+                if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU)
+                    reinterpret_cast<bf16 *>(Cout)[o] = to_bf16(v);
+                else
+                    reinterpret_cast<float *>(Cout)[o] = v;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim (one wave per row), f32 in -> bf16 or f32 out.
 // row_index (optional): normalise only the listed rows (class token / EOS positions).
 // ---------------------------------------------------------------------------------------
+// One wave per row; the row (D <= 1024 floats = 4 float4 per lane) stays in registers, so x is
+// read once with 16-byte loads and mean / variance / normalise are a single pass.
 template <typename OutT>
 __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ x, const int *__restrict__ row_index,
                                                       int n_rows, int D, const float *__restrict__ w,
@@ -185,22 +165,45 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    const float *xr = x + (int64_t)(row_index ? row_index[r] : r) * D;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)(row_index ? row_index[r] : r) * D);
+    const int nv = D >> 2;  // float4 per row (D % 4 == 0)
+    float4 v[4];
     float s = 0.f;
-    for (int c = lane; c < D; c += 64) s += xr[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)D;
-    float v = 0.f;
-    for (int c = lane; c < D; c += 64) {
-        const float d = xr[c] - mean;
-        v += d * d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < nv) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    const float rstd = rsqrtf(v / (float)D + eps);
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = rsqrtf(q / (float)D + eps);
+    const float4 *w4 = reinterpret_cast<const float4 *>(w), *b4 = reinterpret_cast<const float4 *>(b);
     OutT *o = out + (int64_t)r * D;
-    for (int c = lane; c < D; c += 64) o[c] = (OutT)((xr[c] - mean) * rstd * w[c] + b[c]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 ww = w4[c], bb = b4[c];
+            const float y0 = (v[i].x - mean) * rstd * ww.x + bb.x, y1 = (v[i].y - mean) * rstd * ww.y + bb.y;
+            const float y2 = (v[i].z - mean) * rstd * ww.z + bb.z, y3 = (v[i].w - mean) * rstd * ww.w + bb.w;
+            o[4 * c + 0] = (OutT)y0;
+            o[4 * c + 1] = (OutT)y1;
+            o[4 * c + 2] = (OutT)y2;
+            o[4 * c + 3] = (OutT)y3;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -383,26 +386,34 @@ __global__ void text_embed(const int *__restrict__ ids, const float *__restrict_
     }
 }
 
-// out[b, :] = x[b, :] @ Wp^T  (Wp [P, D] bf16), optional L2 normalisation; one workgroup per row
+// out[b, :] = x[b, :] @ Wp^T  (Wp [P, D] bf16), optional L2 normalisation; one workgroup per row,
+// one wave per output column (16-byte bf16 loads, wave reduction)
 __global__ __launch_bounds__(256) void project_rows(const float *__restrict__ x, const bf16 *__restrict__ Wp, int D,
                                                     int P, int normalize, float *__restrict__ out) {
     __shared__ float sx[1024];
     __shared__ float so[1024];
     __shared__ float red[4];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int c = t; c < D; c += 256) sx[c] = x[(int64_t)b * D + c];
     __syncthreads();
-    float ss = 0.f;
-    for (int p = t; p < P; p += 256) {
-        const bf16 *w = Wp + (int64_t)p * D;
+    for (int p = wave; p < P; p += 4) {
+        const bf16x8 *w8 = reinterpret_cast<const bf16x8 *>(Wp + (int64_t)p * D);
         float a = 0.f;
-        for (int c = 0; c < D; ++c) a = fmaf(sx[c], (float)w[c], a);
-        so[p] = a;
-        ss += a * a;
+        for (int c = lane; c < D / 8; c += 64) {
+            const bf16x8 wv = w8[c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(sx[8 * c + j], (float)wv[j], a);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) so[p] = a;
     }
+    __syncthreads();
+    float ss = 0.f;
+    for (int p = t; p < P; p += 256) ss += so[p] * so[p];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if ((t & 63) == 0) red[t >> 6] = ss;
+    if (lane == 0) red[wave] = ss;
     __syncthreads();
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
     const float inv = normalize ? 1.f / fmaxf(nrm, 1e-12f) : 1.f;  // F.normalize eps
@@ -558,17 +569,7 @@ ssw_status gemm(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, 
         set_error("clip gemm: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
         return SSW_ERR_UNSUPPORTED;
     }
-    static int grid_cache = 0;
-    if (grid_cache == 0) {
-        int dev = 0, nb = 0;
-        (void)hipGetDevice(&dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_bf16_nt<EPI>, 256, 0) != hipSuccess || nb < 1) nb = 1;
-        grid_cache = num_cus(dev) * nb;
-    }
-    const int n_tiles = (N / BN) * ((M + BM - 1) / BM);
-    int grid = grid_cache < n_tiles ? grid_cache : n_tiles;
-    grid = (grid + 7) / 8 * 8;  // whole XCD groups (surplus workgroups exit at once)
-    hipLaunchKernelGGL(gemm_bf16_nt<EPI>, dim3(grid), dim3(256), 0, s, A, W, bias, res, C, M, N, K);
+    hipLaunchKernelGGL(gemm_bf16_nt<EPI>, dim3(N / BN, (M + BM - 1) / BM), dim3(256), 0, s, A, W, bias, res, C, M, N, K);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
