@@ -264,6 +264,14 @@ ssw_status ssw_clip_embed_text(ssw_clip *clip, const int32_t *ids_host, int32_t 
                                int32_t normalize, float *out_host);
 ssw_status ssw_clip_sync(ssw_clip *clip);
 
+/* Kernel A/B harness for the towers' bf16 GEMM (C[M,N] = A[M,K] W[N,K]^T + epilogue `epi`, see
+ * csrc/gemm_bf16.hip): runs `variant` on seeded operands, reports ms per launch over `iters`
+ * launches and the max |difference| to variant 0.  Not part of the reference's interface. */
+ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
+                          float *out_ms, float *out_maxdiff);
+/* Selects the GEMM variant the towers use (0 register-staged, 1..3 LDS-DMA ring depth). */
+ssw_status ssw_tune_gemm(int32_t variant);
+
 #ifdef __cplusplus
 }
 #endif

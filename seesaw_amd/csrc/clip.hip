@@ -31,126 +31,9 @@ namespace {
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-__device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
-
-// ---------------------------------------------------------------------------------------
-// C[M,N] = A[M,K] * W[N,K]^T  (+ epilogue)
-// ---------------------------------------------------------------------------------------
 enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per staged row (144 B: breaks the 128-B bank period)
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
-                                                    const float *__restrict__ bias,
-                                                    const float *__restrict__ residual, void *__restrict__ Cout,
-                                                    int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * LDS_STRIDE];
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread (chunk c = t + 256 i:
-    // row c/8, 8 bf16 at column (c%8)*8); kept in registers across the MFMA block
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int srow = t >> 3, scol = (t & 7) * 8;  // chunk i adds 32 rows
-    const bf16 *a_ptr0 = A + (int64_t)min(m0 + srow, M - 1) * K + scol;
-    const bf16 *a_ptr1 = A + (int64_t)min(m0 + srow + 32, M - 1) * K + scol;
-    const bf16 *a_ptr2 = A + (int64_t)min(m0 + srow + 64, M - 1) * K + scol;
-    const bf16 *a_ptr3 = A + (int64_t)min(m0 + srow + 96, M - 1) * K + scol;
-    const bf16 *w_ptr = W + (int64_t)(n0 + srow) * K + scol;
-    const int64_t w_step = (int64_t)32 * K;
-    const int lds_off = srow * LDS_STRIDE + scol;
-#define SSW_LOAD_TILES(k0)                                                   \
-    ra0 = *reinterpret_cast<const uint4 *>(a_ptr0 + (k0));                   \
-    ra1 = *reinterpret_cast<const uint4 *>(a_ptr1 + (k0));                   \
-    ra2 = *reinterpret_cast<const uint4 *>(a_ptr2 + (k0));                   \
-    ra3 = *reinterpret_cast<const uint4 *>(a_ptr3 + (k0));                   \
-    rb0 = *reinterpret_cast<const uint4 *>(w_ptr + (k0));                    \
-    rb1 = *reinterpret_cast<const uint4 *>(w_ptr + w_step + (k0));           \
-    rb2 = *reinterpret_cast<const uint4 *>(w_ptr + 2 * w_step + (k0));       \
-    rb3 = *reinterpret_cast<const uint4 *>(w_ptr + 3 * w_step + (k0));
-#define SSW_STORE_TILES(buf)                                                                  \
-    *reinterpret_cast<uint4 *>(&sA[buf][lds_off]) = ra0;                                      \
-    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 32 * LDS_STRIDE]) = ra1;                    \
-    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 64 * LDS_STRIDE]) = ra2;                    \
-    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 96 * LDS_STRIDE]) = ra3;                    \
-    *reinterpret_cast<uint4 *>(&sB[buf][lds_off]) = rb0;                                      \
-    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 32 * LDS_STRIDE]) = rb1;                    \
-    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 64 * LDS_STRIDE]) = rb2;                    \
-    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 96 * LDS_STRIDE]) = rb3;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    SSW_LOAD_TILES(0)
-    SSW_STORE_TILES(0)
-    __syncthreads();
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {  // global loads fly while this tile is multiplied
-            const int k0 = (kt + 1) * BK;
-            SSW_LOAD_TILES(k0)
-        }
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][(wm * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
-                b[i] = *reinterpret_cast<const bf16x8 *>(&sB[buf][(wn * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            // the other buffer was last read one iteration ago, before the barrier below
-            if (buf == 0) {
-                SSW_STORE_TILES(1)
-            } else {
-                SSW_STORE_TILES(0)
-            }
-            __syncthreads();
-        }
-    }
-#undef SSW_LOAD_TILES
-#undef SSW_STORE_TILES
-
-    // epilogue: lane holds C[row = fq*4 + r][col = fr] of each 16x16 tile
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + fr;
-            const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                const int64_t o = (int64_t)row * N + col;
-                if (EPI == EPI_BF16_BIAS_GELU) v = v / (1.f + __expf(-1.702f * v));  // quick_gelu
-                if (EPI == EPI_F32_BIAS_RESIDUAL) v += residual[o];
-                if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU)
-                    reinterpret_cast<bf16 *>(Cout)[o] = to_bf16(v);
-                else
-                    reinterpret_cast<float *>(Cout)[o] = v;
-            }
-        }
-    }
-}
+__device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim (one wave per row), f32 in -> bf16 or f32 out.
@@ -565,13 +448,7 @@ ssw_status load_tower(ssw_clip *c, Tower &tw, const float *&cur, const float *en
 template <int EPI>
 ssw_status gemm(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                 int N, int K) {
-    if (N % BN != 0 || K % BK != 0 || M <= 0) {
-        set_error("clip gemm: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
-        return SSW_ERR_UNSUPPORTED;
-    }
-    hipLaunchKernelGGL(gemm_bf16_nt<EPI>, dim3(N / BN, (M + BM - 1) / BM), dim3(256), 0, s, A, W, bias, res, C, M, N, K);
-    SSW_HIP_TRY(hipGetLastError());
-    return SSW_OK;
+    return launch_gemm_bf16_nt(EPI, s, A, W, bias, res, C, M, N, K);
 }
 
 ssw_status reserve(ssw_clip *c, int64_t batch) {

@@ -1,0 +1,465 @@
+// bf16 GEMM for the CLIP towers:  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue), f32 accumulate.
+//
+// Both operands are K-contiguous ("NT" form: torch Linear keeps W as [out, in]), so the A and
+// the W fragment of v_mfma_f32_16x16x32_bf16 are the same 16-row x 32-k slice read row-wise.
+// Replaces the torch/cuBLAS linears inside transformers' CLIPModel that the reference calls
+// (seesaw/models/embeddings.py:42-76 -> CLIPVisionModel / CLIPTextModel layers).
+//
+// variant 1..3 (default 2): LDS-DMA pipeline.  A 128x128 tile per 256-thread block, BK = 64:
+//   * staging is global_load_lds_dwordx4 only (no VGPR round trip): one wave-instruction fills
+//     8 rows x 128 B of the LDS image, lane-linear, reading whole 128-B lines;
+//   * the image is XOR-swizzled through the SOURCE address (16-B chunk c of row r sits at chunk
+//     c ^ ((r >> 1) & 7)), the fragment ds_read_b128 applies the same XOR: every 16-lane read
+//     group of ds_read_b128 then touches 16 distinct 16-B slots of the 256-B bank row;
+//   * DEPTH-stage ring in one __shared__ array, one raw s_barrier per k-step, counted
+//     s_waitcnt vmcnt so DEPTH-2 stages stay in flight across the barrier (DEPTH >= 3);
+//   * the MFMA takes (W fragment, A fragment), so a lane owns 4 consecutive output COLUMNS of one
+//     row and the epilogue stores 8 B (bf16) / 16 B (f32) per lane with float4 bias / residual;
+//   * blocks that share an XCD (linear id % 8) walk whole row-tiles of A, so an A tile is pulled
+//     into one L2 only.
+// variant 0 is the first register-staged kernel, kept for A/B runs (ssw_debug_gemm).
+#include "ssw_common.h"
+
+namespace ssw {
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3 };
+
+__device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
+
+// ---------------------------------------------------------------------------------------
+// variant 0: register-staged double buffer (global -> VGPR -> padded LDS), one tile of lookahead
+// ---------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per staged row (144 B: breaks the 128-B bank period)
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
+                                                    const float *__restrict__ bias,
+                                                    const float *__restrict__ residual, void *__restrict__ Cout,
+                                                    int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * LDS_STRIDE];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread (chunk c = t + 256 i:
+    // row c/8, 8 bf16 at column (c%8)*8); kept in registers across the MFMA block
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int srow = t >> 3, scol = (t & 7) * 8;  // chunk i adds 32 rows
+    const bf16 *a_ptr0 = A + (int64_t)min(m0 + srow, M - 1) * K + scol;
+    const bf16 *a_ptr1 = A + (int64_t)min(m0 + srow + 32, M - 1) * K + scol;
+    const bf16 *a_ptr2 = A + (int64_t)min(m0 + srow + 64, M - 1) * K + scol;
+    const bf16 *a_ptr3 = A + (int64_t)min(m0 + srow + 96, M - 1) * K + scol;
+    const bf16 *w_ptr = W + (int64_t)(n0 + srow) * K + scol;
+    const int64_t w_step = (int64_t)32 * K;
+    const int lds_off = srow * LDS_STRIDE + scol;
+#define SSW_LOAD_TILES(k0)                                                   \
+    ra0 = *reinterpret_cast<const uint4 *>(a_ptr0 + (k0));                   \
+    ra1 = *reinterpret_cast<const uint4 *>(a_ptr1 + (k0));                   \
+    ra2 = *reinterpret_cast<const uint4 *>(a_ptr2 + (k0));                   \
+    ra3 = *reinterpret_cast<const uint4 *>(a_ptr3 + (k0));                   \
+    rb0 = *reinterpret_cast<const uint4 *>(w_ptr + (k0));                    \
+    rb1 = *reinterpret_cast<const uint4 *>(w_ptr + w_step + (k0));           \
+    rb2 = *reinterpret_cast<const uint4 *>(w_ptr + 2 * w_step + (k0));       \
+    rb3 = *reinterpret_cast<const uint4 *>(w_ptr + 3 * w_step + (k0));
+#define SSW_STORE_TILES(buf)                                                                  \
+    *reinterpret_cast<uint4 *>(&sA[buf][lds_off]) = ra0;                                      \
+    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 32 * LDS_STRIDE]) = ra1;                    \
+    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 64 * LDS_STRIDE]) = ra2;                    \
+    *reinterpret_cast<uint4 *>(&sA[buf][lds_off + 96 * LDS_STRIDE]) = ra3;                    \
+    *reinterpret_cast<uint4 *>(&sB[buf][lds_off]) = rb0;                                      \
+    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 32 * LDS_STRIDE]) = rb1;                    \
+    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 64 * LDS_STRIDE]) = rb2;                    \
+    *reinterpret_cast<uint4 *>(&sB[buf][lds_off + 96 * LDS_STRIDE]) = rb3;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    SSW_LOAD_TILES(0)
+    SSW_STORE_TILES(0)
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {  // global loads fly while this tile is multiplied
+            const int k0 = (kt + 1) * BK;
+            SSW_LOAD_TILES(k0)
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][(wm * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
+                b[i] = *reinterpret_cast<const bf16x8 *>(&sB[buf][(wn * 64 + i * 16 + fr) * LDS_STRIDE + ks * 32 + fq * 8]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            // the other buffer was last read one iteration ago, before the barrier below
+            if (buf == 0) {
+                SSW_STORE_TILES(1)
+            } else {
+                SSW_STORE_TILES(0)
+            }
+            __syncthreads();
+        }
+    }
+#undef SSW_LOAD_TILES
+#undef SSW_STORE_TILES
+
+    // epilogue: lane holds C[row = fq*4 + r][col = fr] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fr;
+            const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + fq * 4 + r;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                const int64_t o = (int64_t)row * N + col;
+                if (EPI == EPI_BF16_BIAS_GELU) v = v / (1.f + __expf(-1.702f * v));  // quick_gelu
+                if (EPI == EPI_F32_BIAS_RESIDUAL) v += residual[o];
+                if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU)
+                    reinterpret_cast<bf16 *>(Cout)[o] = to_bf16(v);
+                else
+                    reinterpret_cast<float *>(Cout)[o] = v;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// variants 1..3: LDS-DMA ring (DEPTH = 1 keeps one buffer and two barriers per k-step)
+// ---------------------------------------------------------------------------------------
+constexpr int G_STAGE = 32768;  // bytes per ring stage: A image 128 x 128 B, then W image
+constexpr int G_OPER = 16384;
+
+#define SSW_GLDS16(gptr, lptr)                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),        \
+                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+template <int EPI, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
+                                                 const float *__restrict__ bias,
+                                                 const float *__restrict__ residual, void *__restrict__ Cout, int M,
+                                                 int N, int K, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // XCD-aware tile order: ids b and b + 8 share an XCD; XCD x takes row-tiles x, x + 8, ...
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
+    if (mt >= m_tiles) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+
+    // staging: wave w fills pieces p = 4 w + i (rows 8 p .. 8 p + 7) of both images; lane l
+    // lands at row l / 8, chunk position l % 8 and therefore fetches chunk (l % 8) ^ swz(row)
+    const bf16 *a_src[4];
+    const bf16 *w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[i] = A + (int64_t)min(m0 + row, M - 1) * K + chunk * 8;
+        w_src[i] = W + (int64_t)(n0 + row) * K + chunk * 8;
+    }
+    unsigned char *const stage_dst = smem + wave * 4096;
+#define SSW_ISSUE(kt, buf)                                                      \
+    {                                                                           \
+        unsigned char *d = stage_dst + (buf) * G_STAGE;                         \
+        const int k0 = (kt) * BK;                                               \
+        SSW_GLDS16(a_src[0] + k0, d);                                           \
+        SSW_GLDS16(a_src[1] + k0, d + 1024);                                    \
+        SSW_GLDS16(a_src[2] + k0, d + 2048);                                    \
+        SSW_GLDS16(a_src[3] + k0, d + 3072);                                    \
+        SSW_GLDS16(w_src[0] + k0, d + G_OPER);                                  \
+        SSW_GLDS16(w_src[1] + k0, d + G_OPER + 1024);                           \
+        SSW_GLDS16(w_src[2] + k0, d + G_OPER + 2048);                           \
+        SSW_GLDS16(w_src[3] + k0, d + G_OPER + 3072);                           \
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte offset inside an image: row (16-row block + fr), chunk (4 ks + fq) ^ (fr >> 1)
+    const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+    const int a_frag = wm * 8192 + frag0, w_frag = G_OPER + wn * 8192 + frag0;
+#define SSW_COMPUTE(buf)                                                                              \
+    {                                                                                                 \
+        const unsigned char *sb = smem + (buf) * G_STAGE;                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+            bf16x8 a[4], b[4];                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                a[i] = *reinterpret_cast<const bf16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));     \
+                b[i] = *reinterpret_cast<const bf16x8 *>(sb + ((w_frag + i * 2048) ^ (ks * 64)));     \
+            }                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0); \
+        }                                                                                             \
+    }
+
+    const int nk = K / BK;
+    if constexpr (DEPTH == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            SSW_ISSUE(kt, 0)
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            SSW_COMPUTE(0)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (s < nk) SSW_ISSUE(s, s)
+        int buf = 0, nxt = DEPTH - 1;  // ring slots of stage kt and of stage kt + DEPTH - 1
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed once at most the DEPTH-2 younger stages are still in flight
+            if (kt + DEPTH - 2 < nk)
+                wait_vmcnt<8 * (DEPTH - 2)>();
+            else
+                wait_vmcnt<0>();
+            // behind this barrier every wave's part of stage kt is visible and nobody still
+            // reads slot nxt (it held stage kt - 1)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + DEPTH - 1 < nk) SSW_ISSUE(kt + DEPTH - 1, nxt)
+            SSW_COMPUTE(buf)
+            asm volatile("" ::: "memory");
+            buf = (buf + 1 == DEPTH) ? 0 : buf + 1;
+            nxt = (nxt + 1 == DEPTH) ? 0 : nxt + 1;
+        }
+    }
+#undef SSW_ISSUE
+#undef SSW_COMPUTE
+
+    // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + fr;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fq * 4;
+            const int64_t o = (int64_t)row * N + col;
+            f32x4 v = acc[i][j];
+            if (EPI != EPI_F32) v += *reinterpret_cast<const f32x4 *>(bias + col);
+            if (EPI == EPI_BF16_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));  // quick_gelu
+            }
+            if (EPI == EPI_F32_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4 *>(residual + o);
+            if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
+                bf16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
+                *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + o) = h;
+            } else {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
+            }
+        }
+    }
+}
+
+int g_gemm_variant = 2;
+
+template <int EPI, int DEPTH>
+ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
+                       int M, int N, int K) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEPTH * G_STAGE));
+        attr_set = true;
+    }
+    const int m_tiles = (M + BM - 1) / BM, n_tiles = N / BN;
+    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH>), dim3(grid), dim3(256), DEPTH * G_STAGE, s, A, W, bias, res, C, M, N, K,
+                       m_tiles, n_tiles);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+template <int EPI>
+ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
+                      int N, int K) {
+    switch (g_gemm_variant) {
+        case 0:
+            hipLaunchKernelGGL(gemm_bf16_nt<EPI>, dim3(N / BN, (M + BM - 1) / BM), dim3(256), 0, s, A, W, bias, res, C,
+                               M, N, K);
+            SSW_HIP_TRY(hipGetLastError());
+            return SSW_OK;
+        case 1: return launch_glds<EPI, 1>(s, A, W, bias, res, C, M, N, K);
+        case 3: return launch_glds<EPI, 3>(s, A, W, bias, res, C, M, N, K);
+        default: return launch_glds<EPI, 2>(s, A, W, bias, res, C, M, N, K);
+    }
+}
+
+}  // namespace
+
+void tune_gemm(int variant) { g_gemm_variant = variant; }
+
+ssw_status launch_gemm_bf16_nt(int epi, hipStream_t s, const void *A_, const void *W_, const float *bias,
+                               const float *res, void *C, int M, int N, int K) {
+    if (N % BN != 0 || K % BK != 0 || M <= 0) {
+        set_error("gemm_bf16_nt: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    const bf16 *A = static_cast<const bf16 *>(A_), *W = static_cast<const bf16 *>(W_);
+    switch (epi) {
+        case EPI_F32: return launch_epi<EPI_F32>(s, A, W, bias, res, C, M, N, K);
+        case EPI_BF16_BIAS: return launch_epi<EPI_BF16_BIAS>(s, A, W, bias, res, C, M, N, K);
+        case EPI_BF16_BIAS_GELU: return launch_epi<EPI_BF16_BIAS_GELU>(s, A, W, bias, res, C, M, N, K);
+        case EPI_F32_BIAS_RESIDUAL: return launch_epi<EPI_F32_BIAS_RESIDUAL>(s, A, W, bias, res, C, M, N, K);
+    }
+    set_error("gemm_bf16_nt: unknown epilogue %d", epi);
+    return SSW_ERR_INVALID;
+}
+
+}  // namespace ssw
+
+// ---------------------------------------------------------------------------------------
+// A/B harness (tools/perf_gemm.py): time one variant on seeded operands and compare its
+// output with variant 0 in the same process.
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ void k_debug_fill(ssw::bf16 *x, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        x[i] = (ssw::bf16)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
+    }
+}
+__global__ void k_debug_fill_f32(float *x, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + seed;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        x[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
+    }
+}
+template <typename T>
+__global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = fabsf((float)a[i] - (float)b[i]);
+        m = fmaxf(m, d == d ? d : 3.0e38f);
+    }
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
+}
+}  // namespace
+
+extern "C" int ssw_tune_gemm(int variant) {
+    if (variant < 0 || variant > 3) {
+        ssw::set_error("ssw_tune_gemm: variant %d out of range", variant);
+        return SSW_ERR_INVALID;
+    }
+    ssw::tune_gemm(variant);
+    return SSW_OK;
+}
+
+extern "C" int ssw_debug_gemm(int M, int N, int K, int epi, int variant, int iters, float *out_ms,
+                              float *out_maxdiff) {
+    using namespace ssw;
+    if (M <= 0 || iters <= 0 || epi < 0 || epi > 3) {
+        set_error("ssw_debug_gemm: bad arguments");
+        return SSW_ERR_INVALID;
+    }
+    const bool out_bf16 = (epi == 1 || epi == 2);
+    const size_t out_bytes = (size_t)M * N * (out_bf16 ? 2 : 4);
+    bf16 *A = nullptr, *W = nullptr;
+    float *bias = nullptr, *res = nullptr, *diff = nullptr;
+    void *c_ref = nullptr, *c_var = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SSW_OK;
+    auto cleanup = [&]() {
+        for (void *p : {(void *)A, (void *)W, (void *)bias, (void *)res, (void *)diff, c_ref, c_var}) (void)hipFree(p);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define SSW_DBG_TRY(expr)                                                      \
+    if (hipError_t _e = (expr); _e != hipSuccess) {                            \
+        set_error("%s failed: %s", #expr, hipGetErrorString(_e));              \
+        cleanup();                                                             \
+        return SSW_ERR_HIP;                                                    \
+    }
+    SSW_DBG_TRY(hipMalloc(&A, (size_t)M * K * 2));
+    SSW_DBG_TRY(hipMalloc(&W, (size_t)N * K * 2));
+    SSW_DBG_TRY(hipMalloc(&bias, (size_t)N * 4));
+    SSW_DBG_TRY(hipMalloc(&res, (size_t)M * N * 4));
+    SSW_DBG_TRY(hipMalloc(&diff, 4));
+    SSW_DBG_TRY(hipMalloc(&c_ref, out_bytes));
+    SSW_DBG_TRY(hipMalloc(&c_var, out_bytes));
+    hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, A, (int64_t)M * K, 0x1234u, 1.0f);
+    hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, W, (int64_t)N * K, 0x9876u, 0.05f);
+    hipLaunchKernelGGL(k_debug_fill_f32, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 0x4242u, 0.5f);
+    hipLaunchKernelGGL(k_debug_fill_f32, dim3(2048), dim3(256), 0, 0, res, (int64_t)M * N, 0x7777u, 1.0f);
+    SSW_DBG_TRY(hipMemsetAsync(diff, 0, 4, 0));
+    SSW_DBG_TRY(hipEventCreate(&e0));
+    SSW_DBG_TRY(hipEventCreate(&e1));
+    const int keep = g_gemm_variant;
+    tune_gemm(0);
+    rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_ref, M, N, K);
+    tune_gemm(variant);
+    if (rc == SSW_OK) rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_var, M, N, K);  // warm-up + checked run
+    if (rc == SSW_OK) {
+        if (out_bf16)
+            hipLaunchKernelGGL(k_debug_maxdiff<bf16>, dim3(1024), dim3(256), 0, 0, (const bf16 *)c_ref,
+                               (const bf16 *)c_var, (int64_t)M * N, diff);
+        else
+            hipLaunchKernelGGL(k_debug_maxdiff<float>, dim3(1024), dim3(256), 0, 0, (const float *)c_ref,
+                               (const float *)c_var, (int64_t)M * N, diff);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < iters && rc == SSW_OK; ++i) rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_var, M, N, K);
+        (void)hipEventRecord(e1, 0);
+    }
+    tune_gemm(keep);
+    if (rc != SSW_OK) {
+        cleanup();
+        return rc;
+    }
+    SSW_DBG_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SSW_DBG_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (out_ms) *out_ms = ms / iters;
+    if (out_maxdiff) SSW_DBG_TRY(hipMemcpy(out_maxdiff, diff, 4, hipMemcpyDeviceToHost));
+#undef SSW_DBG_TRY
+    cleanup();
+    return SSW_OK;
+}

@@ -93,6 +93,11 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
 ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *rows_dev, int64_t n,
                              int32_t dim, float *out, hipStream_t stream);
 void tune_scan(int variant, int blocks_per_cu);
+// gemm_bf16.hip: C[M,N] = A[M,K] W[N,K]^T (bf16 in, f32 accumulate) with fused epilogue
+// epi: 0 f32 | 1 +bias -> bf16 | 2 +bias, quick-GELU -> bf16 | 3 +bias +residual -> f32
+ssw_status launch_gemm_bf16_nt(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
+                               const float *residual, void *C, int M, int N, int K);
+void tune_gemm(int variant);
 // rng.hip: synthetic unit-norm rows.
 ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
                               hipStream_t stream);
