@@ -90,137 +90,138 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// attention: one WAVE per (batch, head); S <= 16*NT tokens, head_dim 64.
-//   scores  = Q K^T      16x16x32 MFMA, Q / K fragments straight from global (both are
-//                        K-contiguous rows of the fused qkv buffer, i.e. the same "NT" operand
-//                        form as the GEMM) -> the whole S x S score block lives in accumulators
-//   softmax   in registers (f32): row max / sum by xor-shuffles over the 16 lanes of a row
-//   out     = P V        P goes through a 16-row LDS tile (C layout -> A fragments), V is
-//                        transposed once per head into LDS so its fragments are key-contiguous
+// attention: one WORKGROUP per (batch, head), one wave per 16-query tile; S <= 16*NT tokens,
+// head_dim 64.  The MFMA operands are ordered so that a lane owns ONE query:
+//   scores^T = K Q^T     16x16x32 MFMA, K / Q fragments straight from global (K-contiguous rows
+//                        of the fused qkv buffer, the GEMM's "NT" operand form); the lane holds
+//                        keys 16 j + 4 fq + r of query fr -> row max / sum need two shuffles
+//   softmax   in registers (f32), normalised before the bf16 rounding
+//   out^T   = V^T P^T    P goes through a per-wave 16-row LDS tile (8-byte writes), V is
+//                        transposed once per head into LDS by the whole workgroup; the lane ends
+//                        with 4 consecutive head-dim values of its query -> 8-byte stores
 // qkv [R, 3D] bf16 (q | k | v), out [R, D] bf16
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 80;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 template <int NT>
-__global__ __launch_bounds__(256) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
-                                                      int D, int H, float scale, int causal, int n_heads) {
+__global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
+                                                          int D, int H, float scale, int causal) {
     constexpr int KP = ((NT * 16 + 31) / 32) * 32;  // keys padded to the MFMA K step
     constexpr int LDP = KP + 8;                     // LDS row stride (bf16)
-    __shared__ __attribute__((aligned(16))) bf16 sVt[4][64 * LDP];
-    __shared__ __attribute__((aligned(16))) bf16 sP[4][16 * LDP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hid_raw = blockIdx.x * 4 + wave;
-    const bool live = hid_raw < n_heads;
-    const int hid = live ? hid_raw : n_heads - 1;
-    const int b = hid / H, h = hid % H;
+    constexpr int VCH = (KP * 8 + NT * 64 - 1) / (NT * 64);  // 16-byte V chunks per thread
+    __shared__ __attribute__((aligned(16))) bf16 sVt[64 * LDP];
+    __shared__ __attribute__((aligned(16))) bf16 sP[NT][16 * LDP];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16 *base = qkv + (int64_t)b * S * 3 * D + h * 64;
-    bf16 *vt = sVt[wave], *pt = sP[wave];
+    bf16 *pt = sP[wave];
 
-    // V^T into LDS: vt[d][key]; keys >= S are zero
-    for (int c = lane; c < KP * 8; c += 64) {
-        const int key = c >> 3, d0 = (c & 7) * 8;
-        bf16x8 v;
-        if (key < S) {
-            v = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + 2 * D + d0);
-        } else {
+    // V rows of this head (whole workgroup, 128-byte rows); keys >= S are zero
+    bf16x8 vreg[VCH];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
-        }
+    for (int c = 0; c < VCH; ++c) {
+        const int ch = t + c * NT * 64, key = ch >> 3, d0 = (ch & 7) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vt[(d0 + j) * LDP + key] = v[j];
+        for (int j = 0; j < 8; ++j) vreg[c][j] = (bf16)0.f;
+        if (ch < KP * 8 && key < S) vreg[c] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + 2 * D + d0);
     }
-    // K fragments for every key tile (rows clamped: masked below)
-    bf16x8 kf[NT][2];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int key = min(j * 16 + fr, S - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            kf[j][ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + D + ks * 32 + fq * 8);
-    }
-    __syncthreads();
-
-    for (int i = 0; i < NT; ++i) {
-        if (i * 16 >= S) break;  // wave-uniform
-        const int qrow_f = min(i * 16 + fr, S - 1);
+    const int i = wave;                 // query tile
+    const bool tile_live = i * 16 < S;  // wave-uniform
+    f32x4 sc[NT];
+    if (tile_live) {
+        const int qrow = min(i * 16 + fr, S - 1);
         bf16x8 qf[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qrow_f * 3 * D + ks * 32 + fq * 8);
-        f32x4 sc[NT];
+            qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qrow * 3 * D + ks * 32 + fq * 8);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            const int key = min(j * 16 + fr, S - 1);  // clamped rows are masked below
             sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf[j][ks], sc[j], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + D + ks * 32 + fq * 8);
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[j], 0, 0, 0);
+            }
         }
-        // this lane holds scores[query = 16 i + 4 fq + r][key = 16 j + fr]
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        // this lane holds scores[query = 16 i + fr][key = 16 j + 4 fq + r]
+        const int q = i * 16 + fr;
+        float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int key = j * 16 + fr;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int q = i * 16 + fq * 4 + r;
+                const int key = j * 16 + fq * 4 + r;
                 float v = sc[j][r] * scale;
                 if (key >= S || (causal && key > q)) v = -INFINITY;
                 sc[j][r] = v;
-                mx[r] = fmaxf(mx[r], v);
+                mx = fmaxf(mx, v);
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(sc[j][r] - mx[r]);  // key 0 is never masked, so mx is finite
+                const float e = __expf(sc[j][r] - mx);  // key 0 is never masked, so mx is finite
                 sc[j][r] = e;
-                sum[r] += e;
+                sum += e;
             }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        // P (bf16) -> this wave's LDS tile [16 queries][KP keys]
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < NT; ++j) {
+            bf16x4 pv;
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) sum[r] += __shfl_xor(sum[r], off, 64);
-        // P (unnormalised, bf16) -> LDS tile [16 queries][KP keys]
-        __syncthreads();  // the previous iteration's reads of pt are done
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pt[(fq * 4 + r) * LDP + j * 16 + fr] = to_bf16(sc[j][r]);
+            for (int r = 0; r < 4; ++r) pv[r] = to_bf16(sc[j][r] * inv);
+            *reinterpret_cast<bf16x4 *>(&pt[fr * LDP + j * 16 + fq * 4]) = pv;
+        }
         if (KP > NT * 16) {
+            bf16x4 z;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pt[(fq * 4 + r) * LDP + NT * 16 + fr] = (bf16)0.f;
+            for (int r = 0; r < 4; ++r) z[r] = (bf16)0.f;
+            *reinterpret_cast<bf16x4 *>(&pt[fr * LDP + NT * 16 + fq * 4]) = z;
         }
-        __syncthreads();
-        // out tile = P V
-        f32x4 o[4];
+    }
+    // V^T into LDS: sVt[d][key]
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < VCH; ++c) {
+        const int ch = t + c * NT * 64, key = ch >> 3, d0 = (ch & 7) * 8;
+        if (ch < KP * 8) {
 #pragma unroll
-        for (int ks = 0; ks < KP / 32; ++ks) {
-            const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[fr * LDP + ks * 32 + fq * 8]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(&vt[(dt * 16 + fr) * LDP + ks * 32 + fq * 8]);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[dt], 0, 0, 0);
-            }
+            for (int j = 0; j < 8; ++j) sVt[(d0 + j) * LDP + key] = vreg[c][j];
         }
-        if (live) {
+    }
+    __syncthreads();
+    if (!tile_live) return;
+    // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
+    f32x4 o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = i * 16 + fq * 4 + r;
-                if (q < S) {
-                    const float inv = 1.f / sum[r];
-                    bf16 *orow = out + ((int64_t)b * S + q) * D + h * 64;
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) orow[dt * 16 + fr] = to_bf16(o[dt][r] * inv);
-                }
-            }
+    for (int ks = 0; ks < KP / 32; ++ks) {
+        const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[fr * LDP + ks * 32 + fq * 8]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(&sVt[(dt * 16 + fr) * LDP + ks * 32 + fq * 8]);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);
+        }
+    }
+    const int q = i * 16 + fr;
+    if (q < S) {
+        bf16 *orow = out + ((int64_t)b * S + q) * D + h * 64 + fq * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = to_bf16(o[dt][r]);
+            *reinterpret_cast<bf16x4 *>(orow + dt * 16) = ov;
         }
     }
 }
@@ -232,16 +233,21 @@ __global__ __launch_bounds__(256) void attention_mfma(const bf16 *__restrict__ q
 __global__ void im2col_patches(const float *__restrict__ px, bf16 *__restrict__ out, int B, int img, int patch) {
     const int g = img / patch;  // 7
     const int pp = patch * patch;
-    const int cols = 3 * pp;
-    const int64_t total = (int64_t)B * g * g * cols;
+    const int cols8 = 3 * pp / 8;  // 8 consecutive pixels of one patch row per thread (patch % 8 == 0)
+    const int64_t total = (int64_t)B * g * g * cols8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % cols);
-        const int64_t r = i / cols;
+        const int col = (int)(i % cols8) * 8;
+        const int64_t r = i / cols8;
         const int p = (int)(r % (g * g));
         const int b = (int)(r / (g * g));
         const int c = col / pp, py = (col % pp) / patch, pxx = col % patch;
         const int y = (p / g) * patch + py, x = (p % g) * patch + pxx;
-        out[i] = to_bf16(px[(((int64_t)b * 3 + c) * img + y) * img + x]);
+        const float4 *src = reinterpret_cast<const float4 *>(px + (((int64_t)b * 3 + c) * img + y) * img + x);
+        const float4 v0 = src[0], v1 = src[1];
+        bf16x8 o;
+        o[0] = to_bf16(v0.x); o[1] = to_bf16(v0.y); o[2] = to_bf16(v0.z); o[3] = to_bf16(v0.w);
+        o[4] = to_bf16(v1.x); o[5] = to_bf16(v1.y); o[6] = to_bf16(v1.z); o[7] = to_bf16(v1.w);
+        *reinterpret_cast<bf16x8 *>(out + i * 8) = o;
     }
 }
 
@@ -301,6 +307,20 @@ __global__ __launch_bounds__(256) void project_rows(const float *__restrict__ x,
     const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
     const float inv = normalize ? 1.f / fmaxf(nrm, 1e-12f) : 1.f;  // F.normalize eps
     for (int p = t; p < P; p += 256) out[(int64_t)b * P + p] = so[p] * inv;
+}
+
+// in-place L2 normalisation of [B, P] rows (F.normalize, eps 1e-12), one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows(float *__restrict__ x, int B, int P) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    float *row = x + (int64_t)r * P;
+    float ss = 0.f;
+    for (int c = lane; c < P; c += 64) ss += row[c] * row[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane; c < P; c += 64) row[c] *= inv;
 }
 
 __global__ void f32_to_bf16(const float *__restrict__ in, bf16 *__restrict__ out, int64_t n) {
@@ -494,16 +514,35 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         const int n_heads = B * tw.H;
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
         if (S <= 64)
-            hipLaunchKernelGGL(attention_mfma<4>, dim3((n_heads + 3) / 4), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H,
-                               att_scale, causal, n_heads);
+            hipLaunchKernelGGL(attention_mfma<4>, dim3(n_heads), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
+                               causal);
         else
-            hipLaunchKernelGGL(attention_mfma<5>, dim3((n_heads + 3) / 4), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H,
-                               att_scale, causal, n_heads);
+            hipLaunchKernelGGL(attention_mfma<5>, dim3(n_heads), dim3(320), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
+                               causal);
         SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->att, ly.wo, ly.bo, h, h2, R, D, D));
         hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h2, (const int *)nullptr, R, D,
                            ly.ln2w, ly.ln2b, eps, c->xn);
         SSW_TRY(gemm<EPI_BF16_BIAS_GELU>(s, c->xn, ly.w1, ly.b1, nullptr, c->h1, R, M, D));
         SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->h1, ly.w2, ly.b2, h2, h, R, D, M));
+    }
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+// pooled rows -> final LayerNorm -> projection (+ optional L2 normalisation).  The projection is a
+// [B, D] x [P, D]^T GEMM like every other linear; only odd shapes take the wave-per-column kernel.
+ssw_status pool_and_project(ssw_clip *c, const Tower &tw, int B, int D, int normalize, float *out_dev) {
+    hipStream_t s = c->stream;
+    const Header &h = c->hdr;
+    if (h.proj % 128 == 0 && D % 64 == 0) {
+        hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((B + 3) / 4), dim3(256), 0, s, c->hidden, c->rows, B, D,
+                           tw.lnf_w, tw.lnf_b, h.ln_eps, c->xn);
+        SSW_TRY(gemm<EPI_F32>(s, c->xn, tw.proj, nullptr, nullptr, out_dev, B, h.proj, D));
+        if (normalize) hipLaunchKernelGGL(l2norm_rows, dim3((B + 3) / 4), dim3(256), 0, s, out_dev, B, h.proj);
+    } else {
+        hipLaunchKernelGGL(layernorm_rows<float>, dim3((B + 3) / 4), dim3(256), 0, s, c->hidden, c->rows, B, D,
+                           tw.lnf_w, tw.lnf_b, h.ln_eps, c->pooled);
+        hipLaunchKernelGGL(project_rows, dim3(B), dim3(256), 0, s, c->pooled, tw.proj, D, h.proj, normalize, out_dev);
     }
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -521,11 +560,7 @@ ssw_status image_forward(ssw_clip *c, const float *pixels_dev, int B, int normal
                        B * T, D, c->pre_w, c->pre_b, h.ln_eps, c->hidden);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
     hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
-    hipLaunchKernelGGL(layernorm_rows<float>, dim3((B + 3) / 4), dim3(256), 0, s, c->hidden, c->rows, B, D,
-                       c->vis.lnf_w, c->vis.lnf_b, h.ln_eps, c->pooled);
-    hipLaunchKernelGGL(project_rows, dim3(B), dim3(256), 0, s, c->pooled, c->vis.proj, D, h.proj, normalize, out_dev);
-    SSW_HIP_TRY(hipGetLastError());
-    return SSW_OK;
+    return pool_and_project(c, c->vis, B, D, normalize, out_dev);
 }
 
 ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int normalize, float *out_dev) {
@@ -535,11 +570,7 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
     hipLaunchKernelGGL(text_embed, dim3(1024), dim3(256), 0, s, ids_dev, c->tok, c->tpos, c->hidden, B, L, D);
     SSW_TRY(run_tower(c, c->txt, B, L, 1));
     hipLaunchKernelGGL(eos_rows, dim3((B + 255) / 256), dim3(256), 0, s, ids_dev, B, L, h.eos, c->rows);
-    hipLaunchKernelGGL(layernorm_rows<float>, dim3((B + 3) / 4), dim3(256), 0, s, c->hidden, c->rows, B, D,
-                       c->txt.lnf_w, c->txt.lnf_b, h.ln_eps, c->pooled);
-    hipLaunchKernelGGL(project_rows, dim3(B), dim3(256), 0, s, c->pooled, c->txt.proj, D, h.proj, normalize, out_dev);
-    SSW_HIP_TRY(hipGetLastError());
-    return SSW_OK;
+    return pool_and_project(c, c->txt, B, D, normalize, out_dev);
 }
 
 }  // namespace

@@ -151,25 +151,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
 // ---------------------------------------------------------------------------------------
 // variants 1..3: LDS-DMA ring (DEPTH = 1 keeps one buffer and two barriers per k-step)
 // ---------------------------------------------------------------------------------------
-constexpr int G_STAGE = 32768;  // bytes per ring stage: A image 128 x 128 B, then W image
-constexpr int G_OPER = 16384;
+constexpr int G_WIMG = 16384;  // W image: 128 rows x 128 B
 
-#define SSW_GLDS16(gptr, lptr)                                                                       \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),        \
-                                     (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the LDS bytes
+// [lds_dst, lds_dst + 1024) in lane order (lds_dst is wave-uniform).  Issued from inline asm so that
+// the compiler's wait-count bookkeeping is not disturbed: for the builtin form it degrades every
+// later s_waitcnt lgkmcnt / vmcnt to (0), which serialises fragment reads and MFMAs.  The vmcnt
+// accounting for these loads is done by hand (wait_vmcnt below).
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+#define SSW_GLDS16(gptr, lptr) glds16((gptr), (lptr))
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <int EPI, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
-                                                 const float *__restrict__ bias,
-                                                 const float *__restrict__ residual, void *__restrict__ Cout, int M,
-                                                 int N, int K, int m_tiles, int n_tiles) {
+// TM rows x 128 columns per block, TM / 64 x 2 waves of 64 x 64 each (TM = 128: 4 waves, 256: 8)
+template <int EPI, int DEPTH, int TM, bool PIPE>
+__global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
+                                                    const float *__restrict__ bias,
+                                                    const float *__restrict__ residual, void *__restrict__ Cout,
+                                                    int M, int N, int K, int m_tiles, int n_tiles) {
+    constexpr int NW = TM / 32;            // waves
+    constexpr int AIMG = TM * 128;         // A image bytes per stage
+    constexpr int STAGE = AIMG + G_WIMG;   // ring stage
+    constexpr int WP = 16 / NW;            // W pieces per wave (A pieces per wave: 4)
+    constexpr int LOADS = 4 + WP;          // LDS-DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -179,33 +197,35 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
     const int xcd = bid & 7, idx = bid >> 3;
     const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
     if (mt >= m_tiles) return;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, 64 x 64 each
+    const int m0 = mt * TM, n0 = nt * BN;
+    const int wm = wave >> 1, wn = wave & 1;
 
-    // staging: wave w fills pieces p = 4 w + i (rows 8 p .. 8 p + 7) of both images; lane l
-    // lands at row l / 8, chunk position l % 8 and therefore fetches chunk (l % 8) ^ swz(row)
+    // staging: a piece is 8 rows x 128 B (one wave-instruction); lane l lands at row l / 8, chunk
+    // position l % 8 and therefore fetches chunk (l % 8) ^ swz(row)
     const bf16 *a_src[4];
-    const bf16 *w_src[4];
+    const bf16 *w_src[WP];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         a_src[i] = A + (int64_t)min(m0 + row, M - 1) * K + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = (wave * WP + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         w_src[i] = W + (int64_t)(n0 + row) * K + chunk * 8;
     }
-    unsigned char *const stage_dst = smem + wave * 4096;
-#define SSW_ISSUE(kt, buf)                                                      \
-    {                                                                           \
-        unsigned char *d = stage_dst + (buf) * G_STAGE;                         \
-        const int k0 = (kt) * BK;                                               \
-        SSW_GLDS16(a_src[0] + k0, d);                                           \
-        SSW_GLDS16(a_src[1] + k0, d + 1024);                                    \
-        SSW_GLDS16(a_src[2] + k0, d + 2048);                                    \
-        SSW_GLDS16(a_src[3] + k0, d + 3072);                                    \
-        SSW_GLDS16(w_src[0] + k0, d + G_OPER);                                  \
-        SSW_GLDS16(w_src[1] + k0, d + G_OPER + 1024);                           \
-        SSW_GLDS16(w_src[2] + k0, d + G_OPER + 2048);                           \
-        SSW_GLDS16(w_src[3] + k0, d + G_OPER + 3072);                           \
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
+    const unsigned a_dst = lds0 + wave * 4096;
+    const unsigned w_dst = lds0 + AIMG + wave * (WP * 1024);
+#define SSW_ISSUE(kt, buf)                                                                 \
+    {                                                                                      \
+        const int k0 = (kt) * BK;                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
+            SSW_GLDS16(a_src[i] + k0, a_dst + (buf) * STAGE + i * 1024);                   \
+        _Pragma("unroll") for (int i = 0; i < WP; ++i)                                     \
+            SSW_GLDS16(w_src[i] + k0, w_dst + (buf) * STAGE + i * 1024);                   \
     }
 
     f32x4 acc[4][4];
@@ -217,10 +237,10 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
     const int fr = lane & 15, fq = lane >> 4;
     // fragment byte offset inside an image: row (16-row block + fr), chunk (4 ks + fq) ^ (fr >> 1)
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
-    const int a_frag = wm * 8192 + frag0, w_frag = G_OPER + wn * 8192 + frag0;
+    const int a_frag = wm * 8192 + frag0, w_frag = AIMG + wn * 8192 + frag0;
 #define SSW_COMPUTE(buf)                                                                              \
     {                                                                                                 \
-        const unsigned char *sb = smem + (buf) * G_STAGE;                                             \
+        const unsigned char *sb = smem + (buf) * STAGE;                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
             bf16x8 a[4], b[4];                                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
@@ -233,8 +253,70 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
         }                                                                                             \
     }
 
+#define SSW_READ_FRAGS(buf, ks, a, b)                                                                 \
+    {                                                                                                 \
+        const unsigned char *sb = smem + (buf) * STAGE;                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            a[i] = *reinterpret_cast<const bf16x8 *>(sb + ((a_frag + i * 2048) ^ ((ks) * 64)));       \
+            b[i] = *reinterpret_cast<const bf16x8 *>(sb + ((w_frag + i * 2048) ^ ((ks) * 64)));       \
+        }                                                                                             \
+    }
+#define SSW_MFMA_BLOCK(a, b)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+
+    // Have every kernel argument in registers before the loop: a scalar load still pending at loop
+    // entry makes the compiler treat the LGKM counter as unordered and turn each counted wait for
+    // fragment reads into lgkmcnt(0).
+    asm volatile("" ::"s"(bias), "s"(residual), "s"(Cout), "s"(N));
     const int nk = K / BK;
-    if constexpr (DEPTH == 1) {
+    if constexpr (PIPE) {
+        // Software-pipelined form (DEPTH >= 2): the fragments of the next 32-deep half step are
+        // read into a second register set while the current half step multiplies, and the
+        // barrier sits between the two MFMA blocks, so LDS latency never faces an idle MFMA pipe.
+        static_assert(DEPTH >= 2, "pipelined loop needs a ring");
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s)
+            if (s < nk) SSW_ISSUE(s, s)
+        if (DEPTH - 1 < nk)
+            wait_vmcnt<LOADS * (DEPTH - 1)>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        SSW_READ_FRAGS(0, 0, a0, b0)
+        int buf = 0;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const int nbuf = (buf + 1 == DEPTH) ? 0 : buf + 1;
+            SSW_READ_FRAGS(buf, 1, a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            SSW_MFMA_BLOCK(a0, b0)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // stage kt+1 must have landed; stages kt+2 .. kt+DEPTH-1 may stay in flight
+            if (kt + DEPTH - 1 < nk)
+                wait_vmcnt<LOADS * (DEPTH - 2)>();
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): my reads of slot buf are done
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + DEPTH < nk) SSW_ISSUE(kt + DEPTH, buf)
+            SSW_READ_FRAGS(nbuf, 0, a0, b0)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            SSW_MFMA_BLOCK(a1, b1)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nbuf;
+        }
+        SSW_READ_FRAGS(buf, 1, a1, b1)
+        SSW_MFMA_BLOCK(a0, b0)
+        SSW_MFMA_BLOCK(a1, b1)
+    } else if constexpr (DEPTH == 1) {
         for (int kt = 0; kt < nk; ++kt) {
             SSW_ISSUE(kt, 0)
             wait_vmcnt<0>();
@@ -252,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed once at most the DEPTH-2 younger stages are still in flight
             if (kt + DEPTH - 2 < nk)
-                wait_vmcnt<8 * (DEPTH - 2)>();
+                wait_vmcnt<LOADS * (DEPTH - 2)>();
             else
                 wait_vmcnt<0>();
             // behind this barrier every wave's part of stage kt is visible and nobody still
@@ -268,6 +350,8 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
     }
 #undef SSW_ISSUE
 #undef SSW_COMPUTE
+#undef SSW_READ_FRAGS
+#undef SSW_MFMA_BLOCK
 
     // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
 #pragma unroll
@@ -282,7 +366,8 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
             if (EPI != EPI_F32) v += *reinterpret_cast<const f32x4 *>(bias + col);
             if (EPI == EPI_BF16_BIAS_GELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-1.702f * v[r]));  // quick_gelu
+                for (int r = 0; r < 4; ++r)  // quick_gelu: x * sigmoid(1.702 x), v_exp + v_rcp
+                    v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
             }
             if (EPI == EPI_F32_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4 *>(residual + o);
             if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
@@ -299,18 +384,19 @@ __global__ __launch_bounds__(256) void gemm_glds(const bf16 *__restrict__ A, con
 
 int g_gemm_variant = 2;
 
-template <int EPI, int DEPTH>
+template <int EPI, int DEPTH, int TM, bool PIPE = false>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
                        int M, int N, int K) {
     static bool attr_set = false;
+    constexpr int lds = DEPTH * (TM * 128 + G_WIMG);
     if (!attr_set) {
-        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, DEPTH * G_STAGE));
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    const int m_tiles = (M + BM - 1) / BM, n_tiles = N / BN;
+    const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH>), dim3(grid), dim3(256), DEPTH * G_STAGE, s, A, W, bias, res, C, M, N, K,
+    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
                        m_tiles, n_tiles);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -325,9 +411,14 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
                                M, N, K);
             SSW_HIP_TRY(hipGetLastError());
             return SSW_OK;
-        case 1: return launch_glds<EPI, 1>(s, A, W, bias, res, C, M, N, K);
-        case 3: return launch_glds<EPI, 3>(s, A, W, bias, res, C, M, N, K);
-        default: return launch_glds<EPI, 2>(s, A, W, bias, res, C, M, N, K);
+        case 1: return launch_glds<EPI, 1, 128>(s, A, W, bias, res, C, M, N, K);
+        case 3: return launch_glds<EPI, 3, 128>(s, A, W, bias, res, C, M, N, K);
+        case 4: return launch_glds<EPI, 2, 256>(s, A, W, bias, res, C, M, N, K);
+        case 5: return launch_glds<EPI, 3, 256>(s, A, W, bias, res, C, M, N, K);
+        case 6: return launch_glds<EPI, 2, 128, true>(s, A, W, bias, res, C, M, N, K);
+        case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
+        case 8: return launch_glds<EPI, 3, 256, true>(s, A, W, bias, res, C, M, N, K);
+        default: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
     }
 }
 
@@ -386,7 +477,7 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant < 0 || variant > 3) {
+    if (variant < 0 || variant > 8) {
         ssw::set_error("ssw_tune_gemm: variant %d out of range", variant);
         return SSW_ERR_INVALID;
     }

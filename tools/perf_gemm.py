@@ -1,5 +1,7 @@
 """A/B the tower GEMM variants in one process (GPU box): ms, TFLOP/s and max |diff| to variant 0."""
 import ctypes
+
+import torch  # noqa: F401  (first: its bundled HIP runtime must be the one the process uses)
 import sys
 
 from seesaw_amd import _lib
@@ -18,7 +20,7 @@ SHAPES = [  # (M, N, K, epi, what)
 
 def main():
     lib = _lib.load()
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3]
+    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0, 1, 2, 3]
     iters = 20
     for M, N, K, epi, what in SHAPES:
         line = f"{what:10s} M={M:6d} N={N:5d} K={K:5d} epi={epi}"
@@ -34,3 +36,27 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def library_baseline():
+    """hipBLASLt through torch (plain C = A W^T, bf16 out, no epilogue) on the same shapes."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    for M, N, K, epi, what in SHAPES:
+        a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.05
+        for _ in range(3):
+            torch.nn.functional.linear(a, w)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            torch.nn.functional.linear(a, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{what:10s} hipBLASLt(torch) {ms*1e3:7.1f}us {2.0*M*N*K/(ms*1e-3)/1e12:6.0f}TF", flush=True)
+
+
+if __name__ == "__main__" and "--lib" in sys.argv:
+    library_baseline()
