@@ -178,6 +178,11 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
                              double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
                              int32_t *out_sweeps, int32_t *out_converged);
 
+/* K6: out [dim, dim] f64 = X' L X for the resident matrix X of `index` and the CSR matrix L held
+ * by `laplacian` (an ssw_lp created from the graph Laplacian, already divided by its trace):
+ * replaces `X_vectors.T @ (L @ X_vectors)`, seesaw/loops/graph_based.py:45-49. */
+ssw_status ssw_xlx(ssw_index *index, ssw_lp *laplacian, double *out_host);
+
 /* ------------------------------------------------------------------------- */
 /* Online relevance-feedback update: fused loss+gradient on the GPU, L-BFGS    */
 /* (strong Wolfe) driver on the host.                                          */

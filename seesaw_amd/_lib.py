@@ -74,6 +74,7 @@ _SIGNATURES = {
     "ssw_fb_set_data_from_device": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i32]),
     "ssw_fb_set_targets": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_query": (c_i32, [c_void_p, c_void_p]),
+    "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),
     "ssw_fb_get_mean": (c_i32, [c_void_p, c_void_p]),
     "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -125,6 +126,14 @@ def load(path: str = LIB_PATH):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C seesaw_amd/csrc` (hipcc --offload-arch=gfx950). seesaw_amd has no CPU fallback.")
+    # One HIP runtime per process: torch ships its own libamdhip64 and whichever copy is mapped
+    # first owns the GPU ("No HIP GPUs are available" from the other).  Loading torch first makes
+    # the dynamic linker bind this library's libamdhip64 dependency to torch's copy, so the
+    # C-ABI, torch tensors and torch.distributed (RCCL) share one runtime in either import order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -123,6 +123,83 @@ __global__ void k_lp_clear_labels(unsigned char *is_label, const int64_t *ids, i
     if (i < n_labels) is_label[ids[i]] = 0;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// K6: X' L X  (graph_based.py:45-49 -- the database-alignment matrix of MultiReg)
+//   Y = L X          one wave per row, f64, row by row in storage order with separate
+//                    multiply and add: scipy's csr_matvecs order (L f64, X upcast from f32)
+//   P_z = X_z' Y_z   v_mfma_f64_16x16x4_f64 over row chunk z; a 256-thread workgroup owns a
+//                    128 x 128 block of the D x D result (wave: 64 x 64 = 16 accumulators)
+//   out = sum_z P_z  in ascending z (deterministic)
+// Bound: MFMA f64 (2 N D^2 flop) for the product, L2 gathers (nnz x D x 4 B) for Y.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_xlx_spmm(const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices,
+                                                  const double *__restrict__ data, const float *__restrict__ X,
+                                                  int64_t n, int D, double *__restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t lo = indptr[r], hi = indptr[r + 1];
+    for (int c = lane; c < D; c += 64) {
+        double acc = 0.0;
+        for (int64_t jj = lo; jj < hi; ++jj)
+            acc = __dadd_rn(acc, __dmul_rn(data[jj], (double)X[(int64_t)indices[jj] * D + c]));
+        Y[r * D + c] = acc;
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+__global__ __launch_bounds__(256) void k_xlx_partial(const float *__restrict__ X, const double *__restrict__ Y,
+                                                     int64_t n, int D, int64_t rows_per_chunk,
+                                                     double *__restrict__ P) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a0 = blockIdx.x * 128 + (wave >> 1) * 64, b0 = blockIdx.y * 128 + (wave & 1) * 64;
+    const int64_t first = (int64_t)blockIdx.z * rows_per_chunk;
+    const int64_t last = (first + rows_per_chunk < n) ? first + rows_per_chunk : n;
+    const int m = lane & 15, kk = lane >> 4;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = first; i < last; i += 4) {
+        const int64_t row = i + kk;
+        const bool valid = row < last;
+        const float *xr = X + (valid ? row : first) * D + a0 + m;
+        const double *yr = Y + (valid ? row : first) * D + b0 + m;
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = valid ? (double)xr[t * 16] : 0.0;
+            b[t] = valid ? yr[t * 16] : 0.0;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    // f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double *Pz = P + (int64_t)blockIdx.z * D * D;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Pz[(int64_t)(a0 + mt * 16 + kk + 4 * r) * D + b0 + nt * 16 + m] = acc[mt][nt][r];
+}
+
+__global__ void k_xlx_reduce(const double *__restrict__ P, int n_chunks, int64_t dd, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= dd) return;
+    double acc = 0.0;
+    for (int z = 0; z < n_chunks; ++z) acc += P[(int64_t)z * dd + i];
+    out[i] = acc;
+}
+
 }  // namespace
 }  // namespace ssw
 
@@ -325,6 +402,56 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
     SSW_HIP_TRY(hipStreamSynchronize(s));
     if (out_sweeps) *out_sweeps = st.sweeps;
     if (out_converged) *out_converged = st.done;
+    return SSW_OK;
+}
+
+
+ssw_status ssw_xlx(ssw_index *index, ssw_lp *lap, double *out_host) {
+    SSW_REQUIRE(index != nullptr && lap != nullptr && out_host != nullptr, "NULL argument");
+    int64_t n = 0, n_images = 0;
+    int32_t D = 0;
+    void *Xv = nullptr, *scores = nullptr;
+    if (ssw_status rc = ssw_index_shape(index, &n, &D, &n_images); rc != SSW_OK) return rc;
+    if (ssw_status rc = ssw_index_device_ptrs(index, &Xv, &scores); rc != SSW_OK) return rc;
+    SSW_REQUIRE(n == lap->n, "ssw_xlx: the index has %lld rows, the matrix %lld", (long long)n, (long long)lap->n);
+    if (D % 128 != 0) {
+        set_error("ssw_xlx: dim %d unsupported (multiple of 128)", D);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    if (ssw_status rc = ssw_index_sync(index); rc != SSW_OK) return rc;  // uploads into X are complete
+    DeviceGuard guard(lap->device);
+    hipStream_t s = lap->stream;
+    const int64_t dd = (int64_t)D * D;
+    int64_t rows_per_chunk = (n + 127) / 128;
+    rows_per_chunk = ((rows_per_chunk < 1024 ? 1024 : rows_per_chunk) + 3) / 4 * 4;
+    const int n_chunks = (int)((n + rows_per_chunk - 1) / rows_per_chunk);
+    double *Y = nullptr, *P = nullptr, *out = nullptr;
+    auto release = [&]() {
+        (void)hipFree(Y);
+        (void)hipFree(P);
+        (void)hipFree(out);
+    };
+    hipError_t e = hipMalloc((void **)&Y, (size_t)n * D * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&P, (size_t)n_chunks * dd * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&out, (size_t)dd * sizeof(double));
+    if (e != hipSuccess) {
+        release();
+        set_error("ssw_xlx: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SSW_ERR_NOMEM : SSW_ERR_HIP;
+    }
+    hipLaunchKernelGGL(k_xlx_spmm, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, lap->indptr, lap->indices, lap->data,
+                       (const float *)Xv, n, (int)D, Y);
+    hipLaunchKernelGGL(k_xlx_partial, dim3(D / 128, D / 128, n_chunks), dim3(256), 0, s, (const float *)Xv, Y, n, (int)D,
+                       rows_per_chunk, P);
+    hipLaunchKernelGGL(k_xlx_reduce, dim3((unsigned)((dd + 255) / 256)), dim3(256), 0, s, P, n_chunks, dd, out);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, out, (size_t)dd * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    release();
+    if (e != hipSuccess) {
+        set_error("ssw_xlx: %s", hipGetErrorString(e));
+        return SSW_ERR_HIP;
+    }
     return SSW_OK;
 }
 

@@ -5,6 +5,7 @@ from __future__ import annotations
 import os
 
 import numpy as np
+import scipy.sparse as sp
 from pydantic import BaseModel
 
 from ..bitmap import BitMap
@@ -26,14 +27,32 @@ class WeightMatrixOptions(BaseModel):
     xlx_matrix: bool = False
 
 
-def compute_xlx(laplacian, X_vectors: np.ndarray) -> np.ndarray:
+def compute_xlx(laplacian, X_vectors: np.ndarray, device_index=None) -> np.ndarray:
     """X' (L / trace L) X -- the database-alignment regulariser of MultiReg
-    (graph_based.py:45-49).  One-off per index, cached."""
-    L = laplacian / laplacian.diagonal().sum()
-    return np.asarray(X_vectors.T @ (L @ X_vectors))
+    (graph_based.py:45-49).  One-off per index, cached.  Runs on the GPU (ssw_xlx: f64 CSR
+    SpMM + f64 MFMA product) against the matrix already resident for the scan; a temporary
+    device copy of X_vectors is made when the caller has no DeviceIndex."""
+    import ctypes
+
+    from .. import _lib
+    from ..device_index import DeviceIndex
+    from ..label_propagation import LabelPropagation
+    L = sp.csr_array(laplacian / laplacian.diagonal().sum())
+    L.sort_indices()
+    dev = device_index if device_index is not None else DeviceIndex.from_numpy(np.ascontiguousarray(X_vectors, dtype=np.float32))
+    lap = LabelPropagation(L, reg_lambda=0.0, max_iter=0, device=dev.device)
+    out = np.empty((dev.dim, dev.dim), dtype=np.float64)
+    try:
+        _lib.call("ssw_xlx", dev._h, lap._h, ctypes.c_void_p(out.ctypes.data))
+    finally:
+        lap.close()
+        if device_index is None:
+            dev.close()
+    return out
 
 
-def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vectors=None, knng: KNNGraph = None):
+def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vectors=None, knng: KNNGraph = None,
+                         device_index=None):
     key = opts.model_dump_json()
     if opts.xlx_matrix:
         assert opts.symmetric and not opts.self_edges
@@ -45,7 +64,7 @@ def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vector
                            normalized=opts.normalized_weights, symmetric=opts.symmetric, laplacian=opts.xlx_matrix)
     if opts.xlx_matrix:
         assert X_vectors is not None
-        wm = compute_xlx(wm, X_vectors)
+        wm = compute_xlx(wm, X_vectors, device_index=device_index)
     if use_cache:
         _CACHE[key] = wm
     return wm
@@ -60,7 +79,8 @@ def get_weight_matrix_from_index(idx, weight_matrix_options, xlx_matrix=False):
     else:  # in-memory graph attached to the index (synthetic datasets): key the cache by identity
         opts.knn_path = f"mem:{id(idx)}:{opts.knn_path}"
     use_cache = opts.knn_path.find("subset") == -1
-    return lookup_weight_matrix(opts, use_cache=use_cache, X_vectors=idx.vectors, knng=knng)
+    return lookup_weight_matrix(opts, use_cache=use_cache, X_vectors=idx.vectors, knng=knng,
+                                device_index=getattr(idx, "_dev", None) if xlx_matrix else None)
 
 
 def get_label_prop(q, label_prop_params):

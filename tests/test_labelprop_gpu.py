@@ -83,3 +83,29 @@ def test_bound_violation_is_an_error():
     with pytest.raises(SeesawHipError):  # start value outside [0, 1]: the reference asserts
         lp.fit_transform(label_ids=np.zeros(0, np.int64), label_values=np.zeros(0), reg_values=None,
                          start_value=np.array([5.0, -3.0]))
+
+
+@pytest.mark.parametrize("n,dim", [(3000, 256), (20011, 512)])
+def test_xlx_matches_reference_expression(oracle, n, dim):
+    """K6: X' (L / trace L) X (graph_based.py:45-49) -- f64 on both sides; the GPU differs from
+    numpy's dgemm only in the order of the N-long f64 sums (tolerance 1e-11 of the matrix scale),
+    far below the f32 cast MultiReg applies to the result (multi_reg.py:31)."""
+    from seesaw_amd.knn_graph import get_weight_matrix, post_process_graph_df, rbf_kernel
+    from seesaw_amd.loops.graph_based import compute_xlx
+    import pandas as pd
+    rng = np.random.default_rng(n)
+    k = 10
+    src = np.repeat(np.arange(n), k)
+    dst = (src + rng.integers(1, n, size=src.shape[0])) % n
+    df = post_process_graph_df(pd.DataFrame({"src_vertex": src.astype(np.int32), "dst_vertex": dst.astype(np.int32),
+                                             "distance": rng.random(src.shape[0]).astype(np.float32) * 0.3}), nvec=n)
+    L = get_weight_matrix(df, kfun=rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True, laplacian=True)
+    X = oracle.synth_rows(3, 0, n, dim)
+    got = compute_xlx(L, X)
+    Ls = L / L.diagonal().sum()
+    want = X.T @ (Ls @ X)  # the reference expression (f64: scipy upcasts X)
+    assert got.shape == (dim, dim) and got.dtype == np.float64
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-11 * scale, np.abs(got - want).max() / scale
+    assert np.array_equal(got.astype(np.float32), want.astype(np.float32)) or \
+        np.abs(got.astype(np.float32) - want.astype(np.float32)).max() <= 2e-7 * scale
