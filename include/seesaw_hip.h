@@ -178,6 +178,17 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
                              double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
                              int32_t *out_sweeps, int32_t *out_converged);
 
+/* Exact k-NN graph over the resident matrix (rows as vertices, cosine / dot similarity):
+ * replaces compute_exact_knn, seesaw/knn_graph.py:170-191 (`1 - X @ X.T`, argsort, first k+1).
+ * out_dst / out_score are [n_rows, k+1]: per row the k+1 best rows INCLUDING the row itself,
+ * ordered by (score descending, row id ascending); scores are the bits ssw_index_scan would
+ * return for that row as the query (distance = 1 - score).  out_certified [n_rows]: 1 when the
+ * row's list is proven exact; rows with 0 must be recomputed with ssw_index_topk (rare: the
+ * fp16 candidate pass could not separate the k+1-th neighbour from the rest).  `seed` fixes the
+ * random column order of the candidate pass; results do not depend on it.  1 <= k <= 15. */
+ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, int32_t *out_dst_host,
+                         float *out_score_host, uint8_t *out_certified_host);
+
 /* K6: out [dim, dim] f64 = X' L X for the resident matrix X of `index` and the CSR matrix L held
  * by `laplacian` (an ssw_lp created from the graph Laplacian, already divided by its trace):
  * replaces `X_vectors.T @ (L @ X_vectors)`, seesaw/loops/graph_based.py:45-49. */

@@ -218,6 +218,25 @@ def synth_query(seed: int, dim: int = 512) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 # label propagation
 # --------------------------------------------------------------------------------------
+def exact_knn(vectors: np.ndarray, k: int):
+    """compute_exact_knn (seesaw/knn_graph.py:170-191) restated row by row: every row is scanned
+    against all rows (kernel-order f32 scores), the k+1 best rows INCLUDING itself are kept in
+    (score desc, row id asc) order.  The reference orders by `1 - X @ X.T` with BLAS sums and an
+    unstable argsort, so it agrees with this up to f32 rounding of near-ties (checked in
+    tests/test_oracle_cpu.py against its golden output).  Returns (dst int32 [n,k+1], score f32)."""
+    X = np.ascontiguousarray(vectors, dtype=np.float32)
+    n = X.shape[0]
+    k1 = min(k + 1, n)
+    dst = np.empty((n, k1), dtype=np.int32)
+    score = np.empty((n, k1), dtype=np.float32)
+    ids = np.arange(n)
+    for i in range(n):
+        s = scores_kernel_order(X, X[i])
+        order = np.lexsort((ids, -s.astype(np.float64)))[:k1]
+        dst[i], score[i] = order, s[order]
+    return dst, score
+
+
 def label_propagation(W, *, label_ids, label_values, reg_lambda, reg_values=None, start_value=None,
                       max_iter=300, epsilon=1e-5):
     """LabelPropagation.fit_transform -- seesaw/label_propagation.py:45-79 with _step (:30-43):

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "ssw_fb_set_targets": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_query": (c_i32, [c_void_p, c_void_p]),
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_knn_build": (c_i32, [c_void_p, c_i32, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),
     "ssw_fb_get_mean": (c_i32, [c_void_p, c_void_p]),
     "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,429 @@
+// knn.hip -- exact k-NN graph construction over the resident index (gfx950 / MI355X)
+//
+// Replaces compute_exact_knn of the reference (seesaw/knn_graph.py:170-191):
+//     all_pairs = 1 - X @ X.T ;  nn = argsort(all_pairs, axis=-1)[:, :k+1]
+// which is O(N^2 d) and only feasible for small N there (the production graphs come from the
+// approximate pynndescent, knn_graph.py:194-243).  Here the graph is EXACT at any N that fits HBM:
+//
+//   1. candidates   S~ = Xh Xh^T with Xh = fp16(2^e X) on the matrix cores (v_mfma_f32_16x16x32_f16,
+//                   the LDS-DMA tile pipeline of gemm_bf16.hip: 128 x 128 tiles, 8 x 8 super-tiles per
+//                   XCD so both operand panels stay in that XCD's L2).  Nothing is stored: the epilogue
+//                   compares the accumulators with a per-row threshold and appends the few survivors
+//                   (score, column) to a per-row buffer.
+//   2. thresholds   columns are visited in a random order (seeded permutation) in geometrically growing
+//                   levels; after each level a per-row LDS bitonic sort keeps the best M = 32 entries and
+//                   raises the row's threshold to the M-th score, so a level appends ~ M x ratio
+//                   entries per row whatever the data looks like (exchangeability of the permutation).
+//   3. exact scores the <= M candidates of every row are re-scored in f32 in the scan kernel's fixed
+//                   summation order (scan.hip), sorted by (score desc, row id asc), and the best k+1
+//                   are returned -- the same bits and order as a brute-force scan of that row.
+//   4. certificate  a column outside the candidate list has fp16-path score <= b (the M-th kept), and
+//                   |fp16-path - exact| <= E_i (derived below), so the row is PROVEN exact when
+//                   exact(k+1-th) - E_i > b.  Rows that fail (or whose buffer overflowed) are flagged;
+//                   the caller reruns them through the ordinary exact scan (ssw_index_topk).
+//
+// Error bound E_i: fp16 rounding is <= 2^-11 relative per operand (scaled components lie in
+// [2^-14, 256), values below 2^-14 may be flushed), so the product sum differs from the exact one by
+// at most (2^-10 + 2^-22) sum|x_d y_d| <= 2^-10 |x||y|; the f32 accumulation of 512 terms adds
+// <= 512 * 2^-24 |x||y| on either side and the flushed tail <= 2^-21 maxabs sqrt(D) |y|.  E_i is set to
+// 1.2e-3 |x_i| max|x| + 1e-5 max|x|^2, which covers all of it with margin.
+//
+// Roofline: MFMA-bound (2 N^2 d flop, fp16 dense peak 2.5 PFLOP/s); operand traffic per 128^2 tile is
+// 256 KB out of L2, i.e. the same L2 -> LDS ceiling as the tower GEMM.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "ssw_common.h"
+
+namespace ssw {
+namespace {
+
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int KNN_M = 32;       // candidates kept per row between levels
+constexpr int KNN_CAP = 4096;   // row buffer capacity (entries appended within one level + M)
+constexpr int KT = 128;         // tile edge
+constexpr int KBK = 64;         // k-step
+constexpr int K_OPER = 16384;   // one operand image: 128 rows x 128 B
+constexpr int K_STAGE = 2 * K_OPER;
+
+// ---------------------------------------------------------------------------------------
+// preparation
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_knn_stats(const float *__restrict__ X, int64_t n, int D,
+                                                   float *__restrict__ norms, unsigned *__restrict__ maxima) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *x = X + r * D;
+    float ss = 0.f, mx = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = x[c];
+        ss = fmaf(v, v, ss);
+        mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) {
+        const float nr = sqrtf(ss) * 1.000001f;  // upper bound of the norm
+        norms[r] = nr;
+        atomicMax(&maxima[0], __float_as_uint(mx));  // non-negative floats order like their bits
+        atomicMax(&maxima[1], __float_as_uint(nr));
+    }
+}
+
+// Xh[p, :] = fp16(scale * X[perm[p], :])
+__global__ void k_knn_convert(const float *__restrict__ X, const int32_t *__restrict__ perm, int64_t n, int D,
+                              float scale, f16 *__restrict__ Xh) {
+    const int64_t chunks = n * (D / 8);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / (D / 8);
+        const int c = (int)(i % (D / 8)) * 8;
+        const float4 *src = reinterpret_cast<const float4 *>(X + (int64_t)perm[p] * D + c);
+        const float4 a = src[0], b = src[1];
+        f16x8 o;
+        o[0] = (f16)(a.x * scale); o[1] = (f16)(a.y * scale); o[2] = (f16)(a.z * scale); o[3] = (f16)(a.w * scale);
+        o[4] = (f16)(b.x * scale); o[5] = (f16)(b.y * scale); o[6] = (f16)(b.z * scale); o[7] = (f16)(b.w * scale);
+        *reinterpret_cast<f16x8 *>(Xh + p * D + c) = o;
+    }
+}
+
+__global__ void k_knn_reset(float *__restrict__ thr, unsigned *__restrict__ cnt, unsigned char *__restrict__ overflow,
+                            int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) {
+        thr[i] = -INFINITY;
+        cnt[i] = 0;
+        overflow[i] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// candidate pass: S~ tile on the matrix cores, thresholded append
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// rows [r0, r1) of Xh against columns [c0, c1) of Xh; thr / cnt / buf are indexed by row - r0
+__global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__ Xh, int D, int r0, int r1, int c0,
+                                                         int c1, const float *__restrict__ thr,
+                                                         unsigned *__restrict__ cnt, uint64_t *__restrict__ buf,
+                                                         int i_tiles, int j_tiles, int sj_count, int n_super) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // 8 x 8 super-tiles dealt round-robin to the XCDs (block ids b and b + 8 share an XCD): the 64
+    // tiles of a super-tile run on one XCD and share 2 x 8 operand panels through its L2
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int g = (local >> 6) * 8 + xcd;
+    if (g >= n_super) return;
+    const int within = local & 63;
+    const int I = (g / sj_count) * 8 + (within >> 3), J = (g % sj_count) * 8 + (within & 7);
+    if (I >= i_tiles || J >= j_tiles) return;
+    const int m0 = r0 + I * KT, n0 = c0 + J * KT;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const f16 *a_src[4];
+    const f16 *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[i] = Xh + (int64_t)min(m0 + row, r1 - 1) * D + chunk * 8;
+        b_src[i] = Xh + (int64_t)min(n0 + row, c1 - 1) * D + chunk * 8;
+    }
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
+    const unsigned a_dst = lds0 + wave * 4096, b_dst = lds0 + K_OPER + wave * 4096;
+#define KNN_ISSUE(kt, slot)                                                        \
+    {                                                                              \
+        const int k0 = (kt) * KBK;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                              \
+            glds16(a_src[i] + k0, a_dst + (slot) * K_STAGE + i * 1024);            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                              \
+            glds16(b_src[i] + k0, b_dst + (slot) * K_STAGE + i * 1024);            \
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+    const int a_frag = wm * 8192 + frag0, b_frag = K_OPER + wn * 8192 + frag0;
+    // thresholds of this lane's four rows (accumulator row = m0 + wm*64 + i*16 + fr)
+    float trow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + fr;
+        trow[i] = row < r1 ? thr[row - r0] : INFINITY;
+    }
+    asm volatile("" ::"s"(cnt), "s"(buf), "s"(c1));  // all scalar loads done before the loop (gemm_bf16.hip)
+    const int nk = D / KBK;
+    KNN_ISSUE(0, 0)
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) KNN_ISSUE(kt + 1, slot ^ 1)
+        const unsigned char *sb = smem + slot * K_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const f16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));
+                b[i] = *reinterpret_cast<const f16x8 *>(sb + ((b_frag + i * 2048) ^ (ks * 64)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+        slot ^= 1;
+    }
+#undef KNN_ISSUE
+    // acc[i][j][r] = S~[row m0 + wm*64 + i*16 + fr][column n0 + wn*64 + j*16 + fq*4 + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float tr = trow[i];
+        const int lrow = m0 + wm * 64 + i * 16 + fr - r0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc[i][j];
+            if (fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > tr) {
+                const int col = n0 + wn * 64 + j * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (v[r] > tr && col + r < c1) {
+                        const unsigned pos = atomicAdd(&cnt[lrow], 1u);
+                        if (pos < (unsigned)KNN_CAP)
+                            buf[(int64_t)lrow * KNN_CAP + pos] =
+                                ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)(col + r));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// per row: keep the best M entries (score desc, column asc), raise the threshold
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_knn_compact(uint64_t *__restrict__ buf, unsigned *__restrict__ cnt,
+                                                     float *__restrict__ thr, unsigned char *__restrict__ overflow,
+                                                     int rows) {
+    __shared__ uint64_t keys[KNN_CAP];
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    unsigned c = cnt[row];
+    if (c > (unsigned)KNN_CAP) {  // entries were dropped: the row cannot be certified any more
+        if (threadIdx.x == 0) overflow[row] = 1;
+        c = KNN_CAP;
+    }
+    if (c <= 1) return;  // nothing to order (thr stays -inf below M entries)
+    int P = 64;
+    while (P < (int)c) P <<= 1;
+    uint64_t *rb = buf + (int64_t)row * KNN_CAP;
+    for (int i = threadIdx.x; i < P; i += 256) keys[i] = i < (int)c ? rb[i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            for (int i = threadIdx.x; i < P / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));  // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int keep = (int)c < KNN_M ? (int)c : KNN_M;
+    for (int i = threadIdx.x; i < keep; i += 256) rb[i] = keys[i];
+    if (threadIdx.x == 0) {
+        cnt[row] = keep;
+        if ((int)c >= KNN_M) thr[row] = ord_to_f32((uint32_t)(keys[KNN_M - 1] >> 32));
+    }
+}
+
+struct KnnScratch {
+    int32_t *perm = nullptr;
+    float *norms = nullptr;
+    unsigned *maxima = nullptr;
+    f16 *Xh = nullptr;
+    float *thr = nullptr;
+    unsigned *cnt = nullptr;
+    unsigned char *overflow = nullptr;
+    uint64_t *buf = nullptr;
+    int32_t *out_dst = nullptr;
+    float *out_score = nullptr;
+    unsigned char *out_cert = nullptr;
+    void release() {
+        for (void *p : {(void *)perm, (void *)norms, (void *)maxima, (void *)Xh, (void *)thr, (void *)cnt,
+                        (void *)overflow, (void *)buf, (void *)out_dst, (void *)out_score, (void *)out_cert})
+            (void)hipFree(p);
+    }
+};
+
+inline uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+}  // namespace ssw
+
+using namespace ssw;
+
+extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, int32_t *out_dst_host,
+                                    float *out_score_host, uint8_t *out_certified_host) {
+    SSW_REQUIRE(index != nullptr && out_dst_host != nullptr && out_score_host != nullptr &&
+                    out_certified_host != nullptr,
+                "NULL argument");
+    int64_t n = 0, n_images = 0;
+    int32_t D = 0;
+    void *Xv = nullptr, *scores_unused = nullptr;
+    SSW_TRY(ssw_index_shape(index, &n, &D, &n_images));
+    SSW_TRY(ssw_index_device_ptrs(index, &Xv, &scores_unused));
+    SSW_REQUIRE(n >= 1 && n < (int64_t)0x7fff0000, "ssw_knn_build: n=%lld out of range", (long long)n);
+    SSW_REQUIRE(k >= 1 && k + 1 <= KNN_M / 2, "ssw_knn_build: k=%d out of range (1..%d)", k, KNN_M / 2 - 1);
+    if (D != 256 && D != 512 && D != 768 && D != 1024) {
+        set_error("ssw_knn_build: dim=%d unsupported", D);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    SSW_TRY(ssw_index_sync(index));
+    int device = 0;
+    SSW_HIP_TRY(hipGetDevice(&device));
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, Xv) == hipSuccess) device = attr.device;
+    DeviceGuard guard(device);
+    hipStream_t s = nullptr;  // one-off build: the default stream orders everything
+    const float *X = static_cast<const float *>(Xv);
+    const int k1 = k + 1;
+
+    KnnScratch sc;
+    ssw_status rc = SSW_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        set_error("ssw_knn_build: %s: %s", what, hipGetErrorString(e));
+        sc.release();
+        return e == hipErrorOutOfMemory ? SSW_ERR_NOMEM : SSW_ERR_HIP;
+    };
+#define KNN_HIP(expr)                                             \
+    if (hipError_t _e = (expr); _e != hipSuccess) return fail(_e, #expr)
+
+    const int64_t RB = std::min<int64_t>(n, 131072);  // rows per batch (buffer RB x CAP x 8 B = 4.3 GB)
+    KNN_HIP(hipMalloc((void **)&sc.perm, (size_t)n * 4));
+    KNN_HIP(hipMalloc((void **)&sc.norms, (size_t)n * 4));
+    KNN_HIP(hipMalloc((void **)&sc.maxima, 8));
+    KNN_HIP(hipMalloc((void **)&sc.Xh, (size_t)n * D * 2));
+    KNN_HIP(hipMalloc((void **)&sc.thr, (size_t)RB * 4));
+    KNN_HIP(hipMalloc((void **)&sc.cnt, (size_t)RB * 4));
+    KNN_HIP(hipMalloc((void **)&sc.overflow, (size_t)RB));
+    KNN_HIP(hipMalloc((void **)&sc.buf, (size_t)RB * KNN_CAP * 8));
+    KNN_HIP(hipMalloc((void **)&sc.out_dst, (size_t)n * k1 * 4));
+    KNN_HIP(hipMalloc((void **)&sc.out_score, (size_t)n * k1 * 4));
+    KNN_HIP(hipMalloc((void **)&sc.out_cert, (size_t)n));
+
+    // random column order (Fisher-Yates, splitmix64)
+    {
+        std::vector<int32_t> perm((size_t)n);
+        for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = (int32_t)i;
+        uint64_t st = seed ^ 0x5EE5A3D1ull;
+        for (int64_t i = n - 1; i > 0; --i) {
+            const uint64_t j = splitmix64(st) % (uint64_t)(i + 1);
+            std::swap(perm[(size_t)i], perm[(size_t)j]);
+        }
+        KNN_HIP(hipMemcpy(sc.perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    KNN_HIP(hipMemsetAsync(sc.maxima, 0, 8, s));
+    hipLaunchKernelGGL(k_knn_stats, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, X, n, (int)D, sc.norms, sc.maxima);
+    float maxima[2] = {0.f, 0.f};
+    KNN_HIP(hipMemcpy(maxima, sc.maxima, 8, hipMemcpyDeviceToHost));
+    const float maxabs = maxima[0], maxnorm = maxima[1];
+    if (!(maxabs > 0.f) || !std::isfinite(maxabs)) {
+        set_error("ssw_knn_build: the index holds no finite non-zero vector");
+        sc.release();
+        return SSW_ERR_NUMERIC;
+    }
+    int e2 = 0;
+    (void)std::frexp(maxabs, &e2);                 // maxabs in [2^(e2-1), 2^e2)
+    const float scale = std::ldexp(1.0f, 8 - e2);  // scale * maxabs in [128, 256)
+    hipLaunchKernelGGL(k_knn_convert, dim3(4096), dim3(256), 0, s, X, sc.perm, n, (int)D, scale, sc.Xh);
+    KNN_HIP(hipGetLastError());
+    KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
+
+    // level boundaries over the permuted columns: 1024, then a constant ratio <= 40 up to n
+    std::vector<int64_t> bounds;
+    {
+        const int64_t b0 = std::min<int64_t>(n, 1024);
+        bounds.push_back(b0);
+        if (n > b0) {
+            const double span = (double)n / (double)b0;
+            const int levels = std::max(1, (int)std::ceil(std::log(span) / std::log(40.0)));
+            const double ratio = std::pow(span, 1.0 / levels);
+            for (int l = 1; l < levels; ++l)
+                bounds.push_back(std::min<int64_t>(n, (int64_t)std::llround((double)b0 * std::pow(ratio, l))));
+            bounds.push_back(n);
+        }
+    }
+    for (int64_t r0 = 0; r0 < n && rc == SSW_OK; r0 += RB) {
+        const int64_t r1 = std::min(n, r0 + RB);
+        const int rows = (int)(r1 - r0);
+        hipLaunchKernelGGL(k_knn_reset, dim3((rows + 255) / 256), dim3(256), 0, s, sc.thr, sc.cnt, sc.overflow, rows);
+        int64_t c0 = 0;
+        for (int64_t c1 : bounds) {
+            if (c1 <= c0) continue;
+            const int i_tiles = (rows + KT - 1) / KT, j_tiles = (int)((c1 - c0 + KT - 1) / KT);
+            const int si = (i_tiles + 7) / 8, sj = (j_tiles + 7) / 8;
+            const int64_t n_super = (int64_t)si * sj;
+            const int64_t grid = ((n_super + 7) / 8) * 8 * 64;
+            if (grid >= (int64_t)0x7fffffff) {
+                set_error("ssw_knn_build: level of %lld x %lld tiles exceeds one launch", (long long)i_tiles,
+                          (long long)j_tiles);
+                rc = SSW_ERR_UNSUPPORTED;
+                break;
+            }
+            hipLaunchKernelGGL(k_knn_gemm_filter, dim3((unsigned)grid), dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D, (int)r0,
+                               (int)r1, (int)c0, (int)c1, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj, (int)n_super);
+            hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows);
+            c0 = c1;
+        }
+        if (rc != SSW_OK) break;
+        rc = launch_knn_rescore(X, D, sc.perm, (int)r0, rows, sc.buf, KNN_CAP, sc.cnt, sc.overflow, KNN_M, sc.norms, scale,
+                                maxnorm, k1, sc.out_dst, sc.out_score, sc.out_cert, s);
+        if (hipError_t e = hipGetLastError(); rc == SSW_OK && e != hipSuccess) return fail(e, "kernel launch");
+    }
+    if (rc != SSW_OK) {
+        sc.release();
+        return rc;
+    }
+    KNN_HIP(hipMemcpyAsync(out_dst_host, sc.out_dst, (size_t)n * k1 * 4, hipMemcpyDeviceToHost, s));
+    KNN_HIP(hipMemcpyAsync(out_score_host, sc.out_score, (size_t)n * k1 * 4, hipMemcpyDeviceToHost, s));
+    KNN_HIP(hipMemcpyAsync(out_certified_host, sc.out_cert, (size_t)n, hipMemcpyDeviceToHost, s));
+    KNN_HIP(hipStreamSynchronize(s));
+#undef KNN_HIP
+    sc.release();
+    return SSW_OK;
+}

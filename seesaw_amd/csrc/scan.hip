@@ -184,6 +184,67 @@ __global__ __launch_bounds__(256) void score_rows_kernel(const float *__restrict
     if (lane == 0) out[w] = v;
 }
 
+// k-NN graph build, last stage (knn.hip): one wave per row re-scores its <= M candidate columns in
+// the scan's summation order (so the scores are the bits a brute-force scan of that row returns),
+// orders them by (score desc, row id asc) with a 64-lane bitonic network and certifies the row:
+// every column outside the list has fp16-path score <= b, hence exact score <= b + E.
+template <int C>
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restrict__ X, const int32_t *__restrict__ perm,
+                                                         int r0, int rows, const uint64_t *__restrict__ buf, int cap,
+                                                         const unsigned *__restrict__ cnt,
+                                                         const unsigned char *__restrict__ overflow, int M,
+                                                         const float *__restrict__ norms, float inv_scale2,
+                                                         float maxnorm, int k1, int32_t *__restrict__ out_dst,
+                                                         float *__restrict__ out_score,
+                                                         unsigned char *__restrict__ out_cert) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= rows) return;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X);
+    const int orig_i = perm[r0 + w];
+    const int c = min((int)cnt[w], M);
+    const uint64_t key = lane < c ? buf[(int64_t)w * cap + lane] : 0ull;
+    const int orig_c = lane < c ? perm[0xFFFFFFFFu - (uint32_t)key] : -1;
+    const float approx = ord_to_f32((uint32_t)(key >> 32));  // fp16-path score (scaled)
+    const RowFrag<C> xi = load_row<C, false>(X4, orig_i, lane);
+    float mine = -INFINITY;
+    for (int t = 0; t < c; ++t) {
+        const int j = __shfl(orig_c, t, 64);
+        const RowFrag<C> xj = load_row<C, false>(X4, j, lane);
+        float v = dot_frag<C>(xj, xi);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+        if (lane == t) mine = v;
+    }
+    uint32_t hi = lane < c ? f32_to_ord(mine) : 0u, lo = lane < c ? 0xFFFFFFFFu - (uint32_t)orig_c : 0u;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            const uint32_t ohi = __shfl_xor(hi, stride, 64), olo = __shfl_xor(lo, stride, 64);
+            const bool desc = (lane & size) == 0, lower = (lane & stride) == 0;
+            const bool other_gt = ohi > hi || (ohi == hi && olo > lo);
+            if ((lower == desc) == other_gt) {  // keep the larger key on the descending side's lower lane
+                hi = ohi;
+                lo = olo;
+            }
+        }
+    }
+    const bool have = (hi | lo) != 0u;
+    const float score = have ? ord_to_f32(hi) : -INFINITY;
+    if (lane < k1) {
+        out_dst[(int64_t)orig_i * k1 + lane] = have ? (int32_t)(0xFFFFFFFFu - lo) : -1;
+        out_score[(int64_t)orig_i * k1 + lane] = score;
+    }
+    const float s_k1 = __shfl(score, k1 - 1, 64);
+    const float b = __shfl(approx, M - 1, 64) * inv_scale2;  // meaningful when c == M
+    if (lane == 0) {
+        const float E = 1.2e-3f * norms[orig_i] * maxnorm + 1e-5f * maxnorm * maxnorm;
+        const bool cert = !overflow[w] && (c < M || (s_k1 - E > b));
+        out_cert[orig_i] = cert ? 1 : 0;
+    }
+}
+
 // Schedule (measured on MI355X, interleaved A/B in one process, tools/sweep_scan.py):
 // non-temporal loads are worth +4...7 %, and with them FEWER resident waves stream faster --
 // at 100 M rows u2+nt with one block per CU reads 6.70 TB/s, u4 (default policy, 8 waves/SIMD)
@@ -262,6 +323,30 @@ ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *
             set_error("score_rows: dim=%d unsupported", dim);
             return SSW_ERR_UNSUPPORTED;
     }
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, int r0, int rows, const uint64_t *buf,
+                              int cap, const unsigned *cnt, const unsigned char *overflow, int M, const float *norms,
+                              float scale, float maxnorm, int k1, int32_t *out_dst, float *out_score,
+                              unsigned char *out_cert, hipStream_t stream) {
+    if (rows <= 0) return SSW_OK;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const float inv_scale2 = 1.0f / (scale * scale);
+#define SSW_KNN_RESCORE(C)                                                                                          \
+    hipLaunchKernelGGL(knn_rescore_kernel<C>, grid, block, 0, stream, X, perm, r0, rows, buf, cap, cnt, overflow, M, \
+                       norms, inv_scale2, maxnorm, k1, out_dst, out_score, out_cert)
+    switch (dim) {
+        case 256: SSW_KNN_RESCORE(1); break;
+        case 512: SSW_KNN_RESCORE(2); break;
+        case 768: SSW_KNN_RESCORE(3); break;
+        case 1024: SSW_KNN_RESCORE(4); break;
+        default:
+            set_error("knn_rescore: dim=%d unsupported", dim);
+            return SSW_ERR_UNSUPPORTED;
+    }
+#undef SSW_KNN_RESCORE
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

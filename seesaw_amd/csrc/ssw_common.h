@@ -93,6 +93,11 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
 ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *rows_dev, int64_t n,
                              int32_t dim, float *out, hipStream_t stream);
 void tune_scan(int variant, int blocks_per_cu);
+// knn.hip's last stage (lives in scan.hip to share the scan's summation order)
+ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, int r0, int rows, const uint64_t *buf,
+                              int cap, const unsigned *cnt, const unsigned char *overflow, int M, const float *norms,
+                              float scale, float maxnorm, int k1, int32_t *out_dst, float *out_score,
+                              unsigned char *out_cert, hipStream_t stream);
 // gemm_bf16.hip: C[M,N] = A[M,K] W[N,K]^T (bf16 in, f32 accumulate) with fused epilogue
 // epi: 0 f32 | 1 +bias -> bf16 | 2 +bias, quick-GELU -> bf16 | 3 +bias +residual -> f32
 ssw_status launch_gemm_bf16_nt(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,

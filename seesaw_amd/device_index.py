@@ -183,6 +183,30 @@ class DeviceIndex:
         c = cnt.value
         return imgs[:c], scs[:c], rows[:c]
 
+    # -- k-NN graph -------------------------------------------------------------------
+    def knn(self, k: int, seed: int = 0):
+        """Exact k nearest rows of every row (compute_exact_knn, knn_graph.py:170-191):
+        returns (dst int32 [n, k+1], score f32 [n, k+1], n_recomputed).  Each row lists the k+1
+        best rows including itself by (score desc, row id asc); scores are scan-order f32.
+        Rows the fp16 candidate pass could not certify are redone with the ordinary exact scan."""
+        k = int(k)
+        n = self.n_rows
+        dst = np.empty((n, k + 1), dtype=np.int32)
+        score = np.empty((n, k + 1), dtype=np.float32)
+        cert = np.empty(n, dtype=np.uint8)
+        _lib.call("ssw_knn_build", self._h, k, ctypes.c_uint64(int(seed)), _ptr(dst), _ptr(score), _ptr(cert))
+        redo = np.nonzero(cert == 0)[0]
+        if redo.shape[0]:
+            view = DeviceIndex(n, self.dim, device=self.device, dev_ptr=self.device_ptrs()[0])  # rows, no image map
+            try:
+                for r in redo.tolist():
+                    ids, sc, _ = view.topk(self.download(r, 1)[0], k + 1)
+                    dst[r, :ids.shape[0]] = ids
+                    score[r, :ids.shape[0]] = sc
+            finally:
+                view.close()
+        return dst, score, int(redo.shape[0])
+
     # -- profiling --------------------------------------------------------------------
     def profile(self, enable: bool):
         _lib.call("ssw_index_profile", self._h, int(bool(enable)))

@@ -113,16 +113,23 @@ def post_process_graph_df(df: pd.DataFrame, nvec: int) -> pd.DataFrame:
     return out.sort_values(["src_vertex", "dst_rank"]).reset_index(drop=True)
 
 
-def compute_exact_knn(vectors: np.ndarray, n_neighbors: int) -> pd.DataFrame:
-    """all-pairs cosine distances, k+1 nearest per row (offline; knn_graph.py:170-191)."""
-    k = min(n_neighbors + 1, vectors.shape[0])
-    all_pairs = 1.0 - (vectors @ vectors.T)
-    nn = np.argsort(all_pairs, axis=-1)[:, :k]
-    src = np.repeat(np.arange(vectors.shape[0]), k)
-    dst = nn.reshape(-1)
-    df = pd.DataFrame({"src_vertex": src.astype("int32"), "dst_vertex": dst.astype("int32"),
-                       "distance": all_pairs[src, dst].astype("float32")})
-    return post_process_graph_df(df, nvec=vectors.shape[0])
+def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None) -> pd.DataFrame:
+    """all-pairs cosine distances, k+1 nearest per row (knn_graph.py:170-191) on the GPU:
+    DeviceIndex.knn (ssw_knn_build: fp16 MFMA candidate pass + exact f32 rescoring, certified
+    per row).  `device_index` is the index's resident matrix when the caller has one."""
+    from .device_index import DeviceIndex
+    n = vectors.shape[0]
+    k = min(n_neighbors + 1, n) - 1
+    dev = device_index if device_index is not None else DeviceIndex.from_numpy(np.ascontiguousarray(vectors, dtype=np.float32))
+    try:
+        dst, score, _ = dev.knn(k)
+    finally:
+        if device_index is None:
+            dev.close()
+    src = np.repeat(np.arange(n, dtype=np.int32), k + 1)
+    df = pd.DataFrame({"src_vertex": src, "dst_vertex": dst.reshape(-1),
+                       "distance": (np.float32(1.0) - score.reshape(-1)).astype("float32")})
+    return post_process_graph_df(df, nvec=n)
 
 
 class KNNGraph:

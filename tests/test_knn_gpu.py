@@ -1,0 +1,75 @@
+"""GPU parity of the exact k-NN graph build (ssw_knn_build through DeviceIndex.knn /
+seesaw_amd.knn_graph.compute_exact_knn) against the CPU oracle (bit-exact: neighbour ids, their order
+and the f32 score bits) and against the reference's compute_exact_knn output (tests/golden/labelprop.npz,
+BLAS summation there, so near-ties may swap within the rounding band)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _check_vs_oracle(oracle, X, k, rows=None):
+    from seesaw_amd.device_index import DeviceIndex
+    dev = DeviceIndex.from_numpy(X)
+    dst, score, redone = dev.knn(k)
+    dev.close()
+    if rows is None:
+        o_dst, o_score = oracle.exact_knn(X, k)
+        assert np.array_equal(dst, o_dst), np.nonzero((dst != o_dst).any(axis=1))[0][:10]
+        assert np.array_equal(bits(score), bits(o_score))
+    else:
+        ids = np.arange(X.shape[0])
+        for r in rows:
+            s = oracle.scores_kernel_order(X, X[r])
+            order = np.lexsort((ids, -s.astype(np.float64)))[:k + 1]
+            assert np.array_equal(dst[r], order), r
+            assert np.array_equal(bits(score[r]), bits(s[order])), r
+    return redone
+
+
+@pytest.mark.parametrize("n,k,dim", [(1, 1, 512), (5, 4, 512), (40, 10, 512), (130, 15, 256), (1500, 10, 512),
+                                     (3000, 10, 512), (2500, 3, 768)])
+def test_knn_bit_exact_vs_oracle(oracle, n, k, dim):
+    k = min(k, n - 1) if n > 1 else 0
+    X = oracle.synth_rows(100 + n, 0, n, dim)
+    if k == 0:
+        pytest.skip("a single vertex has no neighbours")
+    redone = _check_vs_oracle(oracle, X, k)
+    assert redone <= max(2, n // 50)
+
+
+def test_knn_clustered_and_duplicate_rows(oracle):
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    X = g["X"].copy()  # clustered unit rows
+    X[100:150] = X[7]  # 51 identical rows: exact score ties, ordered by row id
+    redone = _check_vs_oracle(oracle, X, 10)
+    assert redone <= X.shape[0] // 10
+
+
+def test_compute_exact_knn_vs_reference_golden(oracle):
+    from seesaw_amd.knn_graph import compute_exact_knn
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    df = compute_exact_knn(g["X"], int(g["k"]))
+    assert df.shape[0] == g["src"].shape[0]
+    assert np.array_equal(df.src_vertex.values, g["src"]) and np.array_equal(df.dst_rank.values, g["rank"])
+    assert df.dst_vertex.dtype == np.int32 and df.distance.dtype == np.float32
+    assert np.allclose(df.distance.values, g["dist"], rtol=0, atol=1e-6)  # f32 sums in a different order
+    differs = df.dst_vertex.values != g["dst"]
+    assert np.all(np.abs(df.distance.values[differs] - g["dist"][differs]) <= 1e-6) and differs.mean() < 0.01
+
+
+def test_knn_two_hundred_thousand_rows_spot_checked(oracle):
+    """three column levels, two row batches; 64 rows checked bit for bit against full CPU scans"""
+    n, k = 200_000, 10
+    X = oracle.synth_rows(77, 0, n, 512)
+    rows = np.random.default_rng(3).integers(0, n, size=64).tolist() + [0, n - 1, 131071, 131072]
+    redone = _check_vs_oracle(oracle, X, k, rows=rows)
+    assert redone <= n // 100, redone
