@@ -275,6 +275,12 @@ ssw_status ssw_clip_embed_image(ssw_clip *clip, const float *nchw_host, int32_t 
 /* same with device pointers, enqueued on hip_stream (NULL: the handle's stream), no sync. */
 ssw_status ssw_clip_embed_image_dev(ssw_clip *clip, void *hip_stream, const float *nchw_dev, int32_t b,
                                     int32_t normalize, float *out_dev);
+/* tiles [b, image, image, 3] uint8 (HWC, as cut by the multiscale tiler): batch_tx's
+ * `x / 255 -> (x - mean) / std` (seesaw/indices/multiscale/multiscale_tools.py:167-183) is fused into
+ * the patch gather, then the same forward pass as ssw_clip_embed_image.  Replaces batch_tx +
+ * InferenceActor.__call__ (multiscale_tools.py:187-202). */
+ssw_status ssw_clip_embed_tiles_u8(ssw_clip *clip, const uint8_t *tiles_hwc_host, int32_t b, int32_t normalize,
+                                   float *out_host);
 /* input_ids [b, seq_len] int32 (BOS ... EOS [pad]); the feature is taken at the first EOS. */
 ssw_status ssw_clip_embed_text(ssw_clip *clip, const int32_t *ids_host, int32_t b, int32_t seq_len,
                                int32_t normalize, float *out_host);

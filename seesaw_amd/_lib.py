@@ -86,6 +86,7 @@ _SIGNATURES = {
     "ssw_clip_embed_image": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
     "ssw_clip_embed_image_dev": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
     "ssw_clip_embed_text": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
+    "ssw_clip_embed_tiles_u8": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
     "ssw_clip_sync": (c_i32, [c_void_p]),
     "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "ssw_tune_gemm": (c_i32, [c_i32]),

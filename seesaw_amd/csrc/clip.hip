@@ -251,6 +251,44 @@ __global__ void im2col_patches(const float *__restrict__ px, bf16 *__restrict__ 
     }
 }
 
+// uint8 HWC tiles [B,224,224,3] (what the tiler produces, multiscale_tools.py:45-71) -> patches bf16,
+// with batch_tx's arithmetic fused in (multiscale_tools.py:167-183: x / 255, then (x - mean) / std in
+// f32): the f32 NCHW tensor is never materialised and the host hands over a quarter of the bytes.
+__global__ void im2col_patches_u8(const uint8_t *__restrict__ tiles, bf16 *__restrict__ out, int B, int img, int patch,
+                                  float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int g = img / patch;
+    const int pp = patch * patch;
+    const int per_row = patch / 8;  // 8-pixel groups per patch row
+    const int64_t total = (int64_t)B * g * g * patch * per_row;
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xg = (int)(i % per_row);
+        int64_t r = i / per_row;
+        const int py = (int)(r % patch);
+        r /= patch;
+        const int p = (int)(r % (g * g));
+        const int b = (int)(r / (g * g));
+        const int y = (p / g) * patch + py, x = (p % g) * patch + xg * 8;
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(tiles + (((int64_t)b * img + y) * img + x) * 3);
+        const uint64_t w0 = src[0], w1 = src[1], w2 = src[2];  // 8 pixels x RGB = 24 bytes
+        uint8_t px[24];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            px[j] = (uint8_t)(w0 >> (8 * j));
+            px[8 + j] = (uint8_t)(w1 >> (8 * j));
+            px[16 + j] = (uint8_t)(w2 >> (8 * j));
+        }
+        bf16 *row = out + ((int64_t)b * g * g + p) * (3 * pp) + py * patch + xg * 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = to_bf16(((float)px[3 * j + c] / 255.0f - mean[c]) / stdv[c]);
+            *reinterpret_cast<bf16x8 *>(row + c * pp) = o;
+        }
+    }
+}
+
 // hidden[b, 0] = cls + pos[0]; hidden[b, 1+p] = patch_out[b*np + p] + pos[1+p]
 __global__ void vision_assemble(const float *__restrict__ patch_out, const float *__restrict__ cls,
                                 const float *__restrict__ pos, float *__restrict__ hidden, int B, int T, int D) {
@@ -548,12 +586,12 @@ ssw_status pool_and_project(ssw_clip *c, const Tower &tw, int B, int D, int norm
     return SSW_OK;
 }
 
-ssw_status image_forward(ssw_clip *c, const float *pixels_dev, int B, int normalize, float *out_dev) {
+// c->patches holds the im2col'ed bf16 patches of B images
+ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *out_dev) {
     hipStream_t s = c->stream;
     const Header &h = c->hdr;
     const int g = h.image / h.patch, T = g * g + 1, D = h.v_hidden;
     const int pcols = 3 * h.patch * h.patch;
-    hipLaunchKernelGGL(im2col_patches, dim3(2048), dim3(256), 0, s, pixels_dev, c->patches, B, h.image, h.patch);
     SSW_TRY(gemm<EPI_F32>(s, c->patches, c->patch_w, nullptr, nullptr, c->patch_out, B * (T - 1), D, pcols));
     hipLaunchKernelGGL(vision_assemble, dim3(2048), dim3(256), 0, s, c->patch_out, c->cls, c->vpos, c->hidden2, B, T, D);
     hipLaunchKernelGGL(layernorm_rows<float>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->hidden2, (const int *)nullptr,
@@ -561,6 +599,20 @@ ssw_status image_forward(ssw_clip *c, const float *pixels_dev, int B, int normal
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
     hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
     return pool_and_project(c, c->vis, B, D, normalize, out_dev);
+}
+
+ssw_status image_forward(ssw_clip *c, const float *pixels_dev, int B, int normalize, float *out_dev) {
+    const Header &h = c->hdr;
+    hipLaunchKernelGGL(im2col_patches, dim3(2048), dim3(256), 0, c->stream, pixels_dev, c->patches, B, h.image, h.patch);
+    return image_forward_from_patches(c, B, normalize, out_dev);
+}
+
+// CLIP's pixel statistics (make_clip_transform, embeddings.py:405-419; batch_tx, multiscale_tools.py:176-179)
+ssw_status image_forward_u8(ssw_clip *c, const uint8_t *tiles_dev, int B, int normalize, float *out_dev) {
+    const Header &h = c->hdr;
+    hipLaunchKernelGGL(im2col_patches_u8, dim3(2048), dim3(256), 0, c->stream, tiles_dev, c->patches, B, h.image, h.patch,
+                       0.48145466f, 0.4578275f, 0.40821073f, 0.26862954f, 0.26130258f, 0.27577711f);
+    return image_forward_from_patches(c, B, normalize, out_dev);
 }
 
 ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int normalize, float *out_dev) {
@@ -671,6 +723,27 @@ ssw_status ssw_clip_embed_image(ssw_clip *c, const float *nchw_host, int32_t b, 
         SSW_HIP_TRY(hipMemcpyAsync(c->pixels, nchw_host + (size_t)b0 * per, (size_t)nb * per * sizeof(float),
                                    hipMemcpyHostToDevice, c->stream));
         SSW_TRY(image_forward(c, c->pixels, nb, normalize, c->out));
+        SSW_HIP_TRY(hipMemcpyAsync(out_host + (size_t)b0 * h.proj, c->out, (size_t)nb * h.proj * sizeof(float),
+                                   hipMemcpyDeviceToHost, c->stream));
+        SSW_HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SSW_OK;
+}
+
+ssw_status ssw_clip_embed_tiles_u8(ssw_clip *c, const uint8_t *tiles_hwc_host, int32_t b, int32_t normalize,
+                                   float *out_host) {
+    SSW_REQUIRE(c && tiles_hwc_host && out_host && b > 0, "bad argument");
+    DeviceGuard guard(c->device);
+    const Header &h = c->hdr;
+    SSW_REQUIRE(h.patch % 8 == 0, "clip: patch size %d is not a multiple of 8", h.patch);
+    const int chunk = 256;
+    SSW_TRY(reserve(c, std::min<int64_t>(b, chunk)));
+    const size_t per = (size_t)3 * h.image * h.image;  // bytes per tile; c->pixels (f32) is 4x that
+    for (int b0 = 0; b0 < b; b0 += chunk) {
+        const int nb = std::min(chunk, b - b0);
+        SSW_HIP_TRY(hipMemcpyAsync(c->pixels, tiles_hwc_host + (size_t)b0 * per, (size_t)nb * per, hipMemcpyHostToDevice,
+                                   c->stream));
+        SSW_TRY(image_forward_u8(c, reinterpret_cast<const uint8_t *>(c->pixels), nb, normalize, c->out));
         SSW_HIP_TRY(hipMemcpyAsync(out_host + (size_t)b0 * h.proj, c->out, (size_t)nb * h.proj * sizeof(float),
                                    hipMemcpyDeviceToHost, c->stream));
         SSW_HIP_TRY(hipStreamSynchronize(c->stream));

@@ -139,14 +139,19 @@ class MultiscaleIndex(AccessMethod):
     # ---- construction -----------------------------------------------------------------
     @staticmethod
     def from_path(index_path: str, *, use_vec_index=True, exclude=None, device: int = 0, **options):
-        """<index>/info.json {"constructor", "model", ...}; <index>/vectors.npy [N,512] f32;
-        <index>/vector_meta.parquet (dbidx, zoom_level, x1, y1, x2, y2), rows sorted by dbidx."""
+        """<index>/info.json {"constructor", "model", ...} plus either the reference's
+        <index>/vectors.sorted.cached parquet (as create_multiscale_index writes it) or
+        <index>/vectors.npy [N,512] f32 + <index>/vector_meta.parquet; rows sorted by dbidx."""
         index_path = resolve_path(index_path)
         info = json.load(open(f"{index_path}/info.json"))
         from ...models.embeddings import load_embedding
         embedding = load_embedding(info.get("model"), device=device)
-        vectors = np.load(f"{index_path}/vectors.npy", mmap_mode="r")
-        meta = pd.read_parquet(f"{index_path}/vector_meta.parquet").reset_index(drop=True)
+        if os.path.exists(f"{index_path}/vectors.sorted.cached"):  # the reference's on-disk layout (:242-260)
+            from .multiscale_tools import read_vector_parquet
+            meta, vectors = read_vector_parquet(f"{index_path}/vectors.sorted.cached")
+        else:
+            vectors = np.load(f"{index_path}/vectors.npy", mmap_mode="r")
+            meta = pd.read_parquet(f"{index_path}/vector_meta.parquet").reset_index(drop=True)
         meta = meta[["dbidx", "zoom_level", "x1", "y1", "x2", "y2"]]
         return MultiscaleIndex(embedding=embedding, vectors=np.asarray(vectors), vector_meta=meta,
                                vec_index=None, path=index_path,

@@ -95,6 +95,15 @@ class ClipModel:
                   ctypes.c_void_p(out.ctypes.data))
         return out
 
+    def embed_tiles_u8(self, tiles: np.ndarray, normalize: bool = True) -> np.ndarray:
+        """uint8 HWC tiles [B, S, S, 3] straight from the tiler; batch_tx's normalisation runs on the GPU."""
+        x = np.ascontiguousarray(tiles, dtype=np.uint8)
+        assert x.ndim == 4 and x.shape[1:] == (self.image_size, self.image_size, 3), x.shape
+        out = np.empty((x.shape[0], self.projection_dim), dtype=np.float32)
+        _lib.call("ssw_clip_embed_tiles_u8", self._h, ctypes.c_void_p(x.ctypes.data), x.shape[0], int(normalize),
+                  ctypes.c_void_p(out.ctypes.data))
+        return out
+
     def embed_image_dev(self, pixels_ptr: int, b: int, out_ptr: int, normalize: bool = True, stream_ptr: int = 0):
         _lib.call("ssw_clip_embed_image_dev", self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None,
                   ctypes.c_void_p(pixels_ptr), int(b), int(normalize), ctypes.c_void_p(out_ptr))

@@ -96,7 +96,8 @@ class SyntheticDataset:
     def knn_graph(self, name="exact") -> KNNGraph:
         if self._knng is None:
             assert self.knn_k > 0, "dataset built without a k-NN graph"
-            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=self.knn_k))
+            dev = getattr(self._index, "_dev", None) if self._index is not None else None  # matrix already resident
+            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=self.knn_k, device_index=dev))
         return self._knng
 
     def load_index(self, i_name=None, *, options=None):

@@ -82,3 +82,60 @@ def test_embedding_wrappers_and_batch_chunking(models):
     assert out.shape == (300, 512)
     again = ours.embed_image(x[280:290])
     assert np.array_equal(out[280:290], again)  # batch position does not change the result
+
+
+def test_u8_tiles_equal_host_batch_tx_path(models):
+    """ssw_clip_embed_tiles_u8 fuses batch_tx (multiscale_tools.py:167-183) into the patch gather: the
+    bf16 patches, hence the embeddings, are bit-identical to normalising on the host first."""
+    import pandas as pd
+    from seesaw_amd.indices.multiscale.multiscale_tools import batch_tx
+    _, ours = models
+    tiles = np.random.default_rng(4).integers(0, 256, size=(21, 224, 224, 3), dtype=np.uint8)
+    host = np.stack(batch_tx(pd.DataFrame({"tile": list(tiles)})).tile.values)
+    a = ours.embed_image(host, normalize=True)
+    b = ours.embed_tiles_u8(tiles, normalize=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_create_multiscale_index_round_trip(models, tmp_path):
+    """image bytes -> pyramid tiles -> GPU embedding -> the reference's on-disk layout -> from_path ->
+    a text query over it (multiscale_tools.py:225-261, multiscale_index.py:235-269)."""
+    import io
+    import json
+    import pandas as pd
+    import PIL.Image
+    from seesaw_amd.indices.multiscale.multiscale_index import MultiscaleIndex
+    from seesaw_amd.indices.multiscale.multiscale_tools import (create_multiscale_index, generate_multiscale_tiling,
+                                                                read_vector_parquet)
+    from seesaw_amd.models.embeddings import load_clip
+    rng = np.random.default_rng(9)
+    rows = []
+    for dbidx, (w, h) in enumerate([(640, 480), (224, 224), (500, 375), (448, 448)]):
+        buf = io.BytesIO()
+        PIL.Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(buf, format="PNG")
+        rows.append({"dbidx": dbidx, "file_path": f"img{dbidx}.png", "bytes": buf.getvalue()})
+    image_rows = pd.DataFrame(rows)
+    model = load_clip("clip-random-init")  # not a directory -> seeded random init; from_path reloads the same
+    path = create_multiscale_index(image_rows=image_rows, dataset_path=str(tmp_path), index_name="multiscale",
+                                   model=model, model_path="clip-random-init")
+    info = json.load(open(f"{path}/info.json"))
+    assert info["constructor"] == "seesaw.indices.multiscale.multiscale_index.MultiscaleIndex"
+    meta, vecs = read_vector_parquet(f"{path}/vectors.sorted.cached")
+    assert list(meta.columns[:3]) == ["dbidx", "file_path", "patch_id"]
+    for c in ("zoom_level", "x1", "y1", "x2", "y2", "scale_factor", "max_zoom_level"):
+        assert c in meta.columns
+    assert vecs.dtype == np.float32 and vecs.shape == (meta.shape[0], 512)
+    assert np.abs(np.linalg.norm(vecs, axis=1) - 1).max() < 1e-5
+    assert meta.dbidx.is_monotonic_increasing
+    counts = meta.groupby("dbidx").size().tolist()
+    assert counts[0] == 13 and counts[1] == 1  # 640x480 -> 13 tiles, 224x224 -> 1
+    # the stored vector of a tile is the embedding of that tile
+    im0 = PIL.Image.open(io.BytesIO(rows[0]["bytes"])).convert("RGB")
+    t0 = generate_multiscale_tiling(im0, factor=0.5, tile_size=224, min_tile_size=224)
+    again = model.embed_tiles_u8(np.stack(t0.tile.values), normalize=True)
+    assert np.array_equal(again.view(np.uint32), vecs[:13].view(np.uint32))
+    idx = MultiscaleIndex.from_path(path, use_vec_index=False)
+    assert idx.vectors.shape == vecs.shape and len(idx) == 4
+    res = idx.query(vector=idx.string2vec("a photo"), topk=2, shortlist_size=4, agg_method="plain_score",
+                    aug_larger="greater", rescore_method="plain")
+    assert len(res["dbidxs"]) == 2 and set(res["dbidxs"].tolist()) <= {0, 1, 2, 3}

@@ -1,0 +1,61 @@
+"""Host tiling logic (seesaw_amd.indices.multiscale.multiscale_tools) against the reference's own
+known answers: seesaw/indices/multiscale/test_multiscale_tools.py:60-89 (tile counts, strided tiles equal
+crops of the source) and the 13-tiles-per-COCO-image figure the configs rely on."""
+import numpy as np
+import PIL.Image
+import pytest
+
+from seesaw_amd.indices.multiscale.multiscale_tools import (batch_tx, generate_multiscale_tiling, pyramid,
+                                                            rearrange_into_tiles, reconstruct_patch, rescale,
+                                                            strided_tiling, tile_source_box)
+
+
+def make_test_image(b1, b2, seed=0):
+    rng = np.random.default_rng(seed)
+    h, w = int(round(b1 * 224)), int(round(b2 * 224))
+    return PIL.Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+
+
+def test_num_patches():
+    assert rearrange_into_tiles(make_test_image(3, 4), tile_size=224).shape[0] == 12
+    assert rearrange_into_tiles(make_test_image(3.3, 4.2), tile_size=224).shape[0] == 12
+    assert rearrange_into_tiles(make_test_image(1, 1), tile_size=224).shape[0] == 1
+
+
+def test_strided_tiles_are_crops_of_the_source():
+    img = make_test_image(3, 4)
+    d = strided_tiling(img, tile_size=224)
+    assert d.shape[0] == 12 + 3 * 3 + 2 * 4 + 2 * 3  # the four half-tile shifts
+    for i in range(d.shape[0]):
+        assert PIL.Image.fromarray(d.tile.values[i]) == reconstruct_patch(img, d.iloc[i])
+
+
+def test_full_pyramid_tile_count_and_contents():
+    img = make_test_image(2, 2)
+    d = generate_multiscale_tiling(img, factor=0.5, tile_size=224, min_tile_size=224)
+    assert d.shape[0] == 4 + 2 + 2 + 1 + 1  # the reference's expected count
+    assert d.patch_id.tolist() == list(range(10)) and d.max_zoom_level.nunique() == 1
+    assert d.zoom_level.dtype == np.int16 and d.x1.dtype == np.float32 and d.scale_factor.dtype == np.float32
+    for i in range(d.shape[0]):
+        row = d.iloc[i]
+        level = rescale(img, scale=float(row.scale_factor), min_size=224)
+        assert PIL.Image.fromarray(row.tile) == level.crop(tile_source_box(row))
+
+
+def test_coco_shape_gives_thirteen_tiles():
+    img = make_test_image(480 / 224, 640 / 224)  # 640 x 480
+    assert img.size == (640, 480)
+    d = generate_multiscale_tiling(img, factor=0.5, tile_size=224, min_tile_size=224)
+    assert d.shape[0] == 13
+    assert sorted(d.groupby("zoom_level").size().tolist()) == [1, 12]
+    p = pyramid(img, factor=0.5, abs_min=224)
+    assert min(p.image.iloc[0].size) == 224 and p.scale_factor.is_monotonic_increasing
+
+
+def test_batch_tx_is_clip_normalisation():
+    d = rearrange_into_tiles(make_test_image(1, 2), tile_size=224)
+    out = batch_tx(d)
+    x = np.stack(out.tile.values)
+    assert x.shape == (2, 3, 224, 224) and x.dtype == np.float32
+    ref = (d.tile.values[1].astype(np.float32)[5, 7, 2] / np.float32(255.0) - np.float32(0.40821073)) / np.float32(0.27577711)
+    assert x[1, 2, 5, 7] == np.float32(ref)
