@@ -165,7 +165,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
-#define SSW_GLDS16(gptr, lptr) glds16((gptr), (lptr))
+template <bool BUILTIN>
+__device__ __forceinline__ void glds16_sel(const void *gsrc, unsigned lds_dst) {
+    if constexpr (BUILTIN)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)(uintptr_t)lds_dst, 16, 0, 0);
+    else
+        glds16(gsrc, lds_dst);
+}
+#define SSW_GLDS16(gptr, lptr) glds16_sel<BUILTIN>((gptr), (lptr))
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -178,7 +186,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // TM rows x 128 columns per block, TM / 64 x 2 waves of 64 x 64 each (TM = 128: 4 waves, 256: 8)
-template <int EPI, int DEPTH, int TM, bool PIPE>
+template <int EPI, int DEPTH, int TM, bool PIPE, bool BUILTIN = false>
 __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
@@ -384,19 +392,19 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
 
 int g_gemm_variant = 2;
 
-template <int EPI, int DEPTH, int TM, bool PIPE = false>
+template <int EPI, int DEPTH, int TM, bool PIPE = false, bool BUILTIN = false>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
                        int M, int N, int K) {
     static bool attr_set = false;
     constexpr int lds = DEPTH * (TM * 128 + G_WIMG);
     if (!attr_set) {
-        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE>),
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE, BUILTIN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
+    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE, BUILTIN>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
                        m_tiles, n_tiles);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -418,6 +426,7 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
         case 6: return launch_glds<EPI, 2, 128, true>(s, A, W, bias, res, C, M, N, K);
         case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
         case 8: return launch_glds<EPI, 3, 256, true>(s, A, W, bias, res, C, M, N, K);
+        case 9: return launch_glds<EPI, 2, 128, false, true>(s, A, W, bias, res, C, M, N, K);
         default: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
     }
 }
@@ -477,7 +486,7 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant < 0 || variant > 8) {
+    if (variant < 0 || variant > 9) {
         ssw::set_error("ssw_tune_gemm: variant %d out of range", variant);
         return SSW_ERR_INVALID;
     }

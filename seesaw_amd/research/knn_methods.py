@@ -37,6 +37,7 @@ class BaseLabelPropagationRanker:
         self.sigmoid_before_propagate = sigmoid_before_propagate
         self.is_labeled = np.zeros(nvecs)
         self.labels = np.zeros(nvecs)
+        self._label_map = {}  # vector id -> label: the labelled set without O(nvecs) scans per round
         self.prior_scores = None
         self._current_scores = None
         self.all_indices = FrozenBitMap(range(nvecs))
@@ -50,7 +51,7 @@ class BaseLabelPropagationRanker:
         else:
             self.prior_scores = init_scores
         # nothing labelled yet: the prior is the score; otherwise propagate right away
-        if self.is_labeled.sum() == 0:
+        if not self._label_map:
             self._current_scores = self.prior_scores
         else:
             self._current_scores = self._propagate(self.prior_scores)
@@ -64,7 +65,8 @@ class BaseLabelPropagationRanker:
             assert np.isclose(label, 0) or np.isclose(label, 1)
             self.labels[int(idx)] = label
             self.is_labeled[int(idx)] = 1
-        has_negative = bool((self.labels[self.is_labeled > 0] == 0).any())
+            self._label_map[int(idx)] = label
+        has_negative = any(v == 0 for v in self._label_map.values())
         if has_negative:  # the reference skips propagation until a negative label exists
             print(" propagating")
             self._current_scores = self._propagate(self.prior_scores)
@@ -93,6 +95,6 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
                                    verbose=verbose, device=device)
 
     def _propagate(self, scores):
-        ids = np.nonzero(self.is_labeled.reshape(-1))[0]
+        ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))  # == nonzero(is_labeled)
         return self.lp.fit_transform(label_ids=ids, label_values=self.labels.reshape(-1)[ids],
                                      reg_values=self.prior_scores, start_value=scores)
