@@ -116,6 +116,29 @@ def feedback_loop_extras(device: int, full_images: int):
                          "cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])), "cpu_ms_per_iter": 1e3 * float(np.mean(c["latencies"])),
                          "iters": len(g["latencies"]), "cpu_iters_timed": len(c["latencies"]),
                          "hip_nfound": g["nfound"], "cpu_nfound": c["nfound"]}
+        if full:  # one label-propagation sweep against its HBM/L2 stream (12 B per non-zero + 40 B per node)
+            from seesaw_amd.knn_graph import get_weight_matrix, rbf_kernel
+            from seesaw_amd.label_propagation import LabelPropagation
+            with contextlib.redirect_stdout(io.StringIO()):
+                W = get_weight_matrix(ds.knn_graph().restrict_k(k=10).knn_df, kfun=rbf_kernel(0.05), self_edges=False,
+                                      normalized=False, symmetric=True)
+                lp = LabelPropagation(W, reg_lambda=1.0, max_iter=1, epsilon=-1.0, device=device)
+                prior = np.full(W.shape[0], 0.5)
+                ids, vals = np.arange(0, 1000, dtype=np.int64), (np.arange(1000) % 2).astype(np.float64)
+                lp.fit_transform(label_ids=ids, label_values=vals, reg_values=prior, start_value=prior)
+                t1 = time.perf_counter()
+                lp.fit_transform(label_ids=ids, label_values=vals, reg_values=prior, start_value=prior)
+                t1 = time.perf_counter() - t1
+                lp.max_iter = 201
+                t201 = time.perf_counter()
+                lp.fit_transform(label_ids=ids, label_values=vals, reg_values=prior, start_value=prior)
+                t201 = time.perf_counter() - t201
+                lp.close()
+            sweep_s = (t201 - t1) / 200.0
+            nbytes = 12.0 * W.nnz + 40.0 * W.shape[0]
+            res["labelprop_sweep"] = {"nodes": int(W.shape[0]), "nnz": int(W.nnz), "ms_per_sweep": 1e3 * sweep_s,
+                                      "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / sweep_s / 1e9,
+                                      "frac_of_hbm_peak": nbytes / sweep_s / 1e9 / HBM_PEAK_GBS}
         out[tag] = res
         idx = ds.load_index()
         idx._dev.close()
@@ -152,7 +175,20 @@ def clip_extras(device: int):
         m.embed_text(ids)
     dtt = (time.perf_counter() - t0) / n
     m.close()
-    return {"image_batch": B, "image_ms_per_batch": dt * 1e3, "tiles_per_s": B / dt, "tflops": tf,
+    # CPU side by side: the in-container transformers.CLIPModel, f32, torch-CPU,
+    # all host threads, same random-init weights, on a bounded sample of 16 tiles
+    import transformers
+    torch.manual_seed(1234)
+    hf = transformers.CLIPModel(transformers.CLIPConfig()).eval()
+    xc = torch.randn(16, 3, 224, 224)
+    with torch.inference_mode():
+        hf.get_image_features(pixel_values=xc[:2])
+        t0 = time.perf_counter()
+        hf.get_image_features(pixel_values=xc)
+        dtc = time.perf_counter() - t0
+    cpu = {"tiles_per_s": 16 / dtc, "sample": "16 tiles, transformers.CLIPModel f32, torch-CPU", "threads": torch.get_num_threads(),
+           "seconds": dtc}
+    return {"cpu_baseline": cpu, "image_batch": B, "image_ms_per_batch": dt * 1e3, "tiles_per_s": B / dt, "tflops": tf,
             "mfma_peak_tflops": 2500.0, "frac_of_bf16_dense_peak": tf / 2500.0,
             "text_batch": 16, "text_len": 77, "text_ms_per_batch_host_io": dtt * 1e3, "texts_per_s": 16 / dtt,
             "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}

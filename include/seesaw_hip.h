@@ -291,7 +291,7 @@ ssw_status ssw_clip_sync(ssw_clip *clip);
  * launches and the max |difference| to variant 0.  Not part of the reference's interface. */
 ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
                           float *out_ms, float *out_maxdiff);
-/* Selects the GEMM variant the towers use (0 register-staged, 1..3 LDS-DMA ring depth). */
+/* Selects the GEMM variant the towers use (0 register-staged, 2 LDS-DMA ring [default], 7 256-row pipelined). */
 ssw_status ssw_tune_gemm(int32_t variant);
 
 #ifdef __cplusplus

@@ -5,7 +5,7 @@
 // Replaces the torch/cuBLAS linears inside transformers' CLIPModel that the reference calls
 // (seesaw/models/embeddings.py:42-76 -> CLIPVisionModel / CLIPTextModel layers).
 //
-// variant 1..3 (default 2): LDS-DMA pipeline.  A 128x128 tile per 256-thread block, BK = 64:
+// variant 2 (default): LDS-DMA pipeline.  A 128x128 tile per 256-thread block, BK = 64:
 //   * staging is global_load_lds_dwordx4 only (no VGPR round trip): one wave-instruction fills
 //     8 rows x 128 B of the LDS image, lane-linear, reading whole 128-B lines;
 //   * the image is XOR-swizzled through the SOURCE address (16-B chunk c of row r sits at chunk
@@ -17,7 +17,11 @@
 //     row and the epilogue stores 8 B (bf16) / 16 B (f32) per lane with float4 bias / residual;
 //   * blocks that share an XCD (linear id % 8) walk whole row-tiles of A, so an A tile is pulled
 //     into one L2 only.
-// variant 0 is the first register-staged kernel, kept for A/B runs (ssw_debug_gemm).
+// variant 0 is the first register-staged kernel, kept as the A/B reference of ssw_debug_gemm; variant 7 is the
+// 256 x 128 tile, 8-wave, software-pipelined form (fragments of the next half K-step are read while the current
+// one multiplies, barrier between the two MFMA blocks): +2 % at K = 3072, -7 % at K = 768, so not the default.
+// Measured and dropped: one LDS buffer with two barriers (-5...-25 %), a 3-stage ring at one workgroup per CU
+// (-20 %), 256-row tiles without the pipelined loop (-6 %), the pipelined loop on 128-row tiles (-7 %).
 #include "ssw_common.h"
 
 namespace ssw {
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
 
 
 // ---------------------------------------------------------------------------------------
-// variants 1..3: LDS-DMA ring (DEPTH = 1 keeps one buffer and two barriers per k-step)
+// LDS-DMA ring kernel (DEPTH = 1 would keep one buffer and two barriers per k-step)
 // ---------------------------------------------------------------------------------------
 constexpr int G_WIMG = 16384;  // W image: 128 rows x 128 B
 
@@ -419,14 +423,7 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
                                M, N, K);
             SSW_HIP_TRY(hipGetLastError());
             return SSW_OK;
-        case 1: return launch_glds<EPI, 1, 128>(s, A, W, bias, res, C, M, N, K);
-        case 3: return launch_glds<EPI, 3, 128>(s, A, W, bias, res, C, M, N, K);
-        case 4: return launch_glds<EPI, 2, 256>(s, A, W, bias, res, C, M, N, K);
-        case 5: return launch_glds<EPI, 3, 256>(s, A, W, bias, res, C, M, N, K);
-        case 6: return launch_glds<EPI, 2, 128, true>(s, A, W, bias, res, C, M, N, K);
         case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
-        case 8: return launch_glds<EPI, 3, 256, true>(s, A, W, bias, res, C, M, N, K);
-        case 9: return launch_glds<EPI, 2, 128, false, true>(s, A, W, bias, res, C, M, N, K);
         default: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
     }
 }
@@ -486,8 +483,8 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant < 0 || variant > 9) {
-        ssw::set_error("ssw_tune_gemm: variant %d out of range", variant);
+    if (variant != 0 && variant != 2 && variant != 7) {
+        ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
         return SSW_ERR_INVALID;
     }
     ssw::tune_gemm(variant);

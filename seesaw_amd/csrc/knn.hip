@@ -25,8 +25,9 @@
 // Error bound E_i: fp16 rounding is <= 2^-11 relative per operand (scaled components lie in
 // [2^-14, 256), values below 2^-14 may be flushed), so the product sum differs from the exact one by
 // at most (2^-10 + 2^-22) sum|x_d y_d| <= 2^-10 |x||y|; the f32 accumulation of 512 terms adds
-// <= 512 * 2^-24 |x||y| on either side and the flushed tail <= 2^-21 maxabs sqrt(D) |y|.  E_i is set to
-// 1.2e-3 |x_i| max|x| + 1e-5 max|x|^2, which covers all of it with margin.
+// <= 512 * 2^-23 |x||y| on either side (truncating adds assumed) and the flushed tails <= 2^-21 maxabs sqrt(D)
+// (|x_i| + max|x|) <= 1.1e-5 (|x_i| + max|x|) max|x| for D <= 1024... E_i is set to
+// 1.2e-3 |x_i| max|x| + 2.5e-5 max|x|^2, which covers all of it with margin.
 //
 // Roofline: MFMA-bound (2 N^2 d flop, fp16 dense peak 2.5 PFLOP/s); operand traffic per 128^2 tile is
 // 256 KB out of L2, i.e. the same L2 -> LDS ceiling as the tower GEMM.
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void k_knn_stats(const float *__restrict__ X, 
         mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     }
     if (lane == 0) {
-        const float nr = sqrtf(ss) * 1.000001f;  // upper bound of the norm
+        const float nr = sqrtf(ss) * 1.0001f;  // upper bound of the norm (f32 sum of squares: ~3e-5 relative)
         norms[r] = nr;
         atomicMax(&maxima[0], __float_as_uint(mx));  // non-negative floats order like their bits
         atomicMax(&maxima[1], __float_as_uint(nr));

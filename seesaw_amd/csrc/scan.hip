@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
     const float s_k1 = __shfl(score, k1 - 1, 64);
     const float b = __shfl(approx, M - 1, 64) * inv_scale2;  // meaningful when c == M
     if (lane == 0) {
-        const float E = 1.2e-3f * norms[orig_i] * maxnorm + 1e-5f * maxnorm * maxnorm;
+        const float E = 1.2e-3f * norms[orig_i] * maxnorm + 2.5e-5f * maxnorm * maxnorm;
         const bool cert = !overflow[w] && (c < M || (s_k1 - E > b));
         out_cert[orig_i] = cert ? 1 : 0;
     }
