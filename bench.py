@@ -56,10 +56,12 @@ def cpu_baseline(local_index, k, sample_rows, n_queries):
     }
 
 
-def feedback_loop_extras(device: int, full_images: int):
+def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
     """seesaw_bench feedback-loop iterations / s (1 / mean(latencies), seesaw_bench.py:310,352)
     on the LVIS-shape synthetic datasets (BASELINE config C5), HIP path next to the CPU oracle
-    (numpy / scipy / torch-CPU, the reference's own expressions) in the same run."""
+    (numpy / scipy / torch-CPU, the reference's own expressions) in the same run.
+    with_cpu=False (ranks of an N > 1 run: every GPU runs its own replica of the sessions, the way
+    seesaw_bench's parallel_run spreads sessions over actors) skips the CPU side and the sweep timing."""
     import numpy as np
     from oracle import cpu_loop
     from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
@@ -107,16 +109,20 @@ def feedback_loop_extras(device: int, full_images: int):
                     ret = make_session(gdm, p, b=b)
                     np.random.seed(0)
                     g = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+                res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
+                             "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])), "iters": len(g["latencies"]),
+                             "hip_nfound": g["nfound"]}
+                if not with_cpu:
+                    continue
                 qvec = ds.load_index().string2vec("a c1")
                 # bounded CPU sample: scipy label propagation over 1.56 M nodes takes seconds per round
                 cpu_rounds = 4 if (full and name == "knn_prop2") else 30
                 c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=cpu_rounds,
                                          max_results=10 ** 6, knn_df=ds.knn_graph().restrict_k(k=10).knn_df if knn_k else None)
-            res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])), "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])),
-                         "cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])), "cpu_ms_per_iter": 1e3 * float(np.mean(c["latencies"])),
-                         "iters": len(g["latencies"]), "cpu_iters_timed": len(c["latencies"]),
-                         "hip_nfound": g["nfound"], "cpu_nfound": c["nfound"]}
-        if full:  # one label-propagation sweep against its HBM/L2 stream (12 B per non-zero + 40 B per node)
+            res[name].update({"cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])),
+                              "cpu_ms_per_iter": 1e3 * float(np.mean(c["latencies"])),
+                              "cpu_iters_timed": len(c["latencies"]), "cpu_nfound": c["nfound"]})
+        if full and with_cpu:  # one label-propagation sweep against its HBM/L2 stream (12 B per non-zero + 40 B per node)
             from seesaw_amd.knn_graph import get_weight_matrix, rbf_kernel
             from seesaw_amd.label_propagation import LabelPropagation
             with contextlib.redirect_stdout(io.StringIO()):
@@ -271,6 +277,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # N > 1: the feedback loop does not shard (its scans are sub-millisecond at LVIS scale); every GPU runs
+    # its own replica of the benchmark sessions, as seesaw_bench.parallel_run spreads sessions over actors.
+    # Every rank takes part in the gather even if its replica failed.
+    replicas = None
+    if world > 1 and not args.no_extras:
+        index.close()  # free the shard before the loop datasets move in
+        try:
+            mine = feedback_loop_extras(local_rank, args.loop_images, with_cpu=False)
+        except Exception as e:
+            mine = {"error": f"{type(e).__name__}: {e}"}
+        replicas = [None] * world
+        dist.all_gather_object(replicas, mine)
+
     if rank == 0:
         n_local = index.n_local
         avg_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
@@ -329,6 +348,20 @@ def main():
                 except Exception as e:  # the headline metric above stands on its own
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
             out["extras"] = extras
+        if replicas is not None:
+            agg = {}
+            for rep in replicas:
+                for tag, res in (rep or {}).items():
+                    if not isinstance(res, dict):
+                        continue
+                    for name, v in res.items():
+                        if isinstance(v, dict) and "hip_iters_per_s" in v:
+                            a = agg.setdefault(tag, {}).setdefault(name, {"iters_per_s_all_gpus": 0.0, "per_gpu": []})
+                            a["iters_per_s_all_gpus"] += v["hip_iters_per_s"]
+                            a["per_gpu"].append(v["hip_iters_per_s"])
+            out["extras"] = {"feedback_loop_replicas": {"scaling": "replicas only (no data-path collective)", "gpus": world,
+                                                        "aggregate": agg,
+                                                        "errors": [r["error"] for r in replicas if isinstance(r, dict) and "error" in r]}}
         print(json.dumps(out), flush=True)
     index.close()
     if dist is not None:
