@@ -11,12 +11,15 @@
 //                   compares the accumulators with a per-row threshold and appends the few survivors
 //                   (score, column) to a per-row buffer.
 //   2. thresholds   columns are visited in a random order (seeded permutation) in geometrically growing
-//                   levels; after each level a per-row LDS bitonic sort keeps the best M = 32 entries and
+//                   levels (512, x <= 16, ..., N); after each level a per-row LDS bitonic sort keeps the best M = 32 entries and
 //                   raises the row's threshold to the M-th score, so a level appends ~ M x ratio
 //                   entries per row whatever the data looks like (exchangeability of the permutation).
 //   3. exact scores the <= M candidates of every row are re-scored in f32 in the scan kernel's fixed
 //                   summation order (scan.hip), sorted by (score desc, row id asc), and the best k+1
 //                   are returned -- the same bits and order as a brute-force scan of that row.
+//   (symmetry)    S~ is symmetric: when the buffers of all rows fit in HBM at once, the last level -- 97 % of
+//                   the work -- computes only the tiles J >= I and an off-diagonal tile feeds both its rows
+//                   and its columns; the earlier levels (thresholds for every row) stay rectangular.
 //   4. certificate  a column outside the candidate list has fp16-path score <= b (the M-th kept), and
 //                   |fp16-path - exact| <= E_i (derived below), so the row is PROVEN exact when
 //                   exact(k+1-th) - E_i > b.  Rows that fail (or whose buffer overflowed) are flagged;
@@ -33,6 +36,7 @@
 // 256 KB out of L2, i.e. the same L2 -> LDS ceiling as the tower GEMM.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ssw_common.h"
@@ -45,7 +49,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int KNN_M = 32;       // candidates kept per row between levels
-constexpr int KNN_CAP = 4096;   // row buffer capacity (entries appended within one level + M)
+constexpr int KNN_CAP = 1024;   // row buffer capacity: entries appended within one level (~ M x ratio <= 512) + M
 constexpr int KT = 128;         // tile edge
 constexpr int KBK = 64;         // k-step
 constexpr int K_OPER = 16384;   // one operand image: 128 rows x 128 B
@@ -95,11 +99,12 @@ __global__ void k_knn_convert(const float *__restrict__ X, const int32_t *__rest
     }
 }
 
+// rows_padded - rows trailing entries get thr = +inf (nothing is ever appended to them)
 __global__ void k_knn_reset(float *__restrict__ thr, unsigned *__restrict__ cnt, unsigned char *__restrict__ overflow,
-                            int rows) {
+                            int rows, int rows_padded) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < rows) {
-        thr[i] = -INFINITY;
+    if (i < rows_padded) {
+        thr[i] = i < rows ? -INFINITY : INFINITY;
         cnt[i] = 0;
         overflow[i] = 0;
     }
@@ -116,24 +121,47 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-// rows [r0, r1) of Xh against columns [c0, c1) of Xh; thr / cnt / buf are indexed by row - r0
+// rows [r0, r1) of Xh against columns [c0, c1) of Xh; thr / cnt / buf are indexed by row - r0.
+// SYM (r0 = c0 = 0, r1 = c1 = n): S~ is symmetric, so only tiles J >= I of the square are computed and an
+// off-diagonal tile serves both its rows (entries (i, j)) and its columns (entries (j, i)); tiles whose
+// columns all lie below tile index `mirror_from` were covered by the earlier (non-symmetric) levels and are
+// skipped, and the mirrored entries of tiles with I < mirror_from likewise.
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__ Xh, int D, int r0, int r1, int c0,
                                                          int c1, const float *__restrict__ thr,
                                                          unsigned *__restrict__ cnt, uint64_t *__restrict__ buf,
-                                                         int i_tiles, int j_tiles, int sj_count, int n_super) {
+                                                         int i_tiles, int j_tiles, int sj_count, int n_super,
+                                                         int mirror_from) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // 8 x 8 super-tiles dealt round-robin to the XCDs (block ids b and b + 8 share an XCD): the 64
     // tiles of a super-tile run on one XCD and share 2 x 8 operand panels through its L2
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int g = (local >> 6) * 8 + xcd;
-    if (g >= n_super) return;
-    const int within = local & 63;
-    const int I = (g / sj_count) * 8 + (within >> 3), J = (g % sj_count) * 8 + (within & 7);
+    // (the grid is two-dimensional only because one dimension is limited to 2^32 work-items)
+    const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    if ((local >> 6) * 8 + xcd >= n_super) return;
+    const int g = (int)(local >> 6) * 8 + xcd;
+    const int within = (int)(local & 63);
+    int SI, SJ;
+    if (SYM) {  // g enumerates the super-tile pairs SI <= SJ row by row: row SI starts at SI*ns - SI(SI-1)/2
+        const int ns = sj_count;
+        const double b = 2.0 * ns + 1.0;
+        SI = (int)((b - sqrt(b * b - 8.0 * (double)g)) * 0.5);
+        SI = max(0, min(SI, ns - 1));
+        while (SI > 0 && SI * ns - SI * (SI - 1) / 2 > g) --SI;
+        while (SI + 1 < ns && (SI + 1) * ns - (SI + 1) * SI / 2 <= g) ++SI;
+        SJ = SI + (g - (SI * ns - SI * (SI - 1) / 2));
+    } else {
+        SI = g / sj_count;
+        SJ = g % sj_count;
+    }
+    const int I = SI * 8 + (within >> 3), J = SJ * 8 + (within & 7);
     if (I >= i_tiles || J >= j_tiles) return;
+    if (SYM && (J < I || J < mirror_from)) return;
+    const bool mirror = SYM && I != J && I >= mirror_from;
     const int m0 = r0 + I * KT, n0 = c0 + J * KT;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -216,6 +244,29 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
                         if (pos < (unsigned)KNN_CAP)
                             buf[(int64_t)lrow * KNN_CAP + pos] =
                                 ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)(col + r));
+                    }
+                }
+            }
+        }
+    }
+    if (mirror) {  // entry (j, i) of the symmetric matrix: this tile's columns as rows, its rows as columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
+            const f32x4 tc = *reinterpret_cast<const f32x4 *>(thr + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = acc[i][j];
+                const int row = m0 + wm * 64 + i * 16 + fr;
+                if (row < r1 && (v[0] > tc[0] || v[1] > tc[1] || v[2] > tc[2] || v[3] > tc[3])) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (v[r] > tc[r]) {
+                            const unsigned pos = atomicAdd(&cnt[col + r], 1u);
+                            if (pos < (unsigned)KNN_CAP)
+                                buf[(int64_t)(col + r) * KNN_CAP + pos] =
+                                    ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)row);
+                        }
                     }
                 }
             }
@@ -333,15 +384,23 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
 #define KNN_HIP(expr)                                             \
     if (hipError_t _e = (expr); _e != hipSuccess) return fail(_e, #expr)
 
-    const int64_t RB = std::min<int64_t>(n, 131072);  // rows per batch (buffer RB x CAP x 8 B = 4.3 GB)
+    // All rows at once (symmetric last level, half the matrix work) when their buffers fit comfortably,
+    // otherwise batches of 131072 rows against every column (buffer 4.3 GB per batch).
+    size_t free_b = 0, total_b = 0;
+    KNN_HIP(hipMemGetInfo(&free_b, &total_b));
+    const char *force = getenv("SSW_KNN_FORCE_BATCHED");
+    const bool sym = n > 512 && !(force && force[0] == '1') &&
+                     (double)n * (KNN_CAP * 8.0 + D * 2.0 + 64.0) < 0.6 * (double)free_b;
+    const int64_t RB = sym ? n : std::min<int64_t>(n, 131072);
+    const int64_t RBP = (RB + KT - 1) / KT * KT;
     KNN_HIP(hipMalloc((void **)&sc.perm, (size_t)n * 4));
     KNN_HIP(hipMalloc((void **)&sc.norms, (size_t)n * 4));
     KNN_HIP(hipMalloc((void **)&sc.maxima, 8));
     KNN_HIP(hipMalloc((void **)&sc.Xh, (size_t)n * D * 2));
-    KNN_HIP(hipMalloc((void **)&sc.thr, (size_t)RB * 4));
-    KNN_HIP(hipMalloc((void **)&sc.cnt, (size_t)RB * 4));
-    KNN_HIP(hipMalloc((void **)&sc.overflow, (size_t)RB));
-    KNN_HIP(hipMalloc((void **)&sc.buf, (size_t)RB * KNN_CAP * 8));
+    KNN_HIP(hipMalloc((void **)&sc.thr, (size_t)RBP * 4));
+    KNN_HIP(hipMalloc((void **)&sc.cnt, (size_t)RBP * 4));
+    KNN_HIP(hipMalloc((void **)&sc.overflow, (size_t)RBP));
+    KNN_HIP(hipMalloc((void **)&sc.buf, (size_t)RBP * KNN_CAP * 8));
     KNN_HIP(hipMalloc((void **)&sc.out_dst, (size_t)n * k1 * 4));
     KNN_HIP(hipMalloc((void **)&sc.out_score, (size_t)n * k1 * 4));
     KNN_HIP(hipMalloc((void **)&sc.out_cert, (size_t)n));
@@ -372,42 +431,69 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     const float scale = std::ldexp(1.0f, 8 - e2);  // scale * maxabs in [128, 256)
     hipLaunchKernelGGL(k_knn_convert, dim3(4096), dim3(256), 0, s, X, sc.perm, n, (int)D, scale, sc.Xh);
     KNN_HIP(hipGetLastError());
-    KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter),
+    KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
+    KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
 
-    // level boundaries over the permuted columns: 1024, then a constant ratio <= 40 up to n
+    // level boundaries over the permuted columns (multiples of the tile edge): 512, then a constant
+    // ratio <= 16 up to n: a level appends ~ M x ratio <= 512 entries per row (+- 90), the buffers hold 1024
     std::vector<int64_t> bounds;
     {
-        const int64_t b0 = std::min<int64_t>(n, 1024);
+        const int64_t b0 = std::min<int64_t>(n, 512);
         bounds.push_back(b0);
         if (n > b0) {
             const double span = (double)n / (double)b0;
-            const int levels = std::max(1, (int)std::ceil(std::log(span) / std::log(40.0)));
+            const int levels = std::max(1, (int)std::ceil(std::log(span) / std::log(16.0)));
             const double ratio = std::pow(span, 1.0 / levels);
-            for (int l = 1; l < levels; ++l)
-                bounds.push_back(std::min<int64_t>(n, (int64_t)std::llround((double)b0 * std::pow(ratio, l))));
+            for (int l = 1; l < levels; ++l) {
+                const int64_t b = (int64_t)std::llround((double)b0 * std::pow(ratio, l));
+                bounds.push_back(std::min<int64_t>(n, (b + KT - 1) / KT * KT));
+            }
             bounds.push_back(n);
         }
     }
     for (int64_t r0 = 0; r0 < n && rc == SSW_OK; r0 += RB) {
         const int64_t r1 = std::min(n, r0 + RB);
         const int rows = (int)(r1 - r0);
-        hipLaunchKernelGGL(k_knn_reset, dim3((rows + 255) / 256), dim3(256), 0, s, sc.thr, sc.cnt, sc.overflow, rows);
+        const int rows_padded = (rows + KT - 1) / KT * KT;
+        hipLaunchKernelGGL(k_knn_reset, dim3((rows_padded + 255) / 256), dim3(256), 0, s, sc.thr, sc.cnt, sc.overflow, rows,
+                           rows_padded);
         int64_t c0 = 0;
-        for (int64_t c1 : bounds) {
+        for (size_t li = 0; li < bounds.size(); ++li) {
+            const int64_t c1 = bounds[li];
             if (c1 <= c0) continue;
-            const int i_tiles = (rows + KT - 1) / KT, j_tiles = (int)((c1 - c0 + KT - 1) / KT);
-            const int si = (i_tiles + 7) / 8, sj = (j_tiles + 7) / 8;
-            const int64_t n_super = (int64_t)si * sj;
-            const int64_t grid = ((n_super + 7) / 8) * 8 * 64;
-            if (grid >= (int64_t)0x7fffffff) {
+            const bool last_sym = sym && li + 1 == bounds.size() && li > 0;
+            const int i_tiles = (rows + KT - 1) / KT;
+            int j_tiles, sj;
+            int64_t n_super;
+            if (last_sym) {  // upper triangle of the whole square; columns below c0 were done by the levels above
+                j_tiles = i_tiles;
+                sj = (i_tiles + 7) / 8;
+                n_super = (int64_t)sj * (sj + 1) / 2;
+            } else {
+                j_tiles = (int)((c1 - c0 + KT - 1) / KT);
+                sj = (j_tiles + 7) / 8;
+                n_super = (int64_t)((i_tiles + 7) / 8) * sj;
+            }
+            const int64_t blocks = ((n_super + 7) / 8) * 8 * 64;
+            // a grid dimension holds < 2^32 work-items (16.7 M workgroups of 256): fold the rest into y
+            const int64_t gx = std::min<int64_t>(blocks, 1 << 22), gy = (blocks + gx - 1) / gx;
+            if (n_super >= (int64_t)0x7fffffff || gy > 65535) {
                 set_error("ssw_knn_build: level of %lld x %lld tiles exceeds one launch", (long long)i_tiles,
                           (long long)j_tiles);
                 rc = SSW_ERR_UNSUPPORTED;
                 break;
             }
-            hipLaunchKernelGGL(k_knn_gemm_filter, dim3((unsigned)grid), dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D, (int)r0,
-                               (int)r1, (int)c0, (int)c1, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj, (int)n_super);
+            const dim3 grid((unsigned)gx, (unsigned)gy);
+            if (last_sym)
+                hipLaunchKernelGGL(k_knn_gemm_filter<true>, grid, dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D, 0,
+                                   (int)n, 0, (int)n, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj, (int)n_super,
+                                   (int)(c0 / KT));
+            else
+                hipLaunchKernelGGL(k_knn_gemm_filter<false>, grid, dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D,
+                                   (int)r0, (int)r1, (int)c0, (int)c1, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj,
+                                   (int)n_super, 0);
             hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows);
             c0 = c1;
         }

@@ -66,8 +66,13 @@ def test_compute_exact_knn_vs_reference_golden(oracle):
     assert np.all(np.abs(df.distance.values[differs] - g["dist"][differs]) <= 1e-6) and differs.mean() < 0.01
 
 
-def test_knn_two_hundred_thousand_rows_spot_checked(oracle):
-    """three column levels, two row batches; 64 rows checked bit for bit against full CPU scans"""
+@pytest.mark.parametrize("batched", [False, True])
+def test_knn_two_hundred_thousand_rows_spot_checked(oracle, monkeypatch, batched):
+    """three column levels; the symmetric all-rows-at-once path and the batched rectangular path (two row
+    batches, what a graph too large for HBM-resident buffers takes); 68 rows checked bit for bit against
+    full CPU scans"""
+    if batched:
+        monkeypatch.setenv("SSW_KNN_FORCE_BATCHED", "1")
     n, k = 200_000, 10
     X = oracle.synth_rows(77, 0, n, 512)
     rows = np.random.default_rng(3).integers(0, n, size=64).tolist() + [0, n - 1, 131071, 131072]
