@@ -389,7 +389,7 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     size_t free_b = 0, total_b = 0;
     KNN_HIP(hipMemGetInfo(&free_b, &total_b));
     const char *force = getenv("SSW_KNN_FORCE_BATCHED");
-    const bool sym = n > 512 && !(force && force[0] == '1') &&
+    const bool sym = n > 512 && n <= 8000000 && !(force && force[0] == '1') &&  // (one workgroup per row in k_knn_compact)
                      (double)n * (KNN_CAP * 8.0 + D * 2.0 + 64.0) < 0.6 * (double)free_b;
     const int64_t RB = sym ? n : std::min<int64_t>(n, 131072);
     const int64_t RBP = (RB + KT - 1) / KT * KT;
