@@ -57,6 +57,14 @@ __global__ void k_fb_center(float *__restrict__ X, int64_t n, int dim, float *__
 }
 
 // ---- per-evaluation kernels -----------------------------------------------------------
+// Parameters of one closure evaluation, passed BY VALUE in the kernel-argument segment: the driver
+// changes them every evaluation, and a separate 2-KB host-to-device copy per evaluation costs more
+// than the kernels it feeds.  (dim <= 768; larger dims take the device buffer.)
+constexpr int FB_ARG_FLOATS = 772;
+struct FbW {
+    float v[FB_ARG_FLOATS];
+};
+
 // z_i = <x_i, w> + b ; one wave per row
 __global__ __launch_bounds__(256) void k_fb_logits(const float *__restrict__ X,
                                                    const float *__restrict__ w, int64_t n, int dim,
@@ -99,6 +107,40 @@ __global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__
     const double lw = 1.0 + ((double)pw - 1.0) * yi;
     item_loss[i] = ci * ((1.0 - yi) * zi + lw * softplus_neg(zi));
     r[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+}
+
+// k_fb_logits with the parameters in the argument segment and, when `elem` is set, k_fb_elem folded in
+// (same expressions, same order: the results are bit-identical to the two-kernel form)
+__global__ __launch_bounds__(256) void k_fb_logits_arg(const float *__restrict__ X, FbW wv, int64_t n, int dim,
+                                                       int has_bias, float *__restrict__ z, int elem,
+                                                       const float *__restrict__ y, const float *__restrict__ coef,
+                                                       float pw, double *__restrict__ item_loss,
+                                                       float *__restrict__ r) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float4 *x4 = reinterpret_cast<const float4 *>(X + row * dim);
+    const float4 *w4 = reinterpret_cast<const float4 *>(wv.v);
+    float a = 0.f;
+    for (int c = lane; c < dim / 4; c += 64) {
+        const float4 xv = x4[c], wq = w4[c];
+        a = fmaf(xv.x, wq.x, a);
+        a = fmaf(xv.y, wq.y, a);
+        a = fmaf(xv.z, wq.z, a);
+        a = fmaf(xv.w, wq.w, a);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) {
+        const float zf = a + (has_bias ? wv.v[dim] : 0.f);
+        z[row] = zf;
+        if (elem) {
+            const double zi = zf, yi = y[row], ci = coef[row];
+            const double lw = 1.0 + ((double)pw - 1.0) * yi;
+            item_loss[row] = ci * ((1.0 - yi) * zi + lw * softplus_neg(zi));
+            r[row] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+        }
+    }
 }
 
 // pairwise losses over all ordered pairs (i, j), t_ij = sign(y_i - y_j), s_ij = z_i - z_j:
@@ -183,7 +225,7 @@ struct FbObjDev {
 __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ partial, int nslabs,
                                                    const double *__restrict__ item_loss,
                                                    const float *__restrict__ r, int64_t n, int dim,
-                                                   const float *__restrict__ w,
+                                                   const float *__restrict__ w_or_null, FbW wv,
                                                    const float *__restrict__ qhat,
                                                    const float *__restrict__ xlx, FbObjDev obj,
                                                    float *__restrict__ out, double *__restrict__ out_loss) {
@@ -192,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
     __shared__ double scal[8];
     const int c = threadIdx.x;
     const bool act = c < dim;
-    const float wc = act ? w[c] : 0.f;
+    const float wc = act ? (w_or_null ? w_or_null[c] : wv.v[c < FB_ARG_FLOATS ? c : 0]) : 0.f;
     if (act) sw_[c] = wc;
     // data gradient
     float g = 0.f;
@@ -302,6 +344,8 @@ struct ssw_fb {
     bool has_q = false, has_xlx = false;
     float *out = nullptr;      // device [1 + dim + 1 + 4]
     float *out_host = nullptr;  // pinned mirror
+    float *out_host_dev = nullptr;     // the same memory through the device's address space
+    double *loss_host_dev = nullptr;
     float *w_host = nullptr;    // pinned staging
     hipStream_t stream = nullptr;
     // targets (host copies, for the objective set-up)
@@ -427,15 +471,28 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     hipStream_t s = fb->stream;
     const int64_t n = fb->n;
     const int dim = fb->dim;
-    SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)P * sizeof(float), hipMemcpyHostToDevice, s));
+    const bool by_arg = dim + 1 <= FB_ARG_FLOATS;
+    FbW wv;
+    if (by_arg) {
+        memcpy(wv.v, fb->w_host, (size_t)P * sizeof(float));
+        for (int i = P; i < FB_ARG_FLOATS; ++i) wv.v[i] = 0.f;
+    } else {
+        SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)P * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     int nslabs = 0;
     if (n > 0) {
-        hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->w, n, dim,
-                           dev.has_bias, fb->z);
         const bool pairwise = o->kind == SSW_FB_MULTIREG && o->loss_type != SSW_FB_LOSS_CE;
+        nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
+        if (by_arg)
+            hipLaunchKernelGGL(k_fb_logits_arg, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, wv, n, dim,
+                               dev.has_bias, fb->z, pairwise ? 0 : 1, fb->y, fb->coef, pw, fb->item, fb->r);
+        else
+            hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->w, n, dim,
+                               dev.has_bias, fb->z);
         if (!pairwise) {
-            hipLaunchKernelGGL(k_fb_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->z, fb->y, fb->coef,
-                               pw, n, fb->item, fb->r);
+            if (!by_arg)
+                hipLaunchKernelGGL(k_fb_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->z, fb->y, fb->coef,
+                                   pw, n, fb->item, fb->r);
         } else if (pairwise_active) {
             const size_t lds = (size_t)3 * n * sizeof(float);
             if (o->loss_type == SSW_FB_LOSS_PAIRWISE_LOGISTIC)
@@ -448,18 +505,19 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
             SSW_HIP_TRY(hipMemsetAsync(fb->item, 0, (size_t)n * sizeof(double), s));
             SSW_HIP_TRY(hipMemsetAsync(fb->r, 0, (size_t)n * sizeof(float), s));
         }
-        nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
+        // (folding this into the logits kernel, one 32-row slab per workgroup, was measured: fewer, longer
+        // workgroups cost more than the launch they save -- 48 vs 36 us per evaluation)
         const int tx = dim < 256 ? dim : 256;
         hipLaunchKernelGGL(k_fb_grad, dim3((unsigned)nslabs, (unsigned)((dim + tx - 1) / tx)), dim3(tx), 0, s, fb->X,
                            fb->r, n, dim, fb->partial);
     }
-    hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim, fb->w,
+    // the last kernel writes loss + gradient straight into the pinned host mirror (mapped into the
+    // device's address space): no device-to-host copies are queued behind it
+    hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim,
+                       by_arg ? (const float *)nullptr : (const float *)fb->w, wv,
                        fb->has_q ? fb->qhat : (const float *)nullptr, fb->has_xlx ? fb->xlx : (const float *)nullptr,
-                       dev, fb->out, fb->loss_dev);
+                       dev, fb->out_host_dev, fb->loss_host_dev);
     SSW_HIP_TRY(hipGetLastError());
-    SSW_HIP_TRY(hipMemcpyAsync(fb->out_host, fb->out, (size_t)(1 + dim + 1 + 4) * sizeof(float),
-                               hipMemcpyDeviceToHost, s));
-    SSW_HIP_TRY(hipMemcpyAsync(fb->loss_host, fb->loss_dev, sizeof(double), hipMemcpyDeviceToHost, s));
     SSW_HIP_TRY(hipStreamSynchronize(s));
     fb->last_evals++;
     return SSW_OK;
@@ -675,12 +733,18 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipMalloc((void **)&fb->xlx, (size_t)dim * dim * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->out, outn * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->loss_dev, sizeof(double)) != hipSuccess ||
-        hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->w_host, (size_t)(dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("feedback: allocation failed");
         ssw_fb_destroy(fb);
         return SSW_ERR_NOMEM;
+    }
+    if (hipHostGetDevicePointer((void **)&fb->out_host_dev, fb->out_host, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&fb->loss_host_dev, fb->loss_host, 0) != hipSuccess) {
+        set_error("feedback: pinned host memory is not mapped into the device address space");
+        ssw_fb_destroy(fb);
+        return SSW_ERR_HIP;
     }
     *out = fb;
     return SSW_OK;
