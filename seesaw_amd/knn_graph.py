@@ -113,14 +113,15 @@ def post_process_graph_df(df: pd.DataFrame, nvec: int) -> pd.DataFrame:
     return out.sort_values(["src_vertex", "dst_rank"]).reset_index(drop=True)
 
 
-def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None) -> pd.DataFrame:
+def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None, device: int = 0) -> pd.DataFrame:
     """all-pairs cosine distances, k+1 nearest per row (knn_graph.py:170-191) on the GPU:
     DeviceIndex.knn (ssw_knn_build: fp16 MFMA candidate pass + exact f32 rescoring, certified
     per row).  `device_index` is the index's resident matrix when the caller has one."""
     from .device_index import DeviceIndex
     n = vectors.shape[0]
     k = min(n_neighbors + 1, n) - 1
-    dev = device_index if device_index is not None else DeviceIndex.from_numpy(np.ascontiguousarray(vectors, dtype=np.float32))
+    dev = device_index if device_index is not None else DeviceIndex.from_numpy(
+        np.ascontiguousarray(vectors, dtype=np.float32), device=device)
     try:
         dst, score, _ = dev.knn(k)
     finally:

@@ -37,11 +37,39 @@ def category2query(dataset_name: str, cat: str) -> str:
     return cat
 
 
-def fill_imdata(imdata: Imdata, box_data: pd.DataFrame, b: BenchParams) -> Imdata:
-    """the simulated user: mark the ground-truth boxes of the target category."""
+def _group_boxes(box_data: pd.DataFrame) -> dict:
+    """dbidx -> (category array, list of box records): fill_imdata's per-image filter, done once"""
+    cols = ["x1", "x2", "y1", "y2", "description"]
+    out = {}
+    if box_data.shape[0] == 0:
+        return out
+    order = np.argsort(box_data.dbidx.values, kind="stable")  # keep the frame's row order inside an image
+    bd = box_data.iloc[order]
+    recs = bd[cols].to_dict(orient="records")
+    cats = bd.category.values
+    ids = bd.dbidx.values
+    starts = np.flatnonzero(np.r_[True, ids[1:] != ids[:-1]])
+    ends = np.r_[starts[1:], ids.shape[0]]
+    for s0, e0 in zip(starts.tolist(), ends.tolist()):
+        out[int(ids[s0])] = (cats[s0:e0], recs[s0:e0])
+    return out
+
+
+def fill_imdata(imdata: Imdata, box_data: pd.DataFrame, b: BenchParams, _groups: dict = None) -> Imdata:
+    """the simulated user: mark the ground-truth boxes of the target category.  `_groups` (from
+    _group_boxes) replaces the per-call scan of box_data; the random draws are the same either way."""
     imdata = imdata.copy()
-    rows = box_data[box_data.dbidx.values == imdata.dbidx]
     boxes = []
+    if _groups is not None:
+        hit = _groups.get(int(imdata.dbidx))
+        if hit is not None:
+            cats, recs = hit
+            sel = [r for c, r in zip(cats, recs) if c == b.ground_truth_category]
+            keep = np.random.rand(len(sel)) >= b.box_drop_prob
+            boxes = [Box(marked_accepted=True, **r) for r, k in zip(sel, keep) if k]
+        imdata.boxes = boxes
+        return imdata
+    rows = box_data[box_data.dbidx.values == imdata.dbidx]
     if rows.shape[0] > 0:
         feedback = rows[rows.category == b.ground_truth_category].assign(marked_accepted=True)
         feedback = feedback[["x1", "x2", "y1", "y2", "description", "marked_accepted"]]
@@ -59,6 +87,7 @@ def benchmark_loop(*, session: Session, subset: FrozenBitMap, box_data: pd.DataF
     positives = FrozenBitMap(box_data.dbidx.values)
     assert positives.intersection(subset) == positives, "index mismatch"
     max_results = len(positives) if b.max_results is None else min(len(positives), b.max_results)
+    groups = _group_boxes(box_data)
     total_results = total_seen = 0
     seen_dbidxs = BitMap()
     session.set_text(b.qstr)
@@ -78,7 +107,7 @@ def benchmark_loop(*, session: Session, subset: FrozenBitMap, box_data: pd.DataF
         s = session.get_state()
         last_batch = s.gdata[-1]
         for j, imdata in enumerate(last_batch):
-            last_batch[j] = fill_imdata(imdata, box_data, b)
+            last_batch[j] = fill_imdata(imdata, box_data, b, _groups=groups)
         session.update_state(s)
         total_results += int(sum(is_image_accepted(im) for im in last_batch))
         total_seen += len(idxbatch)

@@ -122,11 +122,8 @@ class Session:
                 if activation_batch is None or len(activation_batch) == 0:
                     acts.append(None)
                     continue
-                a = []
-                for row in activation_batch[i].to_dict(orient="records"):
-                    a.append(ActivationData(box=Box(x1=row["x1"], y1=row["y1"], x2=row["x2"], y2=row["y2"]),
-                                            score=row["score"]))
-                acts.append(a)
+                vals = activation_batch[i][["x1", "y1", "x2", "y2", "score"]].to_numpy(dtype=np.float64).tolist()
+                acts.append([ActivationData(box=Box(x1=v[0], y1=v[1], x2=v[2], y2=v[3]), score=v[4]) for v in vals])
             hit = cache[key] = (idxbatch, urls, acts)  # keeps idxbatch alive so its id stays unique
         return hit[1], hit[2]
 

@@ -97,7 +97,8 @@ class SyntheticDataset:
         if self._knng is None:
             assert self.knn_k > 0, "dataset built without a k-NN graph"
             dev = getattr(self._index, "_dev", None) if self._index is not None else None  # matrix already resident
-            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=self.knn_k, device_index=dev))
+            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=self.knn_k, device_index=dev,
+                                                    device=getattr(self, "device", 0) or 0))
         return self._knng
 
     def load_index(self, i_name=None, *, options=None):
