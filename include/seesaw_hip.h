@@ -178,6 +178,17 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
                              double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
                              int32_t *out_sweeps, int32_t *out_converged);
 
+/* Device-resident chaining for the ranking loop (KnnProp2: the same prior is reg_values and start iterate
+ * of every call, and the result only feeds a top-k): install the prior once, propagate without moving the
+ * [n] f64 vectors over PCIe, hand the scores to the index's score buffer as f32 (labelled nodes at -inf
+ * when mask_labeled != 0) for ssw_index_topk(q = NULL), and fetch the f64 result only when asked for. */
+ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host);
+ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, const double *label_vals,
+                                      int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
+                                      int32_t *out_sweeps, int32_t *out_converged);
+ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host);
+ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled);
+
 /* Exact k-NN graph over the resident matrix (rows as vertices, cosine / dot similarity):
  * replaces compute_exact_knn, seesaw/knn_graph.py:170-191 (`1 - X @ X.T`, argsort, first k+1).
  * out_dst / out_score are [n_rows, k+1]: per row the k+1 best rows INCLUDING the row itself,

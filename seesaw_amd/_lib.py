@@ -74,6 +74,10 @@ _SIGNATURES = {
     "ssw_fb_set_data_from_device": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i32]),
     "ssw_fb_set_targets": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_query": (c_i32, [c_void_p, c_void_p]),
+    "ssw_labelprop_set_prior": (c_i32, [c_void_p, c_void_p]),
+    "ssw_labelprop_run_resident": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, c_i32, c_void_p, c_void_p]),
+    "ssw_labelprop_fetch": (c_i32, [c_void_p, c_void_p]),
+    "ssw_labelprop_scores_to_index": (c_i32, [c_void_p, c_void_p, c_i32]),
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_knn_build": (c_i32, [c_void_p, c_i32, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),

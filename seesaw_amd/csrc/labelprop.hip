@@ -65,8 +65,25 @@ __global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep(
     double sum = 0.0;
     for (int64_t base = p_begin; base < p_end; base += LP_CHUNK) {
         const int64_t lim = min(base + LP_CHUNK, p_end);
-        for (int64_t p = base + t; p < lim; p += LP_BLOCK)
-            prod[p - base] = __dmul_rn(data[p], f_old[indices[p]]);
+        // four independent index -> gather chains per thread in flight (the gathers of f_old are what the
+        // sweep waits for: random 8-byte reads, one cache line each)
+        for (int64_t p = base + t; p < lim; p += 4 * LP_BLOCK) {
+            int32_t col[4];
+            double w[4], f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + (int64_t)u * LP_BLOCK;
+                col[u] = q < lim ? indices[q] : 0;
+                w[u] = q < lim ? data[q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = f_old[col[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t q = p + (int64_t)u * LP_BLOCK;
+                if (q < lim) prod[q - base] = __dmul_rn(w[u], f[u]);
+            }
+        }
         __syncthreads();
         const int64_t lo = max(my_lo, base), hi = min(my_hi, lim);
         for (int64_t p = lo; p < hi; ++p) sum = __dadd_rn(sum, prod[p - base]);
@@ -116,6 +133,14 @@ __global__ void k_lp_apply_labels(double *f, unsigned char *is_label, double *la
     is_label[r] = 1;
     label_val[r] = vals[i];
     f[r] = vals[i];
+}
+
+// scores (f64) -> the index's f32 score buffer, labelled nodes at -inf: what the ranking loop hands to the
+// top-k selection (graph_based.py:96-101: `scores[is_labeled] = -inf`, knn_methods.py:163-172)
+__global__ void k_lp_scores_f32(const double *__restrict__ f, const unsigned char *__restrict__ is_label_or_null,
+                                int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (is_label_or_null && is_label_or_null[i]) ? -INFINITY : (float)f[i];
 }
 
 __global__ void k_lp_clear_labels(unsigned char *is_label, const int64_t *ids, int64_t n_labels) {
@@ -220,6 +245,11 @@ struct ssw_lp {
     double *vals = nullptr;
     int64_t ids_cap = 0;
     int64_t n_labels_installed = 0;
+    // device-resident chaining: an installed prior (reg_values == start iterate of every call of the ranking
+    // loop) and the buffer holding the last result
+    bool prior_installed = false;
+    double prior_lo = 0.0, prior_hi = 1.0;
+    int last_result = -1;
     LpState *state = nullptr;
     hipStream_t stream = nullptr;
 };
@@ -313,36 +343,43 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
     return SSW_OK;
 }
 
-ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const double *start_host,
-                             const int64_t *label_ids, const double *label_vals, int64_t n_labels,
-                             double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
-                             int32_t *out_sweeps, int32_t *out_converged) {
-    SSW_REQUIRE(lp != nullptr && start_host != nullptr && out_f_host != nullptr, "NULL argument");
+// Shared body of ssw_labelprop_run / ssw_labelprop_run_resident.  prior: uploaded from
+// prior_host_or_null, or (use_installed) the buffer ssw_labelprop_set_prior left on the device, or zeros.
+// start: uploaded from start_host_or_null, or a device copy of the prior.  The result stays in
+// lp->f[lp->last_result].
+static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool use_installed,
+                              const double *start_host_or_null, const int64_t *label_ids, const double *label_vals,
+                              int64_t n_labels, double reg_lambda, double eps, int32_t max_iter, LpState *st_out) {
     SSW_REQUIRE(reg_lambda >= 0.0, "reg_lambda < 0");
-    SSW_REQUIRE(prior_host_or_null != nullptr || reg_lambda == 0.0,
-                "reg_values is required when reg_lambda != 0 (label_propagation.py:50)");
     SSW_REQUIRE(max_iter >= 0, "max_iter < 0");
     SSW_REQUIRE(n_labels == 0 || (label_ids && label_vals), "NULL labels");
     for (int64_t i = 0; i < n_labels; ++i)
         SSW_REQUIRE(label_ids[i] >= 0 && label_ids[i] < lp->n, "label id %lld out of range",
                     (long long)label_ids[i]);
-    DeviceGuard guard(lp->device);
     const int64_t n = lp->n;
     hipStream_t s = lp->stream;
     // bounds of the reference's sanity asserts: min(0, prior.min()) .. max(1, prior.max())
     double lo = 0.0, hi = 1.0;
-    if (prior_host_or_null) {
+    if (use_installed) {
+        lo = lp->prior_lo;
+        hi = lp->prior_hi;
+    } else if (prior_host_or_null) {
         for (int64_t i = 0; i < n; ++i) {
             const double v = prior_host_or_null[i];
             if (v < lo) lo = v;
             if (v > hi) hi = v;
         }
+        lp->prior_installed = false;
         SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host_or_null, (size_t)n * sizeof(double),
                                    hipMemcpyHostToDevice, s));
     } else {
+        lp->prior_installed = false;
         SSW_HIP_TRY(hipMemsetAsync(lp->prior, 0, (size_t)n * sizeof(double), s));
     }
-    SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], start_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (start_host_or_null)
+        SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], start_host_or_null, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    else
+        SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
     // labels: clear the previous set, install the new one (also clamps the start iterate)
     if (lp->n_labels_installed > 0) {
         const int64_t m = lp->n_labels_installed;
@@ -397,11 +434,86 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
         set_error("label propagation: averaged scores left [%g, %g] (label_propagation.py:39-40)", lo, hi);
         return SSW_ERR_NUMERIC;
     }
-    const int res = (st.sweeps > 0) ? st.result_buf : 0;
-    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[res], (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-    SSW_HIP_TRY(hipStreamSynchronize(s));
+    lp->last_result = (st.sweeps > 0) ? st.result_buf : 0;
+    *st_out = st;
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const double *start_host,
+                             const int64_t *label_ids, const double *label_vals, int64_t n_labels,
+                             double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
+                             int32_t *out_sweeps, int32_t *out_converged) {
+    SSW_REQUIRE(lp != nullptr && start_host != nullptr && out_f_host != nullptr, "NULL argument");
+    SSW_REQUIRE(prior_host_or_null != nullptr || reg_lambda == 0.0,
+                "reg_values is required when reg_lambda != 0 (label_propagation.py:50)");
+    DeviceGuard guard(lp->device);
+    LpState st;
+    SSW_TRY(lp_run_core(lp, prior_host_or_null, false, start_host, label_ids, label_vals, n_labels, reg_lambda, eps,
+                        max_iter, &st));
+    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[lp->last_result], (size_t)lp->n * sizeof(double),
+                               hipMemcpyDeviceToHost, lp->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     if (out_sweeps) *out_sweeps = st.sweeps;
     if (out_converged) *out_converged = st.done;
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
+    SSW_REQUIRE(lp != nullptr && prior_host != nullptr, "NULL argument");
+    DeviceGuard guard(lp->device);
+    double lo = 0.0, hi = 1.0;
+    for (int64_t i = 0; i < lp->n; ++i) {
+        const double v = prior_host[i];
+        if (v < lo) lo = v;
+        if (v > hi) hi = v;
+    }
+    SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host, (size_t)lp->n * sizeof(double), hipMemcpyHostToDevice,
+                               lp->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    lp->prior_lo = lo;
+    lp->prior_hi = hi;
+    lp->prior_installed = true;
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, const double *label_vals,
+                                      int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
+                                      int32_t *out_sweeps, int32_t *out_converged) {
+    SSW_REQUIRE(lp != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->prior_installed, "ssw_labelprop_run_resident: no prior installed (ssw_labelprop_set_prior)");
+    DeviceGuard guard(lp->device);
+    LpState st;
+    SSW_TRY(lp_run_core(lp, nullptr, true, nullptr, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, &st));
+    if (out_sweeps) *out_sweeps = st.sweeps;
+    if (out_converged) *out_converged = st.done;
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host) {
+    SSW_REQUIRE(lp != nullptr && out_f_host != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_fetch: nothing has been propagated yet");
+    DeviceGuard guard(lp->device);
+    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[lp->last_result], (size_t)lp->n * sizeof(double),
+                               hipMemcpyDeviceToHost, lp->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled) {
+    SSW_REQUIRE(lp != nullptr && index != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_scores_to_index: nothing has been propagated yet");
+    int64_t n = 0, n_images = 0;
+    int32_t D = 0;
+    void *Xv = nullptr, *scores = nullptr;
+    SSW_TRY(ssw_index_shape(index, &n, &D, &n_images));
+    SSW_TRY(ssw_index_device_ptrs(index, &Xv, &scores));
+    SSW_REQUIRE(n == lp->n, "the index has %lld rows, the graph %lld nodes", (long long)n, (long long)lp->n);
+    SSW_TRY(ssw_index_sync(index));  // nothing of the index's own stream still writes the score buffer
+    DeviceGuard guard(lp->device);
+    hipLaunchKernelGGL(k_lp_scores_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lp->stream, lp->f[lp->last_result],
+                       mask_labeled ? lp->is_label : (const unsigned char *)nullptr, n, (float *)scores);
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     return SSW_OK;
 }
 

@@ -211,6 +211,19 @@ class MultiscaleIndex(AccessMethod):
         df.attrs["best_rows"] = best_rows[keep]
         return df
 
+    def topk_from_device_scores(self, fill_scores, *, topk_dbidx, exclude_dbidx=None):
+        """topk_from_scores for scores that are already on the device: `fill_scores(device_index)` writes the
+        per-row f32 scores (skipped rows at -inf) into the index's score buffer."""
+        excl_pos = self._excluded_positions(exclude_dbidx)
+        fill_scores(self._dev)
+        self._resident_q = None
+        pos, scores, best_rows = self._dev.topk(None, max(1, min(int(topk_dbidx), self._dbidx.shape[0])), excluded=excl_pos)
+        keep = np.isfinite(scores)
+        df = pd.DataFrame({"dbidx": self._dbidx[pos[keep]], "max_score": scores[keep]})
+        df.attrs["positions"] = pos[keep]
+        df.attrs["best_rows"] = best_rows[keep]
+        return df
+
     def _activations_from_best(self, candidate_df: pd.DataFrame, topk: int):
         rows = np.asarray(candidate_df.attrs["best_rows"][:topk], dtype=np.int64)
         scores = candidate_df.max_score.values[:topk]

@@ -32,6 +32,7 @@ class LabelPropagation:
         self.weight_sum = np.asarray(W.sum(0)).reshape(-1).astype(np.float64)  # column sums, as the reference
         self.last_sweeps = 0
         self.last_converged = False
+        self._prior_installed = False
         self._h = ctypes.c_void_p()
         indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(W.indices, dtype=np.int32)
@@ -50,7 +51,42 @@ class LabelPropagation:
         except Exception:
             pass
 
+    # ---- device-resident chaining (the ranking loop: same prior every call, result feeds a top-k) ----
+    def set_prior(self, reg_values):
+        """install reg_values on the device once; fit_resident then uses it as prior AND start iterate"""
+        assert reg_values.shape[0] == self.n
+        self.reg_values = reg_values
+        prior = np.ascontiguousarray(reg_values, dtype=np.float64)  # (a named reference: _p keeps only the address)
+        _lib.call("ssw_labelprop_set_prior", self._h, _p(prior))
+        self._prior_installed = True
+
+    def fit_resident(self, *, label_ids, label_values):
+        """fit_transform(label_ids, label_values, reg_values=prior, start_value=prior) with the installed
+        prior; the result stays on the device (fetch() / scores_to_index())."""
+        ids = np.ascontiguousarray(np.asarray(label_ids).reshape(-1), dtype=np.int64)
+        vals = np.ascontiguousarray(np.asarray(label_values).reshape(-1), dtype=np.float64)
+        assert ids.shape == vals.shape
+        sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("ssw_labelprop_run_resident", self._h, _p(ids), _p(vals), ids.shape[0], self.reg_lambda,
+                  float(self.epsilon), self.max_iter, ctypes.byref(sweeps), ctypes.byref(conv))
+        self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
+        if self.last_converged:
+            if self.verbose > 0:
+                print(f"prop. converged after {self.last_sweeps} iterations")
+        else:
+            print(f"warning: did not converge after {self.last_sweeps} iterations")
+
+    def fetch(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        _lib.call("ssw_labelprop_fetch", self._h, _p(out))
+        return out
+
+    def scores_to_index(self, device_index, mask_labeled: bool = True):
+        """last result -> the index's f32 score buffer (labelled nodes at -inf), ready for topk(None, ...)"""
+        _lib.call("ssw_labelprop_scores_to_index", self._h, device_index._h, int(bool(mask_labeled)))
+
     def fit_transform(self, *, label_ids, label_values, reg_values=None, start_value=None):
+        self._prior_installed = False  # this call overwrites the device copy of the prior
         if reg_values is not None:
             assert reg_values.shape[0] == self.n
             self.reg_values = reg_values
@@ -70,7 +106,8 @@ class LabelPropagation:
         assert ids.shape == vals.shape
         out = np.empty(self.n, dtype=np.float64)
         sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0)
-        _lib.call("ssw_labelprop_run", self._h, _p(prior), _p(np.ascontiguousarray(start)), _p(ids), _p(vals),
+        start = np.ascontiguousarray(start)
+        _lib.call("ssw_labelprop_run", self._h, _p(prior), _p(start), _p(ids), _p(vals),
                   ids.shape[0], self.reg_lambda, float(self.epsilon), self.max_iter, _p(out),
                   ctypes.byref(sweeps), ctypes.byref(conv))
         self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)

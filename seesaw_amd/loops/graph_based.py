@@ -106,9 +106,16 @@ class KnnProp2(LoopBase):
         """next images by propagated score: unlabelled vectors only, distinct non-returned
         images, then the usual per-image aggregation (graph_based.py:88-109)."""
         model, p, q = self.state.knn_model, self.params, self.q
-        scores = model.current_scores()
-        cand = q.index.topk_from_scores(scores, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned,
-                                        skip_rows=model.is_labeled > 0)
+        on_device = getattr(model, "scores_on_device", lambda: False)() and p.agg_method == "plain_score" \
+            and hasattr(q.index, "topk_from_device_scores")
+        if on_device:  # propagated scores go from the graph handle to the index's score buffer on the GPU
+            cand = q.index.topk_from_device_scores(lambda dev: model.lp.scores_to_index(dev, mask_labeled=True),
+                                                   topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned)
+            scores = None
+        else:
+            scores = model.current_scores()
+            cand = q.index.topk_from_scores(scores, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned,
+                                            skip_rows=model.is_labeled > 0)
         if p.agg_method == "plain_score":  # best tile per image came back with the selection
             ans = q.index._activations_from_best(cand, p.batch_size)
         else:

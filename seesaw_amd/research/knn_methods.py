@@ -94,7 +94,31 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
         self.lp = LabelPropagation(weight_matrix=weight_matrix, reg_lambda=self.prior_weight, max_iter=300,
                                    verbose=verbose, device=device)
 
+    def set_base_scores(self, init_scores):
+        super().set_base_scores(init_scores)
+        self.lp.set_prior(self.prior_scores)  # constant until the next text query: keep it on the device
+        self._resident = False
+
     def _propagate(self, scores):
         ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))  # == nonzero(is_labeled)
-        return self.lp.fit_transform(label_ids=ids, label_values=self.labels.reshape(-1)[ids],
-                                     reg_values=self.prior_scores, start_value=scores)
+        vals = self.labels.reshape(-1)[ids]
+        if scores is self.prior_scores and self.lp._prior_installed and self.lp.reg_values is self.prior_scores:
+            # the loop's case (update(): start == prior): nothing but the labels crosses PCIe; the f64 scores
+            # are fetched only if somebody asks for them (current_scores / top_k)
+            self.lp.fit_resident(label_ids=ids, label_values=vals)
+            self._resident = True
+            return None
+        self._resident = False
+        out = self.lp.fit_transform(label_ids=ids, label_values=vals, reg_values=self.prior_scores, start_value=scores)
+        if scores is self.prior_scores:
+            self.lp.set_prior(self.prior_scores)  # re-install for the following rounds
+        return out
+
+    def current_scores(self):
+        if self._current_scores is None and getattr(self, "_resident", False):
+            self._current_scores = self.lp.fetch()
+        return self._current_scores
+
+    def scores_on_device(self) -> bool:
+        """True when the latest scores live in the label-propagation handle (not yet fetched)"""
+        return bool(getattr(self, "_resident", False))

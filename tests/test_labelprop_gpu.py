@@ -109,3 +109,35 @@ def test_xlx_matches_reference_expression(oracle, n, dim):
     assert np.abs(got - want).max() <= 1e-11 * scale, np.abs(got - want).max() / scale
     assert np.array_equal(got.astype(np.float32), want.astype(np.float32)) or \
         np.abs(got.astype(np.float32) - want.astype(np.float32)).max() <= 2e-7 * scale
+
+
+def test_resident_chaining_equals_host_round_trip(oracle):
+    """set_prior + fit_resident + fetch / scores_to_index == fit_transform with the same prior as reg_values
+    and start value (the ranking loop's call pattern), bit for bit; the f32 scores handed to the index
+    equal `scores.astype(float32)` with labelled nodes at -inf."""
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.label_propagation import LabelPropagation
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    W = _W(g)
+    n = W.shape[0]
+    rng = np.random.default_rng(1)
+    prior = rng.random(n)
+    ids = rng.choice(n, size=40, replace=False).astype(np.int64)
+    vals = (rng.random(40) > 0.5).astype(np.float64)
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
+    want = lp.fit_transform(label_ids=ids, label_values=vals, reg_values=prior, start_value=prior)
+    sweeps = lp.last_sweeps
+    lp.set_prior(prior)
+    for _ in range(2):  # twice: the installed prior survives a call
+        lp.fit_resident(label_ids=ids, label_values=vals)
+        assert lp.last_sweeps == sweeps
+        assert np.array_equal(lp.fetch(), want)
+    dev = DeviceIndex.from_numpy(g["X"])
+    lp.scores_to_index(dev, mask_labeled=True)
+    s32 = want.astype(np.float32)
+    s32[ids] = -np.inf
+    rows, scores, _ = dev.topk(None, 25)
+    order = np.lexsort((np.arange(n), -s32.astype(np.float64)))[:25]
+    assert np.array_equal(rows, order) and np.array_equal(scores, s32[order])
+    dev.close()
+    lp.close()
