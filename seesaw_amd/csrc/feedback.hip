@@ -205,9 +205,20 @@ __global__ void k_fb_grad(const float *__restrict__ X, const float *__restrict__
     const int c = threadIdx.x + blockIdx.y * blockDim.x;
     if (c >= dim) return;
     const int64_t r0 = (int64_t)blockIdx.x * FB_SLAB;
-    const int64_t r1 = min(r0 + FB_SLAB, n);
+    const int cnt = (int)(min(r0 + FB_SLAB, n) - r0);
+    // all of the slab's loads are issued before the (ordered, dependent) fma chain consumes them: the chain
+    // itself is 32 steps, waiting for one row at a time made it 32 memory latencies
+    float xv[FB_SLAB], rv[FB_SLAB];
+#pragma unroll
+    for (int i = 0; i < FB_SLAB; ++i) {
+        const int64_t row = r0 + (i < cnt ? i : 0);
+        xv[i] = X[row * dim + c];
+        rv[i] = r[row];
+    }
     float g = 0.f;
-    for (int64_t i = r0; i < r1; ++i) g = fmaf(r[i], X[i * dim + c], g);
+#pragma unroll
+    for (int i = 0; i < FB_SLAB; ++i)
+        if (i < cnt) g = fmaf(rv[i], xv[i], g);
     partial[(int64_t)blockIdx.x * dim + c] = g;
 }
 
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
                                                    const float *__restrict__ qhat,
                                                    const float *__restrict__ xlx, FbObjDev obj,
                                                    float *__restrict__ out, double *__restrict__ out_loss) {
-    __shared__ double red[1024];
+    __shared__ double red[1024], red2[1024], red3[1024], red4[1024];
     __shared__ float sw_[1024];
     __shared__ double scal[8];
     const int c = threadIdx.x;
@@ -241,27 +252,77 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
     if (act)
         for (int s = 0; s < nslabs; ++s) g += partial[(int64_t)s * dim + c];
     g *= obj.scale;
-    // block reductions: |w|^2, w.qhat, data loss, sum r
-    auto block_sum = [&](double v) -> double {
-        red[c] = v;
+    // block reductions: |w|^2, w.qhat, data loss, sum r.  Same association as the plain LDS tree
+    // (x[c] += x[c + s] for s = 512 ... 1): strides 512 ... 64 through LDS, strides 32 ... 1 inside wave 0
+    // by shuffles (lane c takes lane c + s), result broadcast through LDS; four sums share one pass.
+    auto tree = [&](double v, double *buf) -> double {
+        buf[c] = v;
         __syncthreads();
-        for (int s = 512; s >= 1; s >>= 1) {
-            if (c < s) red[c] += red[c + s];
+        for (int s = 512; s >= 64; s >>= 1) {
+            if (c < s) buf[c] += buf[c + s];
             __syncthreads();
         }
-        const double o = red[0];
+        double x = c < 64 ? buf[c] : 0.0;
+        if (c < 64) {
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) x += __shfl_down(x, s, 64);
+        }
+        return x;  // valid in thread 0
+    };
+    auto block_sum = [&](double v) -> double {
+        const double x = tree(v, red);
+        if (c == 0) scal[0] = x;
+        __syncthreads();
+        const double o = scal[0];
         __syncthreads();
         return o;
     };
-    const double ww = block_sum(act ? (double)wc * wc : 0.0);
-    const double wq = block_sum(act && qhat ? (double)wc * qhat[c] : 0.0);
     double ls = 0.0, rs = 0.0;
     for (int64_t i = c; i < n; i += 1024) {
         ls += item_loss[i];
         rs += (double)r[i];
     }
-    const double data_loss = block_sum(ls) * obj.scale;
-    const double rsum = block_sum(rs) * obj.scale;
+    double ww, wq, data_loss, rsum;
+    {
+        // four independent sums: one barrier schedule (the trees do not interact: separate buffers)
+        const double v0 = act ? (double)wc * wc : 0.0, v1 = act && qhat ? (double)wc * qhat[c] : 0.0;
+        red[c] = v0;
+        red2[c] = v1;
+        red3[c] = ls;
+        red4[c] = rs;
+        __syncthreads();
+        for (int s = 512; s >= 64; s >>= 1) {
+            if (c < s) {
+                red[c] += red[c + s];
+                red2[c] += red2[c + s];
+                red3[c] += red3[c + s];
+                red4[c] += red4[c + s];
+            }
+            __syncthreads();
+        }
+        if (c < 64) {
+            double x0 = red[c], x1 = red2[c], x2 = red3[c], x3 = red4[c];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                x0 += __shfl_down(x0, s, 64);
+                x1 += __shfl_down(x1, s, 64);
+                x2 += __shfl_down(x2, s, 64);
+                x3 += __shfl_down(x3, s, 64);
+            }
+            if (c == 0) {
+                scal[0] = x0;
+                scal[1] = x1;
+                scal[2] = x2;
+                scal[3] = x3;
+            }
+        }
+        __syncthreads();
+        ww = scal[0];
+        wq = scal[1];
+        data_loss = scal[2] * obj.scale;
+        rsum = scal[3] * obj.scale;
+        __syncthreads();
+    }
     const double norm = sqrt(ww);
     const double nclamp = norm > 1e-12 ? norm : 1e-12;  // F.normalize eps
     double reg_loss = 0.0, p_norm = 0.0, p_data = 0.0, p_query = 0.0;
@@ -318,7 +379,6 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
         parts[1] = (float)p_data;
         parts[2] = (float)p_query;
         parts[3] = (float)data_loss;
-        (void)scal;
     }
 }
 
