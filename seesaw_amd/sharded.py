@@ -74,9 +74,12 @@ class ShardedTopK:
         self.merge = merge
         self.k_max = int(k_max)
         dev = device
-        self.send_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
-        self.send_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.all_keys = torch.zeros((world, self.k_max), dtype=torch.int64, device=dev)
+        # one message per rank: k_max keys followed by the count (as an int64 word), so the exchange is a
+        # single all-gather
+        self.send_buf = torch.zeros(self.k_max + 1, dtype=torch.int64, device=dev)
+        self.send_keys = self.send_buf[:self.k_max]
+        self.all_buf = torch.zeros((world, self.k_max + 1), dtype=torch.int64, device=dev)
+        self.all_keys = self.all_buf  # rows are read with stride k_max + 1
         self.all_counts = torch.zeros(world, dtype=torch.int32, device=dev)
         self.out_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -89,15 +92,14 @@ class ShardedTopK:
         # globalise: low 32 bits hold 0xFFFFFFFF - local_id, so subtracting the shard's
         # first image position yields 0xFFFFFFFF - global_id (no borrow: ids < 2^32)
         self.send_keys[:k] = local_keys[:k] - self.image_offset
-        self.send_count.copy_(local_count)
+        self.send_buf[self.k_max:] = local_count.to(torch.int64)
         if self.world > 1:
             import torch.distributed as dist
             # flat (concatenating) form: accepted by both RCCL and gloo
-            dist.all_gather_into_tensor(self.all_keys.view(-1), self.send_keys, group=self.group)
-            dist.all_gather_into_tensor(self.all_counts.view(-1), self.send_count, group=self.group)
+            dist.all_gather_into_tensor(self.all_buf.view(-1), self.send_buf, group=self.group)
         else:
-            self.all_keys[0] = self.send_keys
-            self.all_counts[0] = self.send_count[0]
+            self.all_buf[0] = self.send_buf
+        self.all_counts.copy_(self.all_buf[:, self.k_max])
         stream_ptr = torch.cuda.current_stream().cuda_stream if self.all_keys.is_cuda else 0
         dev_index = self.all_keys.device.index if self.all_keys.is_cuda else -1
         self.merge(dev_index, stream_ptr, self.all_keys, self.all_counts, k, self.out_keys,
