@@ -133,6 +133,48 @@ def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None, 
     return post_process_graph_df(df, nvec=n)
 
 
+MAX_EXACT_K = 15  # ssw_knn_build keeps 32 candidates per vertex between levels; k + 1 <= 16 of them are certified
+
+
+def compute_knn_from_nndescent(vectors, *, n_neighbors, n_jobs=-1, low_memory=False, device_index=None, device: int = 0,
+                               **kwargs):
+    """The reference builds its production graphs with the approximate pynndescent
+    (knn_graph.py:194-215, "nndescent60": 60 neighbours, later restricted to knn_k = 10 by
+    KNNGraph.restrict_k).  Here the same DataFrame comes from the exact GPU builder; graphs are built
+    with the k that will be used (<= 15) instead of a 60-neighbour pool.  n_jobs / low_memory are accepted
+    for signature compatibility."""
+    if n_neighbors > MAX_EXACT_K:
+        raise NotImplementedError(f"exact graphs are built with n_neighbors <= {MAX_EXACT_K} (asked for "
+                                  f"{n_neighbors}): build with the knn_k the loops use instead of a larger pool")
+    return compute_exact_knn(np.asarray(vectors), n_neighbors, device_index=device_index, device=device)
+
+
+def build_knn_graph(index, *, name: str, n_neighbors: int = 10) -> "KNNGraph":
+    """exact k-NN graph of an index's vectors, saved where lookup_weight_matrix looks for it:
+    `<index.path>/knn_graph/<name>/forward.parquet` (AccessMethod.get_knng_path, interface.py:27-30)"""
+    df = compute_exact_knn(index.vectors, n_neighbors, device_index=getattr(index, "_dev", None),
+                           device=getattr(index, "device", 0) or 0)
+    g = KNNGraph(df)
+    g.save(index.get_knng_path(name=name))
+    return g
+
+
+def factor_neighbors(knng, idx, k_intra):
+    """neighbours from other images ranked separately from neighbours inside the same image: the closest
+    tile of every other image, plus up to k_intra tiles of the vertex's own image (knn_graph.py:217-243)"""
+    dbidxs = idx.vector_meta.dbidx.astype("int32").values
+    df = knng.knn_df
+    df = df.assign(src_dbidx=dbidxs[df.src_vertex.values], dst_dbidx=dbidxs[df.dst_vertex.values])
+    inter = df[df.src_dbidx != df.dst_dbidx]
+    edge_ranks = inter.groupby(["src_vertex", "dst_dbidx"]).distance.rank("first").astype("int")
+    inter = inter[edge_ranks <= 1]
+    inter = inter.assign(dst_rank=inter.groupby(["src_vertex"]).distance.rank("first").sub(1).astype("int"))
+    intra = df[df.src_dbidx == df.dst_dbidx]
+    intra = intra.assign(dst_rank=intra.groupby("src_vertex").distance.rank("first").astype("int"))
+    intra = intra[intra.dst_rank <= k_intra]
+    return pd.concat([inter, intra], ignore_index=True)
+
+
 class KNNGraph:
     def __init__(self, knn_df: pd.DataFrame, nvecs=None):
         self.knn_df = knn_df

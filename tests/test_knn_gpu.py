@@ -78,3 +78,27 @@ def test_knn_two_hundred_thousand_rows_spot_checked(oracle, monkeypatch, batched
     rows = np.random.default_rng(3).integers(0, n, size=64).tolist() + [0, n - 1, 131071, 131072]
     redone = _check_vs_oracle(oracle, X, k, rows=rows)
     assert redone <= n // 100, redone
+
+
+def test_build_knn_graph_saved_where_the_loops_look(oracle, tmp_path):
+    """build_knn_graph writes <index>/knn_graph/<name>/forward.parquet; KNNGraph.from_file reads it back and
+    the weight-matrix lookup of the loops (graph_based.py:28-66) finds it by name"""
+    from seesaw_amd.indices.coarse.coarse_index import CoarseIndex
+    from seesaw_amd.knn_graph import KNNGraph, build_knn_graph, compute_knn_from_nndescent
+    from seesaw_amd.loops.graph_based import get_weight_matrix_from_index
+    n = 700
+    X = oracle.synth_rows(5, 0, n, 512)
+    meta = pd.DataFrame({"dbidx": np.arange(n)})
+    idx = CoarseIndex(embedding=None, vectors=X, vector_meta=meta, path=str(tmp_path))
+    g = build_knn_graph(idx, name="exact10", n_neighbors=10)
+    back = KNNGraph.from_file(idx.get_knng_path(name="exact10"))
+    assert back.knn_df.equals(g.knn_df) and back.k == 10 and back.nvecs == n
+    dst, score = oracle.exact_knn(X, 10)
+    got = back.knn_df[back.knn_df.dst_rank > 0].sort_values(["src_vertex", "dst_rank"]).dst_vertex.values.reshape(n, 10)
+    assert np.array_equal(got, dst[:, 1:])  # self edge is rank 0, the oracle lists the vertex itself first
+    W = get_weight_matrix_from_index(idx, dict(knn_path="exact10", knn_k=10, edist=0.1, self_edges=False,
+                                               normalized_weights=False, symmetric=True))
+    assert W.shape == (n, n) and W.nnz >= n * 10
+    with pytest.raises(NotImplementedError):
+        compute_knn_from_nndescent(X, n_neighbors=60)
+    idx._dev.close()
