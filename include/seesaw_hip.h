@@ -196,7 +196,7 @@ ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t m
  * return for that row as the query (distance = 1 - score).  out_certified [n_rows]: 1 when the
  * row's list is proven exact; rows with 0 must be recomputed with ssw_index_topk (rare: the
  * fp16 candidate pass could not separate the k+1-th neighbour from the rest).  `seed` fixes the
- * random column order of the candidate pass; results do not depend on it.  1 <= k <= 15. */
+ * random column order of the candidate pass; results do not depend on it.  1 <= k <= 31. */
 ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, int32_t *out_dst_host,
                          float *out_score_host, uint8_t *out_certified_host);
 

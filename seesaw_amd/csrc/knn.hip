@@ -48,7 +48,7 @@ typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int KNN_M = 32;       // candidates kept per row between levels
+constexpr int KNN_M_MAX = 64;   // candidates kept per row between levels: 32 (k <= 15) or 64 (k <= 31)
 constexpr int KNN_CAP = 1024;   // row buffer capacity: entries appended within one level (~ M x ratio <= 512) + M
 constexpr int KT = 128;         // tile edge
 constexpr int KBK = 64;         // k-step
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_knn_compact(uint64_t *__restrict__ buf, unsigned *__restrict__ cnt,
                                                      float *__restrict__ thr, unsigned char *__restrict__ overflow,
-                                                     int rows) {
+                                                     int rows, int M) {
     __shared__ uint64_t keys[KNN_CAP];
     const int row = blockIdx.x;
     if (row >= rows) return;
@@ -309,11 +309,11 @@ __global__ __launch_bounds__(256) void k_knn_compact(uint64_t *__restrict__ buf,
             __syncthreads();
         }
     }
-    const int keep = (int)c < KNN_M ? (int)c : KNN_M;
+    const int keep = (int)c < M ? (int)c : M;
     for (int i = threadIdx.x; i < keep; i += 256) rb[i] = keys[i];
     if (threadIdx.x == 0) {
         cnt[row] = keep;
-        if ((int)c >= KNN_M) thr[row] = ord_to_f32((uint32_t)(keys[KNN_M - 1] >> 32));
+        if ((int)c >= M) thr[row] = ord_to_f32((uint32_t)(keys[M - 1] >> 32));
     }
 }
 
@@ -359,7 +359,8 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     SSW_TRY(ssw_index_shape(index, &n, &D, &n_images));
     SSW_TRY(ssw_index_device_ptrs(index, &Xv, &scores_unused));
     SSW_REQUIRE(n >= 1 && n < (int64_t)0x7fff0000, "ssw_knn_build: n=%lld out of range", (long long)n);
-    SSW_REQUIRE(k >= 1 && k + 1 <= KNN_M / 2, "ssw_knn_build: k=%d out of range (1..%d)", k, KNN_M / 2 - 1);
+    SSW_REQUIRE(k >= 1 && k + 1 <= KNN_M_MAX / 2, "ssw_knn_build: k=%d out of range (1..%d)", k, KNN_M_MAX / 2 - 1);
+    const int M = (k + 1 <= 16) ? 32 : 64;  // twice the list length: the margin the certificate lives on
     if (D != 256 && D != 512 && D != 768 && D != 1024) {
         set_error("ssw_knn_build: dim=%d unsupported", D);
         return SSW_ERR_UNSUPPORTED;
@@ -437,14 +438,14 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
 
     // level boundaries over the permuted columns (multiples of the tile edge): 512, then a constant
-    // ratio <= 16 up to n: a level appends ~ M x ratio <= 512 entries per row (+- 90), the buffers hold 1024
+    // ratio <= 512 / M up to n: a level appends ~ M x ratio <= 512 entries per row (+- 90), the buffers hold 1024
     std::vector<int64_t> bounds;
     {
         const int64_t b0 = std::min<int64_t>(n, 512);
         bounds.push_back(b0);
         if (n > b0) {
             const double span = (double)n / (double)b0;
-            const int levels = std::max(1, (int)std::ceil(std::log(span) / std::log(16.0)));
+            const int levels = std::max(1, (int)std::ceil(std::log(span) / std::log(512.0 / M)));
             const double ratio = std::pow(span, 1.0 / levels);
             for (int l = 1; l < levels; ++l) {
                 const int64_t b = (int64_t)std::llround((double)b0 * std::pow(ratio, l));
@@ -494,11 +495,11 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
                 hipLaunchKernelGGL(k_knn_gemm_filter<false>, grid, dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D,
                                    (int)r0, (int)r1, (int)c0, (int)c1, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj,
                                    (int)n_super, 0);
-            hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows);
+            hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows, M);
             c0 = c1;
         }
         if (rc != SSW_OK) break;
-        rc = launch_knn_rescore(X, D, sc.perm, (int)r0, rows, sc.buf, KNN_CAP, sc.cnt, sc.overflow, KNN_M, sc.norms, scale,
+        rc = launch_knn_rescore(X, D, sc.perm, (int)r0, rows, sc.buf, KNN_CAP, sc.cnt, sc.overflow, M, sc.norms, scale,
                                 maxnorm, k1, sc.out_dst, sc.out_score, sc.out_cert, s);
         if (hipError_t e = hipGetLastError(); rc == SSW_OK && e != hipSuccess) return fail(e, "kernel launch");
     }

@@ -133,7 +133,7 @@ def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None, 
     return post_process_graph_df(df, nvec=n)
 
 
-MAX_EXACT_K = 15  # ssw_knn_build keeps 32 candidates per vertex between levels; k + 1 <= 16 of them are certified
+MAX_EXACT_K = 31  # ssw_knn_build keeps 2 (k + 1) <= 64 candidates per vertex between levels
 
 
 def compute_knn_from_nndescent(vectors, *, n_neighbors, n_jobs=-1, low_memory=False, device_index=None, device: int = 0,
@@ -141,7 +141,7 @@ def compute_knn_from_nndescent(vectors, *, n_neighbors, n_jobs=-1, low_memory=Fa
     """The reference builds its production graphs with the approximate pynndescent
     (knn_graph.py:194-215, "nndescent60": 60 neighbours, later restricted to knn_k = 10 by
     KNNGraph.restrict_k).  Here the same DataFrame comes from the exact GPU builder; graphs are built
-    with the k that will be used (<= 15) instead of a 60-neighbour pool.  n_jobs / low_memory are accepted
+    with the k that will be used (<= 31) instead of a 60-neighbour pool.  n_jobs / low_memory are accepted
     for signature compatibility."""
     if n_neighbors > MAX_EXACT_K:
         raise NotImplementedError(f"exact graphs are built with n_neighbors <= {MAX_EXACT_K} (asked for "

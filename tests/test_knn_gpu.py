@@ -36,7 +36,7 @@ def _check_vs_oracle(oracle, X, k, rows=None):
 
 
 @pytest.mark.parametrize("n,k,dim", [(1, 1, 512), (5, 4, 512), (40, 10, 512), (130, 15, 256), (1500, 10, 512),
-                                     (3000, 10, 512), (2500, 3, 768)])
+                                     (3000, 10, 512), (2500, 3, 768), (2000, 31, 512), (1800, 16, 512)])
 def test_knn_bit_exact_vs_oracle(oracle, n, k, dim):
     k = min(k, n - 1) if n > 1 else 0
     X = oracle.synth_rows(100 + n, 0, n, dim)
