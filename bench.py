@@ -200,6 +200,22 @@ def clip_extras(device: int):
             "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}
 
 
+def aggregate_replicas(replicas, world: int):
+    """N > 1: sum of the per-GPU feedback-loop rates (every rank ran its own replica of the sessions)."""
+    agg = {}
+    for rep in replicas:
+        for tag, res in (rep or {}).items():
+            if not isinstance(res, dict):
+                continue
+            for name, v in res.items():
+                if isinstance(v, dict) and "hip_iters_per_s" in v:
+                    a = agg.setdefault(tag, {}).setdefault(name, {"iters_per_s_all_gpus": 0.0, "per_gpu": []})
+                    a["iters_per_s_all_gpus"] += v["hip_iters_per_s"]
+                    a["per_gpu"].append(v["hip_iters_per_s"])
+    return {"scaling": "replicas only (no data-path collective)", "gpus": world, "aggregate": agg,
+            "errors": [r["error"] for r in replicas if isinstance(r, dict) and "error" in r]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -349,19 +365,7 @@ def main():
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
             out["extras"] = extras
         if replicas is not None:
-            agg = {}
-            for rep in replicas:
-                for tag, res in (rep or {}).items():
-                    if not isinstance(res, dict):
-                        continue
-                    for name, v in res.items():
-                        if isinstance(v, dict) and "hip_iters_per_s" in v:
-                            a = agg.setdefault(tag, {}).setdefault(name, {"iters_per_s_all_gpus": 0.0, "per_gpu": []})
-                            a["iters_per_s_all_gpus"] += v["hip_iters_per_s"]
-                            a["per_gpu"].append(v["hip_iters_per_s"])
-            out["extras"] = {"feedback_loop_replicas": {"scaling": "replicas only (no data-path collective)", "gpus": world,
-                                                        "aggregate": agg,
-                                                        "errors": [r["error"] for r in replicas if isinstance(r, dict) and "error" in r]}}
+            out["extras"] = {"feedback_loop_replicas": aggregate_replicas(replicas, world)}
         print(json.dumps(out), flush=True)
     index.close()
     if dist is not None:

@@ -65,3 +65,17 @@ def test_two_rank_exchange_matches_single_index(tmp_path, oracle, n_total, k):
         g = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(g["imgs"], ref_ids), r            # every rank holds the global answer
         assert np.array_equal(g["scores"].view(np.uint32), ref_sc.view(np.uint32))
+
+
+def test_bench_replica_aggregation():
+    """bench.py at N > 1: per-GPU feedback-loop rates are summed; a failed replica is reported, not fatal"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rep = {"full": {"vectors": 10, "knn_graph": {"k": 10}, "plain": {"hip_iters_per_s": 500.0, "hip_ms_per_iter": 2.0},
+                    "multi_reg": {"hip_iters_per_s": 250.0}}}
+    out = bench.aggregate_replicas([rep, rep, {"error": "boom"}, None], 4)
+    assert out["gpus"] == 4 and out["errors"] == ["boom"]
+    assert out["aggregate"]["full"]["plain"]["iters_per_s_all_gpus"] == 1000.0
+    assert out["aggregate"]["full"]["multi_reg"]["per_gpu"] == [250.0, 250.0]
