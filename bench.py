@@ -299,8 +299,11 @@ def main():
     replicas = None
     if world > 1 and not args.no_extras:
         index.close()  # free the shard before the loop datasets move in
+        import contextlib
+        import io
         try:
-            mine = feedback_loop_extras(local_rank, args.loop_images, with_cpu=False)
+            with contextlib.redirect_stdout(io.StringIO()):  # rank 0's JSON line is the only stdout of the job
+                mine = feedback_loop_extras(local_rank, args.loop_images, with_cpu=False)
         except Exception as e:
             mine = {"error": f"{type(e).__name__}: {e}"}
         replicas = [None] * world
