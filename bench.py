@@ -200,6 +200,35 @@ def clip_extras(device: int):
             "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}
 
 
+def c2_extras(device: int):
+    """BASELINE config C2: 1 M x 512 on one GPU -- scan kernel bandwidth against the HBM peak and the latency
+    of a complete host-to-host query (2-KB query in, packed top-100 out), 50 timed queries after 5 warm-ups,
+    without and with 1000 excluded ids."""
+    import numpy as np
+    from oracle import seesaw_oracle as orc
+    from seesaw_amd.device_index import DeviceIndex
+    n = 1_000_000
+    idx = DeviceIndex.synthetic(n, 512, seed=2024, device=device)
+    qs = [orc.synth_query(1000 + i) for i in range(55)]
+    excluded = np.random.default_rng(5).choice(n, size=1000, replace=False).tolist()
+    out = {"rows": n, "k": 100}
+    for tag, ex in (("no_exclusion", None), ("excluded_1000", excluded)):
+        for q in qs[:5]:
+            idx.topk(q, 100, excluded=ex)
+        idx.profile(True)
+        t0 = time.perf_counter()
+        for q in qs[5:]:
+            idx.topk(q, 100, excluded=ex)
+        wall = (time.perf_counter() - t0) / 50
+        ms = idx.profile_read()
+        idx.profile(False)
+        gbs = n * ROW_BYTES / (float(np.mean(ms)) * 1e-3) / 1e9
+        out[tag] = {"query_ms_host_to_host": wall * 1e3, "vectors_per_s": n / wall, "scan_kernel_ms": float(np.mean(ms)),
+                    "scan_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    idx.close()
+    return out
+
+
 def aggregate_replicas(replicas, world: int):
     """N > 1: sum of the per-GPU feedback-loop rates (every rank ran its own replica of the sessions)."""
     agg = {}
@@ -360,7 +389,8 @@ def main():
         index.close()
         if world == 1 and not args.no_extras:
             extras = {}
-            for key, fn in (("feedback_loop", lambda: feedback_loop_extras(local_rank, args.loop_images)),
+            for key, fn in (("c2_one_million_rows", lambda: c2_extras(local_rank)),
+                            ("feedback_loop", lambda: feedback_loop_extras(local_rank, args.loop_images)),
                             ("clip", lambda: clip_extras(local_rank))):
                 try:
                     extras[key] = fn()
