@@ -61,25 +61,29 @@ constexpr int K_STAGE = 2 * K_OPER;
 __global__ __launch_bounds__(256) void k_knn_stats(const float *__restrict__ X, int64_t n, int D,
                                                    float *__restrict__ norms, unsigned *__restrict__ maxima) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n) return;
-    const float *x = X + r * D;
-    float ss = 0.f, mx = 0.f;
-    for (int c = lane; c < D; c += 64) {
-        const float v = x[c];
-        ss = fmaf(v, v, ss);
-        mx = fmaxf(mx, fabsf(v));
-    }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (int64_t)gridDim.x * 4;
+    float mx_all = 0.f, nr_all = 0.f;
+    for (int64_t r = wave; r < n; r += waves) {  // grid-stride: one pair of atomics per wave, not per row
+        const float *x = X + r * D;
+        float ss = 0.f, mx = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float v = x[c];
+            ss = fmaf(v, v, ss);
+            mx = fmaxf(mx, fabsf(v));
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        ss += __shfl_xor(ss, off, 64);
-        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        for (int off = 32; off >= 1; off >>= 1) {
+            ss += __shfl_xor(ss, off, 64);
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        const float nr = sqrtf(ss) * 1.0001f;  // upper bound of the norm (f32 sum of squares: ~3e-5 relative)
+        if (lane == 0) norms[r] = nr;
+        mx_all = fmaxf(mx_all, mx);
+        nr_all = fmaxf(nr_all, nr);
     }
     if (lane == 0) {
-        const float nr = sqrtf(ss) * 1.0001f;  // upper bound of the norm (f32 sum of squares: ~3e-5 relative)
-        norms[r] = nr;
-        atomicMax(&maxima[0], __float_as_uint(mx));  // non-negative floats order like their bits
-        atomicMax(&maxima[1], __float_as_uint(nr));
+        atomicMax(&maxima[0], __float_as_uint(mx_all));  // non-negative floats order like their bits
+        atomicMax(&maxima[1], __float_as_uint(nr_all));
     }
 }
 
@@ -136,15 +140,16 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // 8 x 8 super-tiles dealt round-robin to the XCDs (block ids b and b + 8 share an XCD): the 64
-    // tiles of a super-tile run on one XCD and share 2 x 8 operand panels through its L2
+    // 8 x 8 super-tiles dealt round-robin to the XCDs (block ids b and b + 8 share an XCD): the 8
+    // workgroups of a super-tile (one per row-tile, each walking the 8 column tiles in the same order) run
+    // on one XCD and share the operand panels through its L2
     // (the grid is two-dimensional only because one dimension is limited to 2^32 work-items)
     const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = (int)(bid & 7);
     const int64_t local = bid >> 3;
-    if ((local >> 6) * 8 + xcd >= n_super) return;
-    const int g = (int)(local >> 6) * 8 + xcd;
-    const int within = (int)(local & 63);
+    if ((local >> 3) * 8 + xcd >= n_super) return;
+    const int g = (int)(local >> 3) * 8 + xcd;
+    const int within = (int)(local & 7);  // row-tile of the super-tile; the workgroup walks its 8 column tiles
     int SI, SJ;
     if (SYM) {  // g enumerates the super-tile pairs SI <= SJ row by row: row SI starts at SI*ns - SI(SI-1)/2
         const int ns = sj_count;
@@ -158,41 +163,42 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
         SI = g / sj_count;
         SJ = g % sj_count;
     }
-    const int I = SI * 8 + (within >> 3), J = SJ * 8 + (within & 7);
-    if (I >= i_tiles || J >= j_tiles) return;
-    if (SYM && (J < I || J < mirror_from)) return;
-    const bool mirror = SYM && I != J && I >= mirror_from;
-    const int m0 = r0 + I * KT, n0 = c0 + J * KT;
+    const int I = SI * 8 + within;
+    if (I >= i_tiles) return;
+    // column tiles of this workgroup: [j_lo, j_hi)
+    int j_lo = SJ * 8, j_hi = min(SJ * 8 + 8, j_tiles);
+    if (SYM) j_lo = max(j_lo, max(I, mirror_from));
+    if (j_lo >= j_hi) return;
+    const int m0 = r0 + I * KT;
     const int wm = wave >> 1, wn = wave & 1;
 
     const f16 *a_src[4];
-    const f16 *b_src[4];
+    int b_chunk[4], b_row[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave * 4 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         a_src[i] = Xh + (int64_t)min(m0 + row, r1 - 1) * D + chunk * 8;
-        b_src[i] = Xh + (int64_t)min(n0 + row, c1 - 1) * D + chunk * 8;
+        b_row[i] = row;
+        b_chunk[i] = chunk * 8;
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
     const unsigned a_dst = lds0 + wave * 4096, b_dst = lds0 + K_OPER + wave * 4096;
-#define KNN_ISSUE(kt, slot)                                                        \
-    {                                                                              \
-        const int k0 = (kt) * KBK;                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                              \
-            glds16(a_src[i] + k0, a_dst + (slot) * K_STAGE + i * 1024);            \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                              \
-            glds16(b_src[i] + k0, b_dst + (slot) * K_STAGE + i * 1024);            \
+    // stage (column tile J, k-step kt) -> ring slot
+#define KNN_ISSUE(J, kt, slot)                                                                         \
+    {                                                                                                  \
+        const int k0 = (kt) * KBK, nb = c0 + (J) * KT;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+            glds16(a_src[i] + k0, a_dst + (slot) * K_STAGE + i * 1024);                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+            glds16(Xh + (int64_t)min(nb + b_row[i], c1 - 1) * D + b_chunk[i] + k0,                     \
+                   b_dst + (slot) * K_STAGE + i * 1024);                                               \
     }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
     const int a_frag = wm * 8192 + frag0, b_frag = K_OPER + wn * 8192 + frag0;
-    // thresholds of this lane's four rows (accumulator row = m0 + wm*64 + i*16 + fr)
+    // thresholds of this lane's four rows (accumulator row = m0 + wm*64 + i*16 + fr): the same for every
+    // column tile of the walk
     float trow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -201,77 +207,92 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
     }
     asm volatile("" ::"s"(cnt), "s"(buf), "s"(c1));  // all scalar loads done before the loop (gemm_bf16.hip)
     const int nk = D / KBK;
-    KNN_ISSUE(0, 0)
+    KNN_ISSUE(j_lo, 0, 0)
     int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 1 < nk) KNN_ISSUE(kt + 1, slot ^ 1)
-        const unsigned char *sb = smem + slot * K_STAGE;
+    for (int J = j_lo; J < j_hi; ++J) {
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 a[4], b[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = *reinterpret_cast<const f16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));
-                b[i] = *reinterpret_cast<const f16x8 *>(sb + ((b_frag + i * 2048) ^ (ks * 64)));
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // the ring never drains between tiles: the first stage of the next column tile is requested
+            // while this tile's last k-step multiplies and its epilogue runs
+            if (kt + 1 < nk) {
+                KNN_ISSUE(J, kt + 1, slot ^ 1)
+            } else if (J + 1 < j_hi) {
+                KNN_ISSUE(J + 1, 0, slot ^ 1)
             }
+            const unsigned char *sb = smem + slot * K_STAGE;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 a[4], b[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = *reinterpret_cast<const f16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));
+                    b[i] = *reinterpret_cast<const f16x8 *>(sb + ((b_frag + i * 2048) ^ (ks * 64)));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+            slot ^= 1;
         }
-        asm volatile("" ::: "memory");
-        slot ^= 1;
-    }
-#undef KNN_ISSUE
-    // acc[i][j][r] = S~[row m0 + wm*64 + i*16 + fr][column n0 + wn*64 + j*16 + fq*4 + r]
+        const int n0 = c0 + J * KT;
+        const bool mirror = SYM && I != J && I >= mirror_from;
+        // acc[i][j][r] = S~[row m0 + wm*64 + i*16 + fr][column n0 + wn*64 + j*16 + fq*4 + r]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float tr = trow[i];
-        const int lrow = m0 + wm * 64 + i * 16 + fr - r0;
+        for (int i = 0; i < 4; ++i) {
+            const float tr = trow[i];
+            const int lrow = m0 + wm * 64 + i * 16 + fr - r0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 v = acc[i][j];
-            if (fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > tr) {
-                const int col = n0 + wn * 64 + j * 16 + fq * 4;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = acc[i][j];
+                if (fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > tr) {
+                    const int col = n0 + wn * 64 + j * 16 + fq * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (v[r] > tr && col + r < c1) {
-                        const unsigned pos = atomicAdd(&cnt[lrow], 1u);
-                        if (pos < (unsigned)KNN_CAP)
-                            buf[(int64_t)lrow * KNN_CAP + pos] =
-                                ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)(col + r));
+                    for (int r = 0; r < 4; ++r) {
+                        if (v[r] > tr && col + r < c1) {
+                            const unsigned pos = atomicAdd(&cnt[lrow], 1u);
+                            if (pos < (unsigned)KNN_CAP)
+                                buf[(int64_t)lrow * KNN_CAP + pos] =
+                                    ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)(col + r));
+                        }
                     }
                 }
             }
         }
-    }
-    if (mirror) {  // entry (j, i) of the symmetric matrix: this tile's columns as rows, its rows as columns
+        if (mirror) {  // entry (j, i) of the symmetric matrix: this tile's columns as rows, its rows as columns
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
-            const f32x4 tc = *reinterpret_cast<const f32x4 *>(thr + col);
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
+                const f32x4 tc = *reinterpret_cast<const f32x4 *>(thr + col);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v = acc[i][j];
-                const int row = m0 + wm * 64 + i * 16 + fr;
-                if (row < r1 && (v[0] > tc[0] || v[1] > tc[1] || v[2] > tc[2] || v[3] > tc[3])) {
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = acc[i][j];
+                    const int row = m0 + wm * 64 + i * 16 + fr;
+                    if (row < r1 && (v[0] > tc[0] || v[1] > tc[1] || v[2] > tc[2] || v[3] > tc[3])) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (v[r] > tc[r]) {
-                            const unsigned pos = atomicAdd(&cnt[col + r], 1u);
-                            if (pos < (unsigned)KNN_CAP)
-                                buf[(int64_t)(col + r) * KNN_CAP + pos] =
-                                    ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)row);
+                        for (int r = 0; r < 4; ++r) {
+                            if (v[r] > tc[r]) {
+                                const unsigned pos = atomicAdd(&cnt[col + r], 1u);
+                                if (pos < (unsigned)KNN_CAP)
+                                    buf[(int64_t)(col + r) * KNN_CAP + pos] =
+                                        ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)row);
+                            }
                         }
                     }
                 }
             }
         }
     }
+#undef KNN_ISSUE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -418,7 +439,8 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
         KNN_HIP(hipMemcpy(sc.perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     }
     KNN_HIP(hipMemsetAsync(sc.maxima, 0, 8, s));
-    hipLaunchKernelGGL(k_knn_stats, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, X, n, (int)D, sc.norms, sc.maxima);
+    hipLaunchKernelGGL(k_knn_stats, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 4096)), dim3(256), 0, s, X, n, (int)D, sc.norms,
+                       sc.maxima);
     float maxima[2] = {0.f, 0.f};
     KNN_HIP(hipMemcpy(maxima, sc.maxima, 8, hipMemcpyDeviceToHost));
     const float maxabs = maxima[0], maxnorm = maxima[1];
@@ -477,7 +499,7 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
                 sj = (j_tiles + 7) / 8;
                 n_super = (int64_t)((i_tiles + 7) / 8) * sj;
             }
-            const int64_t blocks = ((n_super + 7) / 8) * 8 * 64;
+            const int64_t blocks = ((n_super + 7) / 8) * 8 * 8;  // one workgroup per row-tile of a super-tile
             // a grid dimension holds < 2^32 work-items (16.7 M workgroups of 256): fold the rest into y
             const int64_t gx = std::min<int64_t>(blocks, 1 << 22), gy = (blocks + gx - 1) / gx;
             if (n_super >= (int64_t)0x7fffffff || gy > 65535) {
