@@ -27,6 +27,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0
 ROW_BYTES = 512 * 4    # algorithmic bytes per vector: the row is read exactly once
 
 
+def synth_query(seed: int, dim: int = 512):
+    """unit-norm query vector (inputs of the timed path are generated here, not by the oracle)"""
+    import numpy as np
+    q = np.random.default_rng(10_000 + seed).standard_normal(dim).astype(np.float32)
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
 def cpu_baseline(local_index, k, sample_rows, n_queries):
     """The reference expression timed on this host's cores (numpy, all BLAS threads):
     scores = X @ q; np.argsort(-scores); first k distinct non-excluded images
@@ -63,7 +70,6 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
     with_cpu=False (ranks of an N > 1 run: every GPU runs its own replica of the sessions, the way
     seesaw_bench's parallel_run spreads sessions over actors) skips the CPU side and the sweep timing."""
     import numpy as np
-    from oracle import cpu_loop
     from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
     from seesaw_amd.bitmap import BitMap
     from seesaw_amd.seesaw_bench import benchmark_loop
@@ -114,6 +120,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                              "hip_nfound": g["nfound"]}
                 if not with_cpu:
                     continue
+                from oracle import cpu_loop  # the CPU leg: the reference's expressions on the host cores
                 qvec = ds.load_index().string2vec("a c1")
                 # bounded CPU sample: scipy label propagation over 1.56 M nodes takes seconds per round
                 cpu_rounds = 4 if (full and name == "knn_prop2") else 30
@@ -205,11 +212,10 @@ def c2_extras(device: int):
     of a complete host-to-host query (2-KB query in, packed top-100 out), 50 timed queries after 5 warm-ups,
     without and with 1000 excluded ids."""
     import numpy as np
-    from oracle import seesaw_oracle as orc
     from seesaw_amd.device_index import DeviceIndex
     n = 1_000_000
     idx = DeviceIndex.synthetic(n, 512, seed=2024, device=device)
-    qs = [orc.synth_query(1000 + i) for i in range(55)]
+    qs = [synth_query(1000 + i) for i in range(55)]
     excluded = np.random.default_rng(5).choice(n, size=1000, replace=False).tolist()
     out = {"rows": n, "k": 100}
     for tag, ex in (("no_exclusion", None), ("excluded_1000", excluded)):
@@ -277,14 +283,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from seesaw_amd.sharded import ShardedSyntheticIndex
-    from oracle import seesaw_oracle as orc
 
     n_total = int(args.rows)
     k = args.k
     dev = torch.device("cuda", local_rank)
     index = ShardedSyntheticIndex(n_total, 512, args.seed, rank, world, local_rank, k_max=max(128, k))
     nq = args.steps + args.warmup
-    q_host = np.stack([orc.synth_query(i) for i in range(nq)])
+    q_host = np.stack([synth_query(i) for i in range(nq)])
     q_dev = torch.from_numpy(q_host).to(dev)
     torch.cuda.synchronize(dev)
 
