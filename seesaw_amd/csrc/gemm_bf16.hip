@@ -157,27 +157,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
 // ---------------------------------------------------------------------------------------
 constexpr int G_WIMG = 16384;  // W image: 128 rows x 128 B
 
-// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the LDS bytes
-// [lds_dst, lds_dst + 1024) in lane order (lds_dst is wave-uniform).  Issued from inline asm so that
-// the compiler's wait-count bookkeeping is not disturbed: for the builtin form it degrades every
-// later s_waitcnt lgkmcnt / vmcnt to (0), which serialises fragment reads and MFMAs.  The vmcnt
-// accounting for these loads is done by hand (wait_vmcnt below).
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
-template <bool BUILTIN>
-__device__ __forceinline__ void glds16_sel(const void *gsrc, unsigned lds_dst) {
-    if constexpr (BUILTIN)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                         (__attribute__((address_space(3))) void *)(uintptr_t)lds_dst, 16, 0, 0);
-    else
-        glds16(gsrc, lds_dst);
-}
-#define SSW_GLDS16(gptr, lptr) glds16_sel<BUILTIN>((gptr), (lptr))
+// glds16 (ssw_common.h): one LDS-DMA wave-instruction, issued from inline asm
+#define SSW_GLDS16(gptr, lptr) glds16((gptr), (lptr))
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -190,7 +171,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // TM rows x 128 columns per block, TM / 64 x 2 waves of 64 x 64 each (TM = 128: 4 waves, 256: 8)
-template <int EPI, int DEPTH, int TM, bool PIPE, bool BUILTIN = false>
+template <int EPI, int DEPTH, int TM, bool PIPE>
 __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
@@ -401,19 +382,19 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
 
 int g_gemm_variant = 2;
 
-template <int EPI, int DEPTH, int TM, bool PIPE = false, bool BUILTIN = false>
+template <int EPI, int DEPTH, int TM, bool PIPE = false>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
                        int M, int N, int K) {
     static bool attr_set = false;
     constexpr int lds = DEPTH * (TM * 128 + G_WIMG);
     if (!attr_set) {
-        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE, BUILTIN>),
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE, BUILTIN>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
+    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
                        m_tiles, n_tiles);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;

@@ -117,13 +117,6 @@ __global__ void k_knn_reset(float *__restrict__ thr, unsigned *__restrict__ cnt,
 // ---------------------------------------------------------------------------------------
 // candidate pass: S~ tile on the matrix cores, thresholded append
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
 
 // rows [r0, r1) of Xh against columns [c0, c1) of Xh; thr / cnt / buf are indexed by row - r0.
 // SYM (r0 = c0 = 0, r1 = c1 = n): S~ is symmetric, so only tiles J >= I of the square are computed and an

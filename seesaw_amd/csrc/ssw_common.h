@@ -59,6 +59,19 @@ __host__ __device__ inline float ord_to_f32(uint32_t o) {
 #endif
 }
 
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to the LDS bytes
+// [lds_dst, lds_dst + 1024) in lane order (lds_dst is wave-uniform).  Issued from inline asm so that the
+// compiler's wait-count bookkeeping is not disturbed: for the builtin form it degrades every later
+// s_waitcnt lgkmcnt / vmcnt to (0), which serialises fragment reads and MFMAs.  The vmcnt accounting for
+// these loads is done by hand at the call sites (gemm_bf16.hip, knn.hip).
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = false;
