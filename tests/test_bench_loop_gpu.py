@@ -147,3 +147,27 @@ def test_benchmark_loop_sequence_matches_reference(name):
     ref = g[f"{name}_shown"]
     assert np.array_equal(shown, ref), (shown.tolist(), ref.tolist())
     assert out["nfound"] == int(g[f"{name}_nfound"]) and out["nseen"] == int(g[f"{name}_nseen"])
+
+
+def test_readme_session_snippet():
+    """the end-to-end snippet of README.md, as written there"""
+    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
+    from seesaw_amd.basic_types import IndexSpec, SessionParams
+    from seesaw_amd.seesaw_session import make_session
+    ds = make_dataset("demo", n_images=300, tiles_per_image=13, n_categories=2, positive_frac=0.05, seed=11, knn_k=10)
+    p = SessionParams(index_spec=IndexSpec(d_name="demo", i_name="multiscale"), interactive="multi_reg",
+                      interactive_options=dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None,
+                                               reg_data_lambda=0.0, reg_norm_lambda=100.0, reg_query_lambda=0.0,
+                                               verbose=False, max_iter=200, pos_weight="balanced", lr=1.0,
+                                               matrix_options=None),
+                      batch_size=1, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                      start_policy="after_first_batch", index_options={"use_vec_index": False})
+    session = make_session(GlobalDataManager().add(ds), p)["session"]
+    session.set_text("a c1")
+    shown = session.next()
+    assert len(shown) == 1
+    state = session.get_state()
+    session.update_state(state)
+    session.refine()
+    again = session.next()
+    assert len(again) == 1 and int(again[0]) != int(shown[0])
