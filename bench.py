@@ -84,12 +84,19 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                           pos_weight="balanced", lr=1.0, matrix_options=matrix),
         "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
                           calib_b=-0.4, prior_weight=1.0),
+        "pseudo_lr": dict(switch_over=True, real_sample_weight=1.0, sample_size=10000,
+                          log_reg_params=dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1,
+                                              fit_intercept=False),
+                          label_prop_params=dict(matrix_options=matrix, normalize_scores=False,
+                                                 sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4,
+                                                 prior_weight=1.0)),
     }
+    cpu_legs = ("plain", "multi_reg", "knn_prop2")  # loops oracle/cpu_loop.py restates
     out = {}
     import contextlib
     import io
-    for tag, n_images, knn_k, names in (("lvis_1109x13", 1109, 10, ("plain", "multi_reg", "knn_prop2")),
-                                        (f"full_{full_images}x13", full_images, 10, ("plain", "multi_reg", "knn_prop2"))):
+    for tag, n_images, knn_k, names in (("lvis_1109x13", 1109, 10, ("plain", "multi_reg", "knn_prop2", "pseudo_lr")),
+                                        (f"full_{full_images}x13", full_images, 10, ("plain", "multi_reg", "knn_prop2", "pseudo_lr"))):
         ds = make_dataset("lvis", n_images=n_images, tiles_per_image=13, n_categories=2, positive_frac=0.05,
                           seed=11, knn_k=knn_k, device=device)
         ds.embedding.noise = 1.2  # a mediocre text query, so the loop runs all its rounds
@@ -118,7 +125,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
                              "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])), "iters": len(g["latencies"]),
                              "hip_nfound": g["nfound"]}
-                if not with_cpu:
+                if not with_cpu or name not in cpu_legs:
                     continue
                 from oracle import cpu_loop  # the CPU leg: the reference's expressions on the host cores
                 qvec = ds.load_index().string2vec("a c1")

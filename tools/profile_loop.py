@@ -23,9 +23,15 @@ opts = {"plain": None,
                           reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200, pos_weight="balanced",
                           lr=1.0, matrix_options=matrix),
         "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
-                          calib_b=-0.4, prior_weight=1.0)}[name]
+                          calib_b=-0.4, prior_weight=1.0),
+        "pseudo_lr": dict(switch_over=True, real_sample_weight=1.0, sample_size=10000,
+                          log_reg_params=dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1,
+                                              fit_intercept=False),
+                          label_prop_params=dict(matrix_options=matrix, normalize_scores=False,
+                                                 sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4,
+                                                 prior_weight=1.0))}[name]
 ds = make_dataset("lvis", n_images=n_images, tiles_per_image=13, n_categories=2, positive_frac=0.05, seed=11,
-                  knn_k=10 if name == "knn_prop2" else 0)
+                  knn_k=10 if name in ("knn_prop2", "pseudo_lr") else 0)
 ds.embedding.noise = 1.2
 gdm = GlobalDataManager().add(ds)
 boxes, _ = ds.load_ground_truth()
