@@ -102,3 +102,21 @@ def test_build_knn_graph_saved_where_the_loops_look(oracle, tmp_path):
     with pytest.raises(NotImplementedError):
         compute_knn_from_nndescent(X, n_neighbors=60)
     idx._dev.close()
+
+
+@pytest.mark.parametrize("n", [513, 1025, 4097])
+def test_knn_awkward_sizes(oracle, n):
+    """sizes one past a level / tile boundary: clamped operand rows, padded thresholds, ragged last tiles"""
+    X = oracle.synth_rows(900 + n, 0, n, 512)
+    assert _check_vs_oracle(oracle, X, 10) <= 2
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_knn_one_past_the_row_batch(oracle, monkeypatch, batched):
+    """131 073 rows: the batched path runs a second batch of ONE row; the all-rows path a ragged last tile"""
+    if batched:
+        monkeypatch.setenv("SSW_KNN_FORCE_BATCHED", "1")
+    n = 131_073
+    X = oracle.synth_rows(31, 0, n, 512)
+    rows = [0, 1, 127, 128, 131_071, 131_072] + np.random.default_rng(8).integers(0, n, size=20).tolist()
+    assert _check_vs_oracle(oracle, X, 10, rows=rows) <= n // 100
