@@ -302,7 +302,8 @@ ssw_status ssw_clip_sync(ssw_clip *clip);
  * launches and the max |difference| to variant 0.  Not part of the reference's interface. */
 ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
                           float *out_ms, float *out_maxdiff);
-/* Selects the GEMM variant the towers use (0 register-staged, 2 LDS-DMA ring [default], 7 256-row pipelined). */
+/* Selects the GEMM variant the towers use (0 register-staged, 2 LDS-DMA ring with 4 waves per tile,
+ * 14 the same with 8 waves per tile [default], 7 256-row pipelined). */
 ssw_status ssw_tune_gemm(int32_t variant);
 
 #ifdef __cplusplus

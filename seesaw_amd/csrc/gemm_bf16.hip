@@ -5,7 +5,8 @@
 // Replaces the torch/cuBLAS linears inside transformers' CLIPModel that the reference calls
 // (seesaw/models/embeddings.py:42-76 -> CLIPVisionModel / CLIPTextModel layers).
 //
-// variant 2 (default): LDS-DMA pipeline.  A 128x128 tile per 256-thread block, BK = 64:
+// variant 14 (default): LDS-DMA pipeline.  A 128x128 tile per 512-thread block (8 waves of 64 x 32: twice the
+// waves of variant 2's 64 x 64 per wave for the same tile hide each other's waits, +2...6 %), BK = 64:
 //   * staging is global_load_lds_dwordx4 only (no VGPR round trip): one wave-instruction fills
 //     8 rows x 128 B of the LDS image, lane-linear, reading whole 128-B lines;
 //   * the image is XOR-swizzled through the SOURCE address (16-B chunk c of row r sits at chunk
@@ -170,17 +171,21 @@ __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-// TM rows x 128 columns per block, TM / 64 x 2 waves of 64 x 64 each (TM = 128: 4 waves, 256: 8)
-template <int EPI, int DEPTH, int TM, bool PIPE>
-__global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
+// TM rows x 128 columns per block, TM / 64 x WN waves of 64 x (128 / WN) each (WN = 2: 64 x 64 per wave;
+// WN = 4: 64 x 32 per wave, twice the waves for the same tile)
+template <int EPI, int DEPTH, int TM, bool PIPE, int WN = 2>
+__global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
                                                     int M, int N, int K, int m_tiles, int n_tiles) {
-    constexpr int NW = TM / 32;            // waves
+    constexpr int NW = (TM / 64) * WN;     // waves
+    constexpr int NJ = 128 / WN / 16;      // 16-column accumulator tiles per wave
+    constexpr int AP = (TM / 8) / NW;      // A pieces (8 rows x 128 B) per wave
+    static_assert(!PIPE || WN == 2, "the pipelined loop is written for 64 x 64 per wave");
     constexpr int AIMG = TM * 128;         // A image bytes per stage
     constexpr int STAGE = AIMG + G_WIMG;   // ring stage
-    constexpr int WP = 16 / NW;            // W pieces per wave (A pieces per wave: 4)
-    constexpr int LOADS = 4 + WP;          // LDS-DMA instructions per wave and stage
+    constexpr int WP = 16 / NW;            // W pieces per wave
+    constexpr int LOADS = AP + WP;         // LDS-DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -191,15 +196,15 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
     const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
     if (mt >= m_tiles) return;
     const int m0 = mt * TM, n0 = nt * BN;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // staging: a piece is 8 rows x 128 B (one wave-instruction); lane l lands at row l / 8, chunk
     // position l % 8 and therefore fetches chunk (l % 8) ^ swz(row)
-    const bf16 *a_src[4];
+    const bf16 *a_src[AP];
     const bf16 *w_src[WP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < AP; ++i) {
+        const int row = (wave * AP + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         a_src[i] = A + (int64_t)min(m0 + row, M - 1) * K + chunk * 8;
     }
@@ -210,12 +215,12 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
         w_src[i] = W + (int64_t)(n0 + row) * K + chunk * 8;
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
-    const unsigned a_dst = lds0 + wave * 4096;
+    const unsigned a_dst = lds0 + wave * (AP * 1024);
     const unsigned w_dst = lds0 + AIMG + wave * (WP * 1024);
 #define SSW_ISSUE(kt, buf)                                                                 \
     {                                                                                      \
         const int k0 = (kt) * BK;                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                      \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                     \
             SSW_GLDS16(a_src[i] + k0, a_dst + (buf) * STAGE + i * 1024);                   \
         _Pragma("unroll") for (int i = 0; i < WP; ++i)                                     \
             SSW_GLDS16(w_src[i] + k0, w_dst + (buf) * STAGE + i * 1024);                   \
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
     const int fr = lane & 15, fq = lane >> 4;
     // The accumulators start from the bias.  (Starting them from bias + residual as well was measured:
     // it moves the exposed residual read from the tail of a single-round launch to its head, -8 %.)
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + fq * 4;
+    for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI != EPI_F32) bv = *reinterpret_cast<const f32x4 *>(bias + col);
 #pragma unroll
@@ -236,22 +241,21 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
 
     // fragment byte offset inside an image: row (16-row block + fr), chunk (4 ks + fq) ^ (fr >> 1)
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
-    const int a_frag = wm * 8192 + frag0, w_frag = AIMG + wn * 8192 + frag0;
+    const int a_frag = wm * 8192 + frag0, w_frag = AIMG + wn * (128 / WN) * 128 + frag0;
 #define SSW_COMPUTE(buf)                                                                              \
     {                                                                                                 \
         const unsigned char *sb = smem + (buf) * STAGE;                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
-            bf16x8 a[4], b[4];                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                a[i] = *reinterpret_cast<const bf16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));     \
-                b[i] = *reinterpret_cast<const bf16x8 *>(sb + ((w_frag + i * 2048) ^ (ks * 64)));     \
-            }                                                                                         \
+            bf16x8 a[4], b[NJ];                                                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+                a[i] = *reinterpret_cast<const bf16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));     \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                            \
+                b[j] = *reinterpret_cast<const bf16x8 *>(sb + ((w_frag + j * 2048) ^ (ks * 64)));     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                        \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0); \
         }                                                                                             \
     }
-
 #define SSW_READ_FRAGS(buf, ks, a, b)                                                                 \
     {                                                                                                 \
         const unsigned char *sb = smem + (buf) * STAGE;                                               \
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
         const int row = m0 + wm * 64 + i * 16 + fr;
         if (row >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + fq * 4;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
             const int64_t o = (int64_t)row * N + col;
             f32x4 v = acc[i][j];
             if (EPI == EPI_BF16_BIAS_GELU) {
@@ -380,21 +384,21 @@ __global__ __launch_bounds__(TM * 2) void gemm_glds(const bf16 *__restrict__ A, 
     }
 }
 
-int g_gemm_variant = 2;
+int g_gemm_variant = 14;
 
-template <int EPI, int DEPTH, int TM, bool PIPE = false>
+template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
                        int M, int N, int K) {
     static bool attr_set = false;
     constexpr int lds = DEPTH * (TM * 128 + G_WIMG);
     if (!attr_set) {
-        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE>),
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE, WN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE>), dim3(grid), dim3(TM * 2), lds, s, A, W, bias, res, C, M, N, K,
+    hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE, WN>), dim3(grid), dim3(TM * WN), lds, s, A, W, bias, res, C, M, N, K,
                        m_tiles, n_tiles);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -410,7 +414,8 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
             SSW_HIP_TRY(hipGetLastError());
             return SSW_OK;
         case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
-        default: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
+        case 2: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
+        default: return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
     }
 }
 
@@ -469,7 +474,7 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant != 0 && variant != 2 && variant != 7) {
+    if (variant != 0 && variant != 2 && variant != 7 && variant != 14) {
         ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
         return SSW_ERR_INVALID;
     }

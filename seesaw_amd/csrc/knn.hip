@@ -124,7 +124,7 @@ __global__ void k_knn_reset(float *__restrict__ thr, unsigned *__restrict__ cnt,
 // columns all lie below tile index `mirror_from` were covered by the earlier (non-symmetric) levels and are
 // skipped, and the mirrored entries of tiles with I < mirror_from likewise.
 template <bool SYM>
-__global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__ Xh, int D, int r0, int r1, int c0,
+__global__ __launch_bounds__(512) void k_knn_gemm_filter(const f16 *__restrict__ Xh, int D, int r0, int r1, int c0,
                                                          int c1, const float *__restrict__ thr,
                                                          unsigned *__restrict__ cnt, uint64_t *__restrict__ buf,
                                                          int i_tiles, int j_tiles, int sj_count, int n_super,
@@ -163,33 +163,33 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
     if (SYM) j_lo = max(j_lo, max(I, mirror_from));
     if (j_lo >= j_hi) return;
     const int m0 = r0 + I * KT;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;  // 8 waves: 2 x 4, each 64 rows x 32 columns of the 128 x 128 tile
 
-    const f16 *a_src[4];
-    int b_chunk[4], b_row[4];
+    const f16 *a_src[2];
+    int b_chunk[2], b_row[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < 2; ++i) {  // 16 pieces (8 rows x 128 B) per operand image, 2 per wave
+        const int row = (wave * 2 + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         a_src[i] = Xh + (int64_t)min(m0 + row, r1 - 1) * D + chunk * 8;
         b_row[i] = row;
         b_chunk[i] = chunk * 8;
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
-    const unsigned a_dst = lds0 + wave * 4096, b_dst = lds0 + K_OPER + wave * 4096;
+    const unsigned a_dst = lds0 + wave * 2048, b_dst = lds0 + K_OPER + wave * 2048;
     // stage (column tile J, k-step kt) -> ring slot
 #define KNN_ISSUE(J, kt, slot)                                                                         \
     {                                                                                                  \
         const int k0 = (kt) * KBK, nb = c0 + (J) * KT;                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
             glds16(a_src[i] + k0, a_dst + (slot) * K_STAGE + i * 1024);                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
             glds16(Xh + (int64_t)min(nb + b_row[i], c1 - 1) * D + b_chunk[i] + k0,                     \
                    b_dst + (slot) * K_STAGE + i * 1024);                                               \
     }
     const int fr = lane & 15, fq = lane >> 4;
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
-    const int a_frag = wm * 8192 + frag0, b_frag = K_OPER + wn * 8192 + frag0;
+    const int a_frag = wm * 8192 + frag0, b_frag = K_OPER + wn * 4096 + frag0;
     // thresholds of this lane's four rows (accumulator row = m0 + wm*64 + i*16 + fr): the same for every
     // column tile of the walk
     float trow[4];
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
     KNN_ISSUE(j_lo, 0, 0)
     int slot = 0;
     for (int J = j_lo; J < j_hi; ++J) {
-        f32x4 acc[4][4];
+        f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -222,16 +222,17 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
             const unsigned char *sb = smem + slot * K_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                f16x8 a[4], b[4];
+                f16x8 a[4], b[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i)
                     a[i] = *reinterpret_cast<const f16x8 *>(sb + ((a_frag + i * 2048) ^ (ks * 64)));
-                    b[i] = *reinterpret_cast<const f16x8 *>(sb + ((b_frag + i * 2048) ^ (ks * 64)));
-                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    b[j] = *reinterpret_cast<const f16x8 *>(sb + ((b_frag + j * 2048) ^ (ks * 64)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
             }
             asm volatile("" ::: "memory");
@@ -239,16 +240,16 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
         }
         const int n0 = c0 + J * KT;
         const bool mirror = SYM && I != J && I >= mirror_from;
-        // acc[i][j][r] = S~[row m0 + wm*64 + i*16 + fr][column n0 + wn*64 + j*16 + fq*4 + r]
+        // acc[i][j][r] = S~[row m0 + wm*64 + i*16 + fr][column n0 + wn*32 + j*16 + fq*4 + r]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float tr = trow[i];
             const int lrow = m0 + wm * 64 + i * 16 + fr - r0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
                 const f32x4 v = acc[i][j];
                 if (fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > tr) {
-                    const int col = n0 + wn * 64 + j * 16 + fq * 4;
+                    const int col = n0 + wn * 32 + j * 16 + fq * 4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (v[r] > tr && col + r < c1) {
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(256) void k_knn_gemm_filter(const f16 *__restrict__
         }
         if (mirror) {  // entry (j, i) of the symmetric matrix: this tile's columns as rows, its rows as columns
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wn * 64 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 32 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
                 const f32x4 tc = *reinterpret_cast<const f32x4 *>(thr + col);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -493,8 +494,8 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
                 n_super = (int64_t)((i_tiles + 7) / 8) * sj;
             }
             const int64_t blocks = ((n_super + 7) / 8) * 8 * 8;  // one workgroup per row-tile of a super-tile
-            // a grid dimension holds < 2^32 work-items (16.7 M workgroups of 256): fold the rest into y
-            const int64_t gx = std::min<int64_t>(blocks, 1 << 22), gy = (blocks + gx - 1) / gx;
+            // a grid dimension holds < 2^32 work-items (8.4 M workgroups of 512): fold the rest into y
+            const int64_t gx = std::min<int64_t>(blocks, 1 << 22), gy = (blocks + gx - 1) / gx;  // 2^22 x 512 < 2^32
             if (n_super >= (int64_t)0x7fffffff || gy > 65535) {
                 set_error("ssw_knn_build: level of %lld x %lld tiles exceeds one launch", (long long)i_tiles,
                           (long long)j_tiles);
@@ -503,11 +504,11 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
             }
             const dim3 grid((unsigned)gx, (unsigned)gy);
             if (last_sym)
-                hipLaunchKernelGGL(k_knn_gemm_filter<true>, grid, dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D, 0,
+                hipLaunchKernelGGL(k_knn_gemm_filter<true>, grid, dim3(512), 2 * K_STAGE, s, sc.Xh, (int)D, 0,
                                    (int)n, 0, (int)n, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj, (int)n_super,
                                    (int)(c0 / KT));
             else
-                hipLaunchKernelGGL(k_knn_gemm_filter<false>, grid, dim3(256), 2 * K_STAGE, s, sc.Xh, (int)D,
+                hipLaunchKernelGGL(k_knn_gemm_filter<false>, grid, dim3(512), 2 * K_STAGE, s, sc.Xh, (int)D,
                                    (int)r0, (int)r1, (int)c0, (int)c1, sc.thr, sc.cnt, sc.buf, i_tiles, j_tiles, sj,
                                    (int)n_super, 0);
             hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows, M);

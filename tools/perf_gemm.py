@@ -20,7 +20,7 @@ SHAPES = [  # (M, N, K, epi, what)
 
 def main():
     lib = _lib.load()
-    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0, 2, 7]
+    variants = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [0, 2, 14, 7]
     iters = 20
     for M, N, K, epi, what in SHAPES:
         line = f"{what:10s} M={M:6d} N={N:5d} K={K:5d} epi={epi}"
