@@ -28,6 +28,8 @@ class _Record(BaseModel):
 
 
 class Box(_Record):
+    """axis-aligned box in image pixels; as user feedback it carries the query text it answers and whether the
+    user accepted it"""
     x1: float
     y1: float
     x2: float
@@ -37,22 +39,26 @@ class Box(_Record):
 
 
 class Annotation(_Record):
+    """a box with its own description / acceptance (textual-feedback experiments)"""
     box: Box
     description: Optional[str] = None
     marked_accepted: bool = False
 
 
 class ActivationData(_Record):
+    """why an image was returned: the tile that scored and its score"""
     box: Box
     score: float
 
 
 class Interval(_Record):
+    """time span (ms) an image spent on screen, recorded by the UI"""
     start_ms: int
     end_ms: int
 
 
 class Imdata(_Record):
+    """one result image as the UI / the simulated user sees it"""
     url: str
     dbidx: int
     boxes: Optional[List[Box]] = None  # None: not labelled yet; []: seen, nothing marked
@@ -65,6 +71,7 @@ def is_image_accepted(imdata: Imdata) -> bool:
 
 
 class IndexSpec(_Record):
+    """which dataset (d_name), which of its indices (i_name) and optionally which subset (c_name)"""
     d_name: str
     i_name: str
     c_name: Optional[str] = None  # ground-truth category naming an LVIS-style subset
@@ -75,6 +82,8 @@ StartPolicy = Literal["from_start", "after_first_batch", "after_first_negative",
 
 
 class SessionParams(_Record):
+    """everything that defines a search session: index, loop (`interactive` + its options), batch and shortlist
+    sizes, per-image aggregation"""
     index_spec: IndexSpec
     interactive: str
     pass_ground_truth: Optional[bool] = False
@@ -92,6 +101,7 @@ class SessionParams(_Record):
 
 
 class LogEntry(_Record):
+    """one line of the session's action log"""
     logger: Literal["server", "client"]
     message: str
     time: float
@@ -101,6 +111,7 @@ class LogEntry(_Record):
 
 
 class SessionState(_Record):
+    """the whole visible state of a session: parameters, every batch returned so far, timings, log"""
     params: SessionParams
     gdata: List[List[Imdata]]
     timing: List[float]
@@ -110,6 +121,7 @@ class SessionState(_Record):
 
 
 class BenchParams(_Record):
+    """one benchmark run: target category, query string, number of batches, stopping rules, simulated-user knobs"""
     name: str
     sample_id: Optional[str] = None
     ground_truth_category: str
@@ -123,6 +135,7 @@ class BenchParams(_Record):
 
 
 class BenchResult(_Record):
+    """outcome of a benchmark run (found / seen counts, the final session state, timings)"""
     nimages: int
     ntotal: int
     session: SessionState
@@ -133,6 +146,7 @@ class BenchResult(_Record):
 
 
 class BenchSummary(_Record):
+    """what `summary.json` of a run directory holds"""
     bench_params: BenchParams
     session_params: SessionParams
     timestamp: str

@@ -52,9 +52,13 @@ class LoopBase:
                                      agg_method=p.agg_method, aug_larger=p.aug_larger,
                                      rescore_method=lambda vecs: vecs @ vec.reshape(-1, 1))
 
-    @staticmethod
-    def from_params(gdm, q, params) -> "LoopBase":
-        raise NotImplementedError
+    @classmethod
+    def from_params(cls, gdm, q, params) -> "LoopBase":
+        """the registry's constructor hook (every loop of the reference defines the same three-argument
+        static method; here the concrete loops inherit it)"""
+        if cls is LoopBase:
+            raise NotImplementedError
+        return cls(gdm, q, params)
 
     def next_batch_external(self):
         if self.started:

@@ -98,10 +98,6 @@ class MultiReg(PointBased):
             self.xlx_matrix = get_weight_matrix_from_index(q.index, self.options["matrix_options"], xlx_matrix=True)
         self._engine = FeedbackEngine(q.index.vectors.shape[1], device=getattr(q.index, "device", 0))
 
-    @staticmethod
-    def from_params(gdm, q, params):
-        return MultiReg(gdm, q, params)
-
     def set_text_vec(self, tvec):
         super().set_text_vec(tvec)
         # with both regularisers on, optimise the query against them before any label exists

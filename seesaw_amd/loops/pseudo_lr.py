@@ -9,23 +9,22 @@ from .util import makeXy_rows
 
 
 class PseudoLR(PointBased):
+    """two rankers side by side: a KnnProp2 over the k-NN graph produces pseudo-labels (and serves the batches
+    until both classes have a real label, when `switch_over` is set); the logistic scorer fitted on real +
+    pseudo labels serves them afterwards"""
+
     def __init__(self, gdm, q, params):
-        super().__init__(gdm, q, params)
-        o = self.options = self.params.interactive_options
-        self.label_prop_params = o["label_prop_params"]
-        self.log_reg_params = o["log_reg_params"]
-        self.switch_over = o["switch_over"]
-        self.real_sample_weight = o["real_sample_weight"]
-        assert self.real_sample_weight >= 1.0
+        PointBased.__init__(self, gdm, q, params)
+        opts = self.options = params.interactive_options
+        for name in ("label_prop_params", "log_reg_params", "switch_over", "real_sample_weight"):
+            setattr(self, name, opts[name])
+        if not self.real_sample_weight >= 1.0:
+            raise AssertionError("real labels must weigh at least as much as pseudo-labels")
         self.knn_based = KnnProp2(gdm, q, params, knn_model=get_label_prop(q, label_prop_params=self.label_prop_params))
 
-    @staticmethod
-    def from_params(gdm, q, params):
-        return PseudoLR(gdm, q, params)
-
     def set_text_vec(self, tvec):
-        super().set_text_vec(tvec)
-        self.knn_based.set_text_vec(tvec)
+        for loop in (super(), self.knn_based):
+            loop.set_text_vec(tvec)
 
     def refine(self, change=None):
         self.knn_based.refine()

@@ -3,10 +3,6 @@ from .loop_base import LoopBase
 
 
 class RandomResults(LoopBase):
-    @staticmethod
-    def from_params(gdm, q, params):
-        return RandomResults(gdm, q, params)
-
     def set_text_vec(self, vec):
         super().set_text_vec(vec)
 

@@ -11,10 +11,6 @@ class RocchioUpdate(PointBased):
         o = params.interactive_options
         self.alpha, self.beta, self.gamma = o["rocchio_alpha"], o["rocchio_beta"], o["rocchio_gamma"]
 
-    @staticmethod
-    def from_params(gdm, q, params):
-        return RocchioUpdate(gdm, q, params)
-
     def refine(self, change=None):
         matchdf = self.q.getXy()
         X = self.q.index.vectors[matchdf.index.values]

@@ -17,18 +17,16 @@ from .loops.registry import build_loop_from_params
 
 
 class Session:
+    """State kept per session: the batches returned so far (`acc_indices`, `acc_activations`), which images were
+    seen / accepted, the label database of the query object (`q.label_db`, what the loops learn from), per-call
+    timings and the action log.  The loop object (`self.loop`) owns the ranking state."""
+
     def __init__(self, gdm, dataset, hdb: AccessMethod, params: SessionParams, _y: np.ndarray = None):
-        self.gdm = gdm
-        self.dataset = dataset
-        self.acc_indices = []
-        self.acc_activations = []
-        self.seen = BitMap([])
-        self.accepted = BitMap([])
-        self.params = params
-        self.init_q = None
-        self.timing = []
-        self.image_timing = {}
-        self.index = hdb
+        self.gdm, self.dataset, self.index, self.params = gdm, dataset, hdb, params
+        self.acc_indices, self.acc_activations = [], []   # one entry per batch returned
+        self.seen, self.accepted = BitMap([]), BitMap([])
+        self.timing, self.image_timing = [], {}           # seconds per next(); UI intervals per image
+        self.init_q = None                                 # the text of the query, once set
         self.q = hdb.new_query()
         if _y is not None:
             from .calibration import GroundTruthCalibrator
@@ -47,9 +45,11 @@ class Session:
         self._log("init")
 
     def get_totals(self):
-        return {"seen": len(self.seen), "accepted": len(self.accepted)}
+        """counts shown by the UI header"""
+        return dict(seen=len(self.seen), accepted=len(self.accepted))
 
     def get_method_stats(self):
+        """whatever the loop wants recorded in the benchmark summary"""
         return self.loop.get_stats()
 
     def _log(self, message: str):
@@ -57,6 +57,7 @@ class Session:
                                 "seen": len(self.seen), "accepted": len(self.accepted)})
 
     def next(self):
+        """next batch of image ids from the loop; the batch and its activations are remembered for get_state"""
         self._log("next.start")
         start = time.time()
         r = self.loop.next_batch_external()
@@ -67,6 +68,7 @@ class Session:
         return r["dbidxs"]
 
     def set_text(self, key):
+        """embed the text (CLIP text tower through the index) and hand the unit vector to the loop"""
         self._log("set_text")
         self.init_q = key
         self.loop.state.curr_str = key
@@ -75,6 +77,7 @@ class Session:
         self.loop.set_text_vec(vec)
 
     def update_state(self, state: SessionState):
+        """take the client's view of the session (labels drawn on the returned images) as the new truth"""
         self._update_labeldb(state)
         self._log("update_state.end")
         if self._check_reversals():
@@ -94,11 +97,13 @@ class Session:
         return False
 
     def refine(self):
+        """let the loop learn from the labels that changed since the last call"""
         self._log("refine.start")
         self.loop.refine_external(self._last_change)
         self._log("refine.end")
 
     def get_state(self) -> SessionState:
+        """every batch so far as Imdata records (boxes from the label database), plus log and timings"""
         gdata = []
         last = len(self.acc_indices) - 1
         for i, (indices, accs) in enumerate(zip(self.acc_indices, self.acc_activations)):
