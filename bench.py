@@ -194,6 +194,13 @@ def clip_extras(device: int):
     for _ in range(n):
         m.embed_text(ids)
     dtt = (time.perf_counter() - t0) / n
+    one = ids[:1, :8].copy()  # one short query string, the interactive case (set_text)
+    one[:, -1] = 49407
+    m.embed_text(one)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        m.embed_text(one)
+    dt1 = (time.perf_counter() - t0) / 20
     m.close()
     # CPU side by side: the in-container transformers.CLIPModel, f32, torch-CPU,
     # all host threads, same random-init weights, on a bounded sample of 16 tiles
@@ -211,6 +218,7 @@ def clip_extras(device: int):
     return {"cpu_baseline": cpu, "image_batch": B, "image_ms_per_batch": dt * 1e3, "tiles_per_s": B / dt, "tflops": tf,
             "mfma_peak_tflops": 2500.0, "frac_of_bf16_dense_peak": tf / 2500.0,
             "text_batch": 16, "text_len": 77, "text_ms_per_batch_host_io": dtt * 1e3, "texts_per_s": 16 / dtt,
+            "single_query_8_tokens_ms_host_io": dt1 * 1e3,
             "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}
 
 
