@@ -262,6 +262,15 @@ ssw_status ssw_fb_scores(ssw_fb *fb, const float *w_host, int32_t has_bias, floa
 ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, int32_t max_iter,
                       float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss);
 
+/* The pairwise rank losses on given scores (no data matrix): per-item column sums and d(sum)/d scores.
+ * replaces ref_pairwise_rank_loss / ref_pairwise_logistic_loss(aggregate='sum') and
+ * ref_pairwise_rank_loss_gradient, seesaw/rank_loss.py:34-106, and the per-item normalisation of
+ * RegModule._step, seesaw/loops/multi_reg.py:106-121: out_item_loss[j] = coef_j / max_inversions_j *
+ * sum_i loss_ij (coef NULL = all ones; coef = max_inversions gives the raw sums), out_grad = d sum_j / d scores. */
+ssw_status ssw_rank_pairwise(int32_t device, int32_t logistic, const float *target_host, const float *scores_host,
+                             const float *coef_host_or_null, int32_t n, float margin, double *out_item_loss,
+                             float *out_grad);
+
 /* ------------------------------------------------------------------------- */
 /* CLIP ViT-B/32 image / text towers (bf16 MFMA forward)                       */
 /* replaces: transformers.CLIPModel.get_text_features                          */

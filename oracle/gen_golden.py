@@ -18,13 +18,32 @@ from oracle import _ref_import as R  # noqa: E402
 from oracle import seesaw_oracle as orc  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-os.makedirs(GOLDEN, exist_ok=True)
+OUT_DIR = GOLDEN  # --check redirects the writes to a scratch directory
 
 
 def save(name, **arrays):
-    path = os.path.join(GOLDEN, name + ".npz")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+def compare_npz(path_a, path_b):
+    """-> list of differences between two .npz files, array by array: keys, dtype, shape and raw bytes
+    (the zip container itself carries timestamps, so files are compared by content)."""
+    a, b = np.load(path_a), np.load(path_b)
+    diffs = [f"key only in {os.path.basename(p)}: {k}" for p, ks in ((path_a, set(a.files) - set(b.files)),
+                                                                      (path_b, set(b.files) - set(a.files))) for k in sorted(ks)]
+    for k in sorted(set(a.files) & set(b.files)):
+        x, y = a[k], b[k]
+        if x.dtype != y.dtype or x.shape != y.shape:
+            diffs.append(f"{k}: {x.dtype}{x.shape} vs {y.dtype}{y.shape}")
+        elif x.tobytes() != y.tobytes():
+            if x.dtype.kind == "f":
+                diffs.append(f"{k}: values differ, max |delta| = {np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64))):.3e}")
+            else:
+                diffs.append(f"{k}: values differ")
+    return diffs
 
 
 def synth_vector_meta(n_images, tiles_per_image, dbidx_of_position, rng):
@@ -273,7 +292,7 @@ def gen_rank_loss():
 
 
 # ------------------------------------------------------------------------------------
-def _labelled_set(seed, n, n_pos, dim=512):
+def _labelled_set(seed, n, n_pos, dim=512, q_noise=0.8):
     """A small labelled set shaped like q.getXy(): tile vectors of seen images."""
     rng = np.random.default_rng(seed)
     target = orc.synth_query(seed)
@@ -283,13 +302,41 @@ def _labelled_set(seed, n, n_pos, dim=512):
     X[pos] = X[pos] + 0.6 * target
     X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
     y[pos] = 1.0
-    q = target + 0.8 * orc.synth_query(seed + 77)
+    q = target + q_noise * orc.synth_query(seed + 77)
     q = (q / np.linalg.norm(q)).astype(np.float32)
     return X, y, q
 
 
+class _Trajectory:
+    """Records every (w, loss, grad) the reference's L-BFGS closure evaluates (basic_trainer.py:24-57):
+    `training_step` is wrapped to note the parameter and the loss it returns, a tensor hook on the
+    parameter notes the gradient of the one backward() that follows."""
+
+    def __init__(self, module, param):
+        self.w, self.loss, self.grad = [], [], []
+        orig = module.training_step
+
+        def step(batch, batch_idx, _o=orig):
+            ret = _o(batch, batch_idx)
+            self.w.append(param.detach().clone().numpy().reshape(-1))
+            self.loss.append(float(ret["loss"].detach().item()))
+            return ret
+
+        module.training_step = step
+        param.register_hook(lambda g: self.grad.append(g.detach().clone().numpy().reshape(-1)))
+
+    def arrays(self):
+        assert len(self.w) == len(self.loss) == len(self.grad), (len(self.w), len(self.loss), len(self.grad))
+        return (np.stack(self.w).astype(np.float32), np.asarray(self.loss, dtype=np.float64),
+                np.stack(self.grad).astype(np.float32))
+
+
+FIT_SEEDS = (0, 1, 2)  # torch seeds: the reference's DataLoader shuffles the rows, so a fit depends on the seed
+
+
 def gen_logreg():
-    """(iv-a) LogisticRegressionPT.fit -> get_coeff (logistic_regression.py:270-421)."""
+    """(iv-a) LogisticRegressionPT.fit -> get_coeff (logistic_regression.py:270-421), seeded before every
+    fit; the whole closure trajectory of the first seed and the coefficients of all FIT_SEEDS are kept."""
     import torch
     lr = R.ref("seesaw.logistic_regression")
     out = {}
@@ -297,41 +344,56 @@ def gen_logreg():
     for (n, n_pos, lam, cw, with_weights) in [(40, 6, 1.0, "balanced", False), (300, 30, 3.3, "balanced", False),
                                               (120, 10, 10.0, 1.0, True), (13, 1, 1.0, "balanced", False)]:
         X, y, q = _labelled_set(500 + i, n, n_pos)
-        captured = {}
+        sw = None
+        if with_weights:
+            sw = np.ones((n, 1))
+            sw[: n // 3] = 4.0
         orig_init = lr.LogisticRegModule.__init__
+        coeffs = []
+        for seed in FIT_SEEDS:
+            captured = {}
 
-        def patched(self, *a, _o=orig_init, **kw):
-            _o(self, *a, **kw)
-            captured["w0"] = self.linear.weight.detach().clone().numpy()
-            captured["b0"] = None if self.linear.bias is None else self.linear.bias.detach().clone().numpy()
+            # fit() draws twice from torch's generator: nn.Linear's initial weights (inside the module's
+            # __init__) and then the DataLoader shuffle.  w0 is the same for every seed of a case (it is
+            # handed to the HIP path as the start point); `seed` governs the shuffle only.
+            def patched(self, *a, _o=orig_init, _seed=seed, **kw):
+                _o(self, *a, **kw)
+                captured["w0"] = self.linear.weight.detach().clone().numpy()
+                captured["traj"] = _Trajectory(self, self.linear.weight)
+                torch.manual_seed(_seed)
 
-        lr.LogisticRegModule.__init__ = patched
-        try:
-            torch.manual_seed(1000 + i)
-            model = lr.LogisticRegressionPT(class_weights=cw, scale="centered", reg_lambda=lam,
-                                            regularizer_vector=q, fit_intercept=False, max_iter=200, lr=1.0)
-            sw = None
-            if with_weights:
-                sw = np.ones((n, 1))
-                sw[: n // 3] = 4.0
-            model.fit(X, y.reshape(-1, 1), sw)
-        finally:
-            lr.LogisticRegModule.__init__ = orig_init
+            lr.LogisticRegModule.__init__ = patched
+            try:
+                torch.manual_seed(1000 + i)
+                model = lr.LogisticRegressionPT(class_weights=cw, scale="centered", reg_lambda=lam,
+                                                regularizer_vector=q, fit_intercept=False, max_iter=200, lr=1.0)
+                model.fit(X, y.reshape(-1, 1), sw)
+            finally:
+                lr.LogisticRegModule.__init__ = orig_init
+            coeffs.append(model.get_coeff().reshape(-1).copy())
+            if seed == FIT_SEEDS[0]:
+                first, first_captured = model, captured
+        tw, tl, tg = first_captured["traj"].arrays()
         out[f"c{i}_X"], out[f"c{i}_y"], out[f"c{i}_q"] = X, y, q
         out[f"c{i}_lam"] = np.asarray(lam)
         out[f"c{i}_cw"] = np.asarray(-1.0 if cw == "balanced" else cw)
         out[f"c{i}_sw"] = np.zeros(0) if sw is None else sw.reshape(-1)
-        out[f"c{i}_w0"] = captured["w0"]
-        out[f"c{i}_coeff"] = model.get_coeff()
-        out[f"c{i}_losses"] = np.array([l["loss"] for l in model.losses_], dtype=np.float64)
-        out[f"c{i}_proba"] = model.predict_proba(X).reshape(-1)
+        out[f"c{i}_w0"] = first_captured["w0"]
+        out[f"c{i}_coeff"] = first.get_coeff()
+        out[f"c{i}_coeff_seeds"] = np.stack(coeffs)
+        out[f"c{i}_traj_w"], out[f"c{i}_traj_loss"], out[f"c{i}_traj_grad"] = tw, tl, tg
+        out[f"c{i}_losses"] = np.array([l["loss"] for l in first.losses_], dtype=np.float64)
+        out[f"c{i}_proba"] = first.predict_proba(X).reshape(-1)
         i += 1
     out["n_cases"] = np.asarray(i)
+    out["fit_seeds"] = np.asarray(FIT_SEEDS)
     save("logreg", **out)
 
 
 def gen_multireg():
-    """(iv-b) RegModule.fit -> get_coeff for the three label losses (loops/multi_reg.py:24-200)."""
+    """(iv-b) RegModule.fit -> get_coeff for the three label losses (loops/multi_reg.py:24-200); torch is
+    seeded immediately before every fit (the DataLoader shuffle is the only random draw), the closure
+    trajectory of the first seed and the coefficients of all FIT_SEEDS are kept."""
     import pandas as pd
     import torch
     mr = R.ref("seesaw.loops.multi_reg")
@@ -339,30 +401,45 @@ def gen_multireg():
     xlx = torch.from_numpy(g["xlx"]).float()
     out = {"xlx": g["xlx"].astype(np.float32)}
     i = 0
-    for loss_type in ["ce_loss", "pairwise_rank_loss", "pairwise_logistic_loss"]:
-        for (n, n_pos, data_lam, query_lam) in [(60, 8, 0.0, 0.0), (150, 20, 1000.0, 10.0)]:
-            X, y, q = _labelled_set(700 + i, n, n_pos)
+    configs = [(lt, n, n_pos, dl, ql, 0.8) for lt in ["ce_loss", "pairwise_rank_loss", "pairwise_logistic_loss"]
+               for (n, n_pos, dl, ql) in [(60, 8, 0.0, 0.0), (150, 20, 1000.0, 10.0)]]
+    # a poor text query (mostly noise): inversions exist at w0, so the pairwise losses have work to do
+    configs += [(lt, 100, 12, 0.0, 1.0, 3.0) for lt in ["pairwise_rank_loss", "pairwise_logistic_loss", "ce_loss"]]
+    for (loss_type, n, n_pos, data_lam, query_lam, q_noise) in configs:
+        if True:
+            X, y, q = _labelled_set(700 + i, n, n_pos, q_noise=q_noise)
             # tiles grouped into images of 1..5 vectors
             rng = np.random.default_rng(i)
             img = np.sort(rng.integers(0, max(2, n // 3), n))
             matchdf = pd.DataFrame({"dbidx": img, "ys": y, "max_iou": y * 0.5})
-            model = mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(),
-                                 label_loss_type=loss_type, rank_loss_margin=0.2,
-                                 reg_data_lambda=data_lam, reg_norm_lambda=100.0, use_qvec_norm=None,
-                                 reg_query_lambda=query_lam, verbose=False, max_iter=200,
-                                 pos_weight="balanced", lr=1.0)
-            losses = model.fit(X, y, matchdf)
+
+            def make():
+                return mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(),
+                                    label_loss_type=loss_type, rank_loss_margin=0.2,
+                                    reg_data_lambda=data_lam, reg_norm_lambda=100.0, use_qvec_norm=None,
+                                    reg_query_lambda=query_lam, verbose=False, max_iter=200,
+                                    pos_weight="balanced", lr=1.0)
+
+            coeffs = []
+            for seed in FIT_SEEDS:
+                model = make()
+                traj = _Trajectory(model, model.weight)
+                torch.manual_seed(seed)
+                losses = model.fit(X, y, matchdf)
+                coeffs.append(model.get_coeff().copy())
+                if seed == FIT_SEEDS[0]:
+                    first, first_traj, first_losses = model, traj, losses
+            tw, tl, tg = first_traj.arrays()
             out[f"c{i}_X"], out[f"c{i}_y"], out[f"c{i}_q"], out[f"c{i}_img"] = X, y, q, img
             out[f"c{i}_loss_type"] = np.asarray(loss_type)
             out[f"c{i}_data_lam"], out[f"c{i}_query_lam"] = np.asarray(data_lam), np.asarray(query_lam)
-            out[f"c{i}_coeff"] = model.get_coeff()
-            out[f"c{i}_raw_weight"] = model.weight.detach().numpy()
-            out[f"c{i}_losses"] = np.array([l["loss"] for l in losses], dtype=np.float64)
-            # one loss/gradient evaluation at w0 = normalised q (pins the fused loss kernel)
-            m0 = mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(),
-                              label_loss_type=loss_type, rank_loss_margin=0.2, reg_data_lambda=data_lam,
-                              reg_norm_lambda=100.0, use_qvec_norm=None, reg_query_lambda=query_lam,
-                              verbose=False, max_iter=200, pos_weight="balanced", lr=1.0)
+            out[f"c{i}_coeff"] = first.get_coeff()
+            out[f"c{i}_coeff_seeds"] = np.stack(coeffs)
+            out[f"c{i}_raw_weight"] = first.weight.detach().numpy()
+            out[f"c{i}_traj_w"], out[f"c{i}_traj_loss"], out[f"c{i}_traj_grad"] = tw, tl, tg
+            out[f"c{i}_losses"] = np.array([l["loss"] for l in first_losses], dtype=np.float64)
+            # one loss/gradient evaluation at w0 = normalised q with the rows in storage order
+            m0 = make()
             vw = 1.0 / pd.Series(img).map(pd.Series(img).value_counts()).values
             Xc = X - X.mean(axis=0).reshape(1, -1)
             ret = m0._step((torch.from_numpy(Xc), torch.from_numpy(y), torch.from_numpy(vw)))
@@ -372,18 +449,40 @@ def gen_multireg():
             out[f"c{i}_parts0"] = np.array([ret[k].item() for k in ["loss_norm", "loss_datareg", "loss_queryreg", "loss_labels"]])
             i += 1
     out["n_cases"] = np.asarray(i)
+    out["fit_seeds"] = np.asarray(FIT_SEEDS)
     save("multireg", **out)
+
+
+BENCH_LOOP_DATASETS = {
+    # A: weak signal, mediocre text query -- hits and misses alternate, the point-based updates matter
+    "A": dict(make=dict(n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=21, signal=0.17),
+              noise=1.0),
+    # B: the positives of a category form a tight cluster in the k-NN graph (cosine ~0.6 between them) but the
+    # text query is nearly orthogonal to it: propagating the first labels over the graph is what finds the rest
+    "B": dict(make=dict(n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=22, signal=0.55),
+              noise=6.0),
+    # C: one vector per image behind the reference's CoarseIndex -- the only index its LogReg2 loop supports
+    # (loops/log_reg.py:21 unpacks CoarseQuery.getXy's pair)
+    "C": dict(make=dict(n_images=3000, tiles_per_image=1, n_categories=3, positive_frac=0.02, seed=23, signal=0.2),
+              noise=3.5),
+}
+BENCH_LOOP_KNN_POOL = 11  # neighbours in the stored graph; the loops keep dst_rank < knn_k = 10 of them
 
 
 def gen_bench_loop():
     """(vii) the reference's own Session + benchmark_loop (seesaw_session.py, seesaw_bench.py:278-355)
-    over its own MultiscaleIndex and loops, on the synthetic LVIS-shape dataset of
-    seesaw_amd.synthetic (data only: vectors, tile boxes, ground truth).  Captured: the dbidx
-    returned in every round, nfound / nseen.  Ray-backed caches are bypassed by handing the
-    loops the weight matrices directly (they are built by the reference's get_weight_matrix)."""
-    import pandas as pd
+    over its own MultiscaleIndex and loops, on synthetic LVIS-shape datasets (seesaw_amd.synthetic supplies
+    data only: vectors, tile boxes, ground truth).  The k-NN graph is the reference's compute_exact_knn
+    (knn_graph.py:170-191) and the weight matrices its get_weight_matrix; Ray-backed caches are bypassed by
+    handing the loops the matrices directly.  Captured: the dbidx returned in every round, nfound / nseen.
+    Runs on the CPU only."""
+    import contextlib
+    import io
+    import json
+    import torch
     from seesaw_amd.synthetic import make_dataset
     msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    coarse = R.ref("seesaw.indices.coarse.coarse_index")
     sess = R.ref("seesaw.seesaw_session")
     bench = R.ref("seesaw.seesaw_bench")
     bt = R.ref("seesaw.basic_types")
@@ -391,21 +490,6 @@ def gen_bench_loop():
     mreg = R.ref("seesaw.loops.multi_reg")
     gb = R.ref("seesaw.loops.graph_based")
     pr = sys.modules["pyroaring"]
-
-    ds = make_dataset("lvis", n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=21, knn_k=10,
-                      signal=0.17)
-    ds.embedding.noise = 1.0  # a mediocre text query: hits and misses alternate, feedback matters
-    knn_df = ds.knn_graph().restrict_k(k=10).knn_df
-    W = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
-    L = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True,
-                             laplacian=True)
-    xlx = np.asarray(ds.vectors.T @ ((L / L.diagonal().sum()) @ ds.vectors))
-
-    def fake_wm(idx, options, xlx_matrix=False):
-        return xlx if xlx_matrix else W
-
-    mreg.get_weight_matrix_from_index = fake_wm
-    gb.get_weight_matrix_from_index = fake_wm
 
     class FakeDataset:
         def __init__(self, d):
@@ -420,34 +504,72 @@ def gen_bench_loop():
             return self.d.get_urls(idxbatch)
 
     matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    lp_opts = dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                   calib_b=-0.4, prior_weight=1.0)
+    logreg_opts = dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1, fit_intercept=False)
+    # name -> (dataset, interactive, options)
     variants = {
-        "plain": None,
-        "rocchio_update": dict(rocchio_alpha=1.0, rocchio_beta=0.5, rocchio_gamma=0.25, verbose=False),
-        "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
-                          reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200,
-                          pos_weight="balanced", lr=1.0, matrix_options=matrix),
-        "multi_reg_data": dict(label_loss_type="pairwise_rank_loss", rank_loss_margin=0.2, use_qvec_norm=None,
-                               reg_data_lambda=1000.0, reg_norm_lambda=100.0, reg_query_lambda=10.0, verbose=False,
-                               max_iter=100, pos_weight="balanced", lr=1.0, matrix_options=matrix),
-        "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
-                          calib_b=-0.4, prior_weight=1.0),
+        "plain": ("A", "plain", None),
+        "rocchio_update": ("A", "rocchio_update", dict(rocchio_alpha=1.0, rocchio_beta=0.5, rocchio_gamma=0.25, verbose=False)),
+        "multi_reg": ("A", "multi_reg", dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None,
+                                             reg_data_lambda=0.0, reg_norm_lambda=100.0, reg_query_lambda=0.0,
+                                             verbose=False, max_iter=200, pos_weight="balanced", lr=1.0,
+                                             matrix_options=matrix)),
+        "multi_reg_data": ("A", "multi_reg", dict(label_loss_type="pairwise_rank_loss", rank_loss_margin=0.2,
+                                                  use_qvec_norm=None, reg_data_lambda=1000.0, reg_norm_lambda=100.0,
+                                                  reg_query_lambda=10.0, verbose=False, max_iter=100,
+                                                  pos_weight="balanced", lr=1.0, matrix_options=matrix)),
+        "plain_c": ("C", "plain", None),
+        "log_reg2_c": ("C", "log_reg2", logreg_opts),
+        "knn_prop2": ("A", "knn_prop2", lp_opts),
+        "plain_b": ("B", "plain", None),
+        "knn_prop2_b": ("B", "knn_prop2", lp_opts),
+        "pseudo_lr_b": ("B", "pseudo_lr", dict(switch_over=True, real_sample_weight=1.0, sample_size=2000,
+                                               log_reg_params=logreg_opts, label_prop_params=lp_opts)),
     }
-    boxes, _ = ds.load_ground_truth()
-    out = {"names": np.array(list(variants))}
-    import contextlib
-    import io
-    for name, opts in variants.items():
-        interactive = "multi_reg" if name.startswith("multi_reg") else name
-        index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
-        p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="multiscale", c_name=None),
+    out = {"names": np.array(list(variants)), "datasets": np.asarray(json.dumps(BENCH_LOOP_DATASETS)),
+           "knn_pool": np.asarray(BENCH_LOOP_KNN_POOL),
+           "variant_dataset": np.array([v[0] for v in variants.values()]),
+           "variant_interactive": np.array([v[1] for v in variants.values()])}
+    built = {}
+    for key, spec in BENCH_LOOP_DATASETS.items():
+        ds = make_dataset("lvis", knn_k=0, **spec["make"])
+        ds.embedding.noise = spec["noise"]
+        if spec["make"]["tiles_per_image"] == 1:  # coarse: no graph-based loop runs on it
+            built[key] = (ds, None, None)
+            continue
+        knn_df = kg.KNNGraph(kg.compute_exact_knn(ds.vectors, n_neighbors=BENCH_LOOP_KNN_POOL)).restrict_k(k=10).knn_df
+        W = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
+        L = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True,
+                                 laplacian=True)
+        xlx = np.asarray(ds.vectors.T @ ((L / L.diagonal().sum()) @ ds.vectors))
+        built[key] = (ds, W, xlx)
+        out[f"ds{key}_knn_rows"] = np.asarray(knn_df.shape[0])
+
+    current = {}
+
+    def fake_wm(idx, options, xlx_matrix=False):
+        return current["xlx"] if xlx_matrix else current["W"]
+
+    mreg.get_weight_matrix_from_index = fake_wm
+    gb.get_weight_matrix_from_index = fake_wm
+    for name, (key, interactive, opts) in variants.items():
+        ds, current["W"], current["xlx"] = built[key]
+        boxes, _ = ds.load_ground_truth()
+        is_coarse = current["W"] is None
+        if is_coarse:
+            index = coarse.CoarseIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta)
+        else:
+            index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+        p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="coarse" if is_coarse else "multiscale", c_name=None),
                              interactive=interactive, interactive_options=opts, batch_size=1, shortlist_size=50,
                              agg_method="plain_score", aug_larger="greater",
-                             # the reference's KnnProp2 never sets curr_qvec, so it only runs from_start
-                             start_policy="from_start" if name == "knn_prop2" else "after_first_batch",
+                             # the reference's KnnProp2 never sets curr_qvec, and its start-policy check reads
+                             # the multiscale form of getXy (loop_base.py:82-83): both only run from_start
+                             start_policy="from_start" if (interactive == "knn_prop2" or is_coarse) else "after_first_batch",
                              index_options={"use_vec_index": False})
         b = bt.BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
         np.random.seed(0)
-        import torch
         torch.manual_seed(0)
         with contextlib.redirect_stdout(io.StringIO()):
             session = sess.Session(None, FakeDataset(ds), index, p)
@@ -457,15 +579,40 @@ def gen_bench_loop():
         out[f"{name}_shown"] = shown
         out[f"{name}_nfound"] = np.asarray(res["nfound"])
         out[f"{name}_nseen"] = np.asarray(res["nseen"])
-        print(name, res["nfound"], res["nseen"], shown[:12])
+        print(name, res["nfound"], res["nseen"], shown[:14])
+    assert not np.array_equal(out["knn_prop2_b_shown"], out["plain_b_shown"]), "label propagation left no trace"
     save("bench_loop", **out)
 
 
 FAMILIES = {"scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
             "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop}
 
+def main(argv):
+    """python oracle/gen_golden.py [--check] [family ...]
+    --check: regenerate into a scratch directory and fail on any byte of any array that differs from the
+    committed tests/golden/*.npz (run by tests/test_golden_regen_cpu.py where /root/reference exists)."""
+    global OUT_DIR
+    check = "--check" in argv
+    names = [a for a in argv if not a.startswith("--")] or list(FAMILIES)
+    if not check:
+        for nm in names:
+            print(f"== {nm}")
+            FAMILIES[nm]()
+        return 0
+    import tempfile
+    bad = 0
+    with tempfile.TemporaryDirectory(prefix="ssw_golden_") as tmp:
+        OUT_DIR = tmp
+        for nm in names:
+            print(f"== {nm}")
+            FAMILIES[nm]()
+            diffs = compare_npz(os.path.join(GOLDEN, nm + ".npz"), os.path.join(tmp, nm + ".npz"))
+            for d in diffs:
+                print(f"   DIFF {nm}: {d}")
+            print(f"   {nm}: {'reproduced byte for byte' if not diffs else f'{len(diffs)} arrays differ'}")
+            bad += bool(diffs)
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(FAMILIES)
-    for nm in names:
-        print(f"== {nm}")
-        FAMILIES[nm]()
+    sys.exit(main(sys.argv[1:]))

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_scores": (c_i32, [c_void_p, c_void_p, c_i32, c_void_p]),
     "ssw_fb_fit": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_i32_p, c_i32_p, c_void_p]),
+    "ssw_rank_pairwise": (c_i32, [c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_void_p, c_void_p]),
     "ssw_clip_create": (c_i32, [c_i32, c_void_p, ctypes.c_size_t, c_void_pp]),
     "ssw_clip_destroy": (c_i32, [c_void_p]),
     "ssw_clip_embed_image": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p]),

@@ -366,16 +366,28 @@ __global__ void f32_to_bf16(const float *__restrict__ in, bf16 *__restrict__ out
         out[i] = to_bf16(in[i]);
 }
 
-// first position of the EOS token in every sequence -> row index into [B*L]
+// pooled position of every sequence -> row index into [B*L].  transformers' CLIPTextTransformer.forward:
+// a config with the legacy eos_token_id == 2 (what the published openai/clip-vit-* checkpoints carry) pools at
+// argmax(ids) -- the end-of-text token has the highest id --, any other value at the first id equal to it.
+// (the host entry point has already checked that such a position exists)
 __global__ void eos_rows(const int *__restrict__ ids, int B, int L, int eos, int *__restrict__ rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int pos = 0;
-    for (int j = 0; j < L; ++j)
-        if (ids[b * L + j] == eos) {
-            pos = j;
-            break;
-        }
+    if (eos == 2) {
+        int best = ids[b * L];
+        for (int j = 1; j < L; ++j)
+            if (ids[b * L + j] > best) {
+                best = ids[b * L + j];
+                pos = j;
+            }
+    } else {
+        for (int j = 0; j < L; ++j)
+            if (ids[b * L + j] == eos) {
+                pos = j;
+                break;
+            }
+    }
     rows[b] = b * L + pos;
 }
 
@@ -771,6 +783,12 @@ ssw_status ssw_clip_embed_text(ssw_clip *c, const int32_t *ids_host, int32_t b, 
     SSW_REQUIRE(seq_len >= 1 && seq_len <= h.t_maxpos, "clip: sequence length %d outside [1, %d]", seq_len, h.t_maxpos);
     for (int64_t i = 0; i < (int64_t)b * seq_len; ++i)
         SSW_REQUIRE(ids_host[i] >= 0 && ids_host[i] < h.vocab, "clip: token id %d outside the vocabulary", ids_host[i]);
+    if (h.eos != 2)  // legacy configs pool at argmax(ids), which always exists
+        for (int r = 0; r < b; ++r) {
+            bool found = false;
+            for (int j = 0; j < seq_len && !found; ++j) found = ids_host[(int64_t)r * seq_len + j] == h.eos;
+            SSW_REQUIRE(found, "clip: sequence %d holds no end-of-text token (id %d): nothing to pool", r, h.eos);
+        }
     DeviceGuard guard(c->device);
     const int chunk = 256;
     SSW_TRY(reserve(c, std::min<int64_t>(b, chunk)));

@@ -1029,4 +1029,50 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
     return SSW_OK;
 }
 
+// The pairwise losses evaluated directly on given scores: the kernel the fit uses (k_fb_pairwise), without a
+// data matrix in front of it.  The reference's functions normalise nothing (rank_loss.py:34-95); RegModule
+// divides column j by max_inversions_j and multiplies by sample_weight_j (multi_reg.py:106-121):
+// coef_j is that per-item factor times max_inversions_j, i.e. coef = max_inversions reproduces the raw column
+// sums / gradient of rank_loss.py and coef = sample_weight what RegModule optimises.
+ssw_status ssw_rank_pairwise(int32_t device, int32_t logistic, const float *target_host, const float *scores_host,
+                             const float *coef_host_or_null, int32_t n, float margin, double *out_item_loss,
+                             float *out_grad) {
+    SSW_REQUIRE(n >= 0 && n <= FB_MAX_PAIRWISE, "rank_pairwise: n = %d outside [0, %d]", n, FB_MAX_PAIRWISE);
+    if (n == 0) return SSW_OK;
+    SSW_REQUIRE(target_host && scores_host && out_item_loss && out_grad, "NULL argument");
+    DeviceGuard guard(device);
+    float *buf = nullptr;  // z | y | coef | r   then f64 item losses
+    double *item = nullptr;
+    SSW_HIP_TRY(hipMalloc((void **)&buf, (size_t)4 * n * sizeof(float)));
+    if (hipMalloc((void **)&item, (size_t)n * sizeof(double)) != hipSuccess) {
+        (void)hipFree(buf);
+        set_error("rank_pairwise: out of device memory");
+        return SSW_ERR_HIP;
+    }
+    std::vector<float> ones;
+    if (!coef_host_or_null) ones.assign((size_t)n, 1.f);
+    ssw_status st = SSW_OK;
+    auto run = [&]() -> ssw_status {
+        SSW_HIP_TRY(hipMemcpy(buf, scores_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        SSW_HIP_TRY(hipMemcpy(buf + n, target_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        SSW_HIP_TRY(hipMemcpy(buf + 2 * n, coef_host_or_null ? coef_host_or_null : ones.data(), (size_t)n * sizeof(float),
+                              hipMemcpyHostToDevice));
+        const size_t lds = (size_t)3 * n * sizeof(float);
+        if (logistic)
+            hipLaunchKernelGGL(k_fb_pairwise<1>, dim3(1), dim3(1024), lds, 0, buf, buf + n, buf + 2 * n, margin, n, item,
+                               buf + 3 * n);
+        else
+            hipLaunchKernelGGL(k_fb_pairwise<0>, dim3(1), dim3(1024), lds, 0, buf, buf + n, buf + 2 * n, margin, n, item,
+                               buf + 3 * n);
+        SSW_HIP_TRY(hipGetLastError());
+        SSW_HIP_TRY(hipMemcpy(out_grad, buf + 3 * n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        SSW_HIP_TRY(hipMemcpy(out_item_loss, item, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        return SSW_OK;
+    };
+    st = run();
+    (void)hipFree(buf);
+    (void)hipFree(item);
+    return st;
+}
+
 }  // extern "C"

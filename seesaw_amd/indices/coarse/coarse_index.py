@@ -102,6 +102,9 @@ class CoarseQuery(InteractiveQuery):
     def getXy(self, get_positions=False):
         seen = np.asarray(self.label_db.get_seen(), dtype=np.int64)
         positions = _positions_of(self.index._dbidx, seen)
+        # the reference takes all_indices.rank(idx) - 1 for every seen id (coarse_index.py:116-118), which for
+        # an id outside the index silently lands on its predecessor's vector; labels and vectors must pair up
+        assert positions.shape[0] == seen.shape[0], "labels recorded for images that are not in this index"
         yt = np.array([len(self.label_db.get(int(d), format="box")) > 0 for d in seen], dtype=bool)
         if get_positions:
             return positions[yt], positions[~yt]

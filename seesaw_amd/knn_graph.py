@@ -140,12 +140,13 @@ def compute_knn_from_nndescent(vectors, *, n_neighbors, n_jobs=-1, low_memory=Fa
                                **kwargs):
     """The reference builds its production graphs with the approximate pynndescent
     (knn_graph.py:194-215, "nndescent60": 60 neighbours, later restricted to knn_k = 10 by
-    KNNGraph.restrict_k).  Here the same DataFrame comes from the exact GPU builder; graphs are built
-    with the k that will be used (<= 31) instead of a 60-neighbour pool.  n_jobs / low_memory are accepted
-    for signature compatibility."""
+    KNNGraph.restrict_k).  Here the same DataFrame comes from the exact GPU builder, with pools of up to 31
+    neighbours: build with at least knn_k + 1 so that restrict_k(k=knn_k) keeps `dst_rank < knn_k` as it does
+    on the reference's pools (an exact graph needs no larger pool: the first knn_k - 1 neighbours do not
+    depend on it).  n_jobs / low_memory are accepted for signature compatibility."""
     if n_neighbors > MAX_EXACT_K:
         raise NotImplementedError(f"exact graphs are built with n_neighbors <= {MAX_EXACT_K} (asked for "
-                                  f"{n_neighbors}): build with the knn_k the loops use instead of a larger pool")
+                                  f"{n_neighbors}): a pool of knn_k + 1 gives the loops the same restricted graph")
     return compute_exact_knn(np.asarray(vectors), n_neighbors, device_index=device_index, device=device)
 
 

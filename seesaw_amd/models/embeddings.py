@@ -73,27 +73,51 @@ class ImageEmbedding:
         return self.model.embed_image(x, normalize=True)
 
 
+SYNTHETIC_PREFIX = "synthetic:"  # explicit opt-in: "synthetic:random-init" or "synthetic:random-init:<seed>"
+
+
+def _synthetic_seed(path):
+    """seed when `path` is the explicit synthetic opt-in, else None"""
+    if isinstance(path, str) and path.startswith(SYNTHETIC_PREFIX):
+        parts = path.split(":")
+        return int(parts[2]) if len(parts) > 2 else 1234
+    return None
+
+
 def _load_tokenizer(path, model: ClipModel):
-    if path and os.path.exists(os.path.join(str(path), "vocab.json")):
-        import transformers
-        tok = transformers.CLIPTokenizer.from_pretrained(path)
-        return lambda s: np.asarray(tok(s, return_tensors="np")["input_ids"], dtype=np.int32)
-    return HashTokenizer(model.vocab_size, eos=model.eos_token_id, max_len=model.max_positions)
+    """CLIPTokenizer of the model directory (embeddings.py:433-434 loads both from one path).  The hash
+    stand-in is used only with the explicit synthetic opt-in (or no path at all, bench / tests): a real
+    model directory without its vocabulary raises, as from_pretrained does in the reference."""
+    if path is None or _synthetic_seed(path) is not None:
+        return HashTokenizer(model.vocab_size, eos=model.eos_token_id if model.eos_token_id != 2 else model.vocab_size - 1,
+                             max_len=model.max_positions)
+    if not os.path.exists(os.path.join(str(path), "vocab.json")):
+        raise FileNotFoundError(f"no CLIP tokenizer files (vocab.json) under {path!r}")
+    import transformers
+    tok = transformers.CLIPTokenizer.from_pretrained(path)
+    return lambda s: np.asarray(tok(s, return_tensors="np")["input_ids"], dtype=np.int32)
 
 
 _CLIP_CACHE = {}
 
 
 def load_clip(path=None, device: int = 0) -> ClipModel:
-    """HF CLIP directory (config + weights) -> ClipModel; None / missing -> seeded random init."""
+    """HF CLIP directory (config + weights) -> ClipModel.  Seeded random-init weights (BASELINE.json's
+    synthetic configuration) only on request: path None or "synthetic:random-init[:seed]".  Anything else
+    that cannot be loaded raises FileNotFoundError -- an index whose info.json names a missing model must
+    not serve meaningless text vectors."""
     key = (path, device)
     if key not in _CLIP_CACHE:
-        if path and os.path.isdir(str(path)) and os.path.exists(os.path.join(str(path), "config.json")):
+        seed = 1234 if path is None else _synthetic_seed(path)
+        if seed is not None:
+            _CLIP_CACHE[key] = ClipModel.random_init(seed=seed, device=device)
+        elif os.path.isdir(str(path)) and os.path.exists(os.path.join(str(path), "config.json")):
             import transformers
             hf = transformers.CLIPModel.from_pretrained(path).eval()
             _CLIP_CACHE[key] = ClipModel.from_hf(hf, device=device)
         else:
-            _CLIP_CACHE[key] = ClipModel.random_init(device=device)
+            raise FileNotFoundError(f"CLIP model directory {path!r} not found (expected config.json + weights); "
+                                    f"pass '{SYNTHETIC_PREFIX}random-init' for seeded random weights")
     return _CLIP_CACHE[key]
 
 

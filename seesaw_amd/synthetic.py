@@ -21,7 +21,7 @@ import zlib
 import numpy as np
 import pandas as pd
 
-from .knn_graph import KNNGraph, compute_exact_knn
+from .knn_graph import MAX_EXACT_K, KNNGraph, compute_exact_knn
 
 
 def _unit(x):
@@ -97,7 +97,11 @@ class SyntheticDataset:
         if self._knng is None:
             assert self.knn_k > 0, "dataset built without a k-NN graph"
             dev = getattr(self._index, "_dev", None) if self._index is not None else None  # matrix already resident
-            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=self.knn_k, device_index=dev,
+            # stored like the reference's graphs: a pool larger than the k the loops keep, so that
+            # KNNGraph.restrict_k(k=knn_k) applies `dst_rank < knn_k` (self + knn_k - 1 neighbours) exactly as
+            # it does to the reference's 60-neighbour pools (knn_graph.py:264-266)
+            pool = min(MAX_EXACT_K, self.knn_k + 1)
+            self._knng = KNNGraph(compute_exact_knn(self.vectors, n_neighbors=pool, device_index=dev,
                                                     device=getattr(self, "device", 0) or 0))
         return self._knng
 

@@ -122,24 +122,53 @@ def test_feedback_beats_plain(lvis):
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name", ["plain", "rocchio_update", "multi_reg", "multi_reg_data", "knn_prop2"])
-def test_benchmark_loop_sequence_matches_reference(name):
+SEQUENCE_VARIANTS = ["plain", "rocchio_update", "multi_reg", "multi_reg_data", "knn_prop2", "plain_c", "log_reg2_c",
+                     "plain_b", "knn_prop2_b", "pseudo_lr_b"]
+
+
+@pytest.fixture(scope="module")
+def sequence_datasets():
+    """the synthetic datasets of tests/golden/bench_loop.npz, rebuilt from the parameters stored in it"""
+    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
+    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
+    specs = json.loads(str(g["datasets"]))
+    assert int(g["knn_pool"]) == 11  # synthetic.knn_graph stores knn_k + 1 neighbours, as the generator did
+    out = {}
+    for key, spec in specs.items():
+        coarse = spec["make"]["tiles_per_image"] == 1
+        ds = make_dataset("lvis", knn_k=0 if coarse else 10, **spec["make"])
+        ds.embedding.noise = spec["noise"]
+        out[key] = (GlobalDataManager().add(ds), ds, coarse)
+    return g, out
+
+
+@pytest.mark.parametrize("name", SEQUENCE_VARIANTS)
+def test_benchmark_loop_sequence_matches_reference(sequence_datasets, name):
     """The dbidx returned in every round, nfound and nseen equal what the REFERENCE's own
-    Session + benchmark_loop + MultiscaleIndex + loops produced on the same synthetic dataset
-    (tests/golden/bench_loop.npz, captured by oracle/gen_golden.py::gen_bench_loop)."""
-    from seesaw_amd.basic_types import BenchParams
+    Session + benchmark_loop + MultiscaleIndex / CoarseIndex + loops produced on the same synthetic
+    datasets (tests/golden/bench_loop.npz, captured by oracle/gen_golden.py::gen_bench_loop with the
+    reference's own compute_exact_knn graph).  Dataset B is the one where label propagation matters:
+    knn_prop2_b and pseudo_lr_b differ from plain_b."""
+    import torch
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
     from seesaw_amd.bitmap import BitMap
     from seesaw_amd.seesaw_bench import benchmark_loop
     from seesaw_amd.seesaw_session import make_session
-    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
-    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
-    ds = make_dataset("lvis", n_images=400, tiles_per_image=13, n_categories=3, positive_frac=0.04, seed=21, knn_k=10,
-                      signal=0.17)
-    ds.embedding.noise = 1.0
-    gdm = GlobalDataManager().add(ds)
-    interactive = "multi_reg" if name.startswith("multi_reg") else name
-    p = _params(interactive, LOOPS[name], start_policy="from_start" if name == "knn_prop2" else "after_first_batch")
+    g, datasets = sequence_datasets
+    names = [str(x) for x in g["names"]]
+    assert sorted(names) == sorted(SEQUENCE_VARIANTS)
+    i = names.index(name)
+    key, interactive = str(g["variant_dataset"][i]), str(g["variant_interactive"][i])
+    gdm, ds, coarse = datasets[key]
+    opts_name = {"multi_reg_data": "multi_reg_data"}.get(name, interactive)
+    p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="coarse" if coarse else "multiscale", c_name=None),
+                      interactive=interactive, interactive_options=LOOPS[opts_name], batch_size=1, shortlist_size=50,
+                      agg_method="plain_score", aug_larger="greater",
+                      start_policy="from_start" if (interactive == "knn_prop2" or coarse) else "after_first_batch",
+                      index_options={"use_vec_index": False})
     b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
+    np.random.seed(0)
+    torch.manual_seed(0)
     ret = make_session(gdm, p, b=b)
     boxes, _ = ds.load_ground_truth()
     out = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
@@ -147,6 +176,13 @@ def test_benchmark_loop_sequence_matches_reference(name):
     ref = g[f"{name}_shown"]
     assert np.array_equal(shown, ref), (shown.tolist(), ref.tolist())
     assert out["nfound"] == int(g[f"{name}_nfound"]) and out["nseen"] == int(g[f"{name}_nseen"])
+
+
+def test_sequence_fixture_discriminates_label_propagation():
+    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
+    assert not np.array_equal(g["knn_prop2_b_shown"], g["plain_b_shown"])
+    assert not np.array_equal(g["pseudo_lr_b_shown"], g["plain_b_shown"])
+    assert not np.array_equal(g["log_reg2_c_shown"], g["plain_c_shown"])
 
 
 def test_readme_session_snippet():

@@ -69,6 +69,49 @@ def test_text_tower_vs_hf(models, L):
     assert np.abs(np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1) - 1).max() < 2e-2
 
 
+def test_text_pooling_legacy_eos_token_id_2():
+    """The published openai/clip-vit-* configs still say text_config.eos_token_id = 2; transformers then pools
+    at argmax(input_ids) (modeling_clip.py, CLIPTextTransformer.forward).  A tokenised string never contains
+    id 2, so pooling at 'the first 2' would read the BOS row for every query."""
+    import torch
+    import transformers
+    from seesaw_amd.models.clip import ClipModel
+    cfg = transformers.CLIPConfig()
+    cfg.text_config.eos_token_id = 2
+    torch.manual_seed(77)
+    hf = transformers.CLIPModel(cfg).eval()
+    assert hf.text_model.eos_token_id == 2
+    ours = ClipModel.from_hf(hf)
+    assert ours.eos_token_id == 2
+    rng = np.random.default_rng(5)
+    B, L = 6, 20
+    ids = rng.integers(3, 49405, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 49406
+    eot_at = rng.integers(2, L, size=B)
+    for b in range(B):
+        ids[b, eot_at[b]] = 49407
+        ids[b, eot_at[b] + 1:] = 0  # padding after the end-of-text token
+    with torch.inference_mode():
+        ref = hf.get_text_features(input_ids=torch.from_numpy(ids))
+        ref = (ref.pooler_output if hasattr(ref, "pooler_output") else ref).numpy()
+    got = ours.embed_text(ids.astype(np.int32), normalize=False)
+    cos = (_unit(got) * _unit(ref)).sum(1)
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(_unit(got) - _unit(ref)).max() <= ABS_MAX
+    # different strings -> different vectors (the BOS row would give identical ones)
+    assert np.abs(_unit(got)[0] - _unit(got)[1]).max() > 1e-3
+    ours.close()
+
+
+def test_text_without_eos_is_an_error(models):
+    from seesaw_amd import _lib
+    _, ours = models
+    ids = np.full((2, 8), 11, dtype=np.int32)
+    ids[0, 5] = 49407
+    with pytest.raises(_lib.SeesawHipError, match="end-of-text"):
+        ours.embed_text(ids)
+
+
 def test_embedding_wrappers_and_batch_chunking(models):
     from seesaw_amd.models.embeddings import HGWrapper, ImageEmbedding
     hf, ours = models
@@ -115,9 +158,9 @@ def test_create_multiscale_index_round_trip(models, tmp_path):
         PIL.Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(buf, format="PNG")
         rows.append({"dbidx": dbidx, "file_path": f"img{dbidx}.png", "bytes": buf.getvalue()})
     image_rows = pd.DataFrame(rows)
-    model = load_clip("clip-random-init")  # not a directory -> seeded random init; from_path reloads the same
+    model = load_clip("synthetic:random-init")  # explicit opt-in; from_path reloads the same
     path = create_multiscale_index(image_rows=image_rows, dataset_path=str(tmp_path), index_name="multiscale",
-                                   model=model, model_path="clip-random-init")
+                                   model=model, model_path="synthetic:random-init")
     info = json.load(open(f"{path}/info.json"))
     assert info["constructor"] == "seesaw.indices.multiscale.multiscale_index.MultiscaleIndex"
     meta, vecs = read_vector_parquet(f"{path}/vectors.sorted.cached")

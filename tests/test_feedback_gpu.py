@@ -10,10 +10,6 @@ import pytest
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 TOL = 1e-4
-# fitted coefficients: L-BFGS stops on tolerances; the reference's own run-to-run spread (row
-# shuffling in its DataLoader) is 1.56e-4 in rank scores on the flattest golden case, so
-# fits are held to 2.5e-4 while single loss/gradient evaluations are held to 1e-4.
-FIT_TOL = 2.5e-4
 
 
 def _multireg_obj(lt, data_lam, query_lam):
@@ -44,30 +40,111 @@ def test_multireg_lossgrad_vs_reference_golden():
         assert np.allclose(parts, ref_parts, rtol=1e-4, atol=1e-5), (c, parts, ref_parts)
 
 
-def test_multireg_fit_vs_reference_golden():
-    from seesaw_amd.loops.multi_reg import RegModule
+def _rank_scores(Xc, a, b):
+    return float(np.abs(Xc @ (np.asarray(a, np.float64).reshape(-1) - np.asarray(b, np.float64).reshape(-1))).max())
+
+
+def _seed_spread(Xc, coeff_seeds):
+    """how far apart (in rank scores of the labelled rows) the reference's own fits land when only the
+    DataLoader shuffle seed changes (recorded in the fixture for 3 seeds)"""
+    k = coeff_seeds.shape[0]
+    return max(_rank_scores(Xc, coeff_seeds[i], coeff_seeds[j]) for i in range(k) for j in range(k))
+
+
+REPRODUCIBLE = 1e-5  # a reference fit that reproduces itself to this across seeds is held to TOL directly
+
+
+def test_multireg_lossgrad_along_the_reference_trajectory():
+    """every (w, loss, grad) the reference's L-BFGS closure evaluated during its fits
+    (tests/golden/multireg.npz: cN_traj_*) -- the HIP loss/gradient kernels agree within 1e-4 at each
+    of them, not only at w0"""
+    from seesaw_amd.feedback import FeedbackEngine
     g = np.load(os.path.join(GOLDEN, "multireg.npz"))
-    import pandas as pd
+    eng = FeedbackEngine(512)
+    eng.set_xlx(g["xlx"])
+    n_points = 0
     for c in range(int(g["n_cases"])):
         X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
-        mod = RegModule(dim=512, xlx_matrix=g["xlx"], qvec=q, label_loss_type=str(g[f"c{c}_loss_type"]),
+        _, inv, counts = np.unique(img, return_inverse=True, return_counts=True)
+        eng.set_data(X, center=True)
+        eng.set_targets(y, 1.0 / counts[inv])
+        eng.set_query(q)
+        obj = _multireg_obj(str(g[f"c{c}_loss_type"]), float(g[f"c{c}_data_lam"]), float(g[f"c{c}_query_lam"]))
+        W, L, G = g[f"c{c}_traj_w"], g[f"c{c}_traj_loss"], g[f"c{c}_traj_grad"]
+        assert W.shape[0] == L.shape[0] == G.shape[0] >= 1
+        worst_l = worst_g = 0.0
+        for t in range(W.shape[0]):
+            loss, grad, _ = eng.lossgrad(obj, W[t])
+            worst_l = max(worst_l, abs(loss - L[t]) / max(1.0, abs(L[t])))
+            worst_g = max(worst_g, np.abs(grad - G[t]).max() / max(1.0, np.abs(G[t]).max()))
+            n_points += 1
+        print(f"multireg c{c} {str(g[f'c{c}_loss_type'])}: {W.shape[0]} closure evaluations, worst rel loss diff "
+              f"{worst_l:.2e}, worst rel grad diff {worst_g:.2e}")
+        assert worst_l <= TOL, (c, worst_l)
+        assert worst_g <= TOL, (c, worst_g)
+    assert n_points > 200
+
+
+def test_logreg_lossgrad_along_the_reference_trajectory():
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    g = np.load(os.path.join(GOLDEN, "logreg.npz"))
+    eng = FeedbackEngine(512)
+    for c in range(int(g["n_cases"])):
+        X, y, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_q"]
+        cw, sw, n = float(g[f"c{c}_cw"]), g[f"c{c}_sw"], X.shape[0]
+        pw = max(int((y == 0).sum()), 1) / max(int((y == 1).sum()), 1) if cw < 0 else cw
+        eng.set_data(X, center=True)
+        eng.set_targets(y, None if sw.size == 0 else sw)
+        eng.set_query(q)
+        obj = _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=0, reg_kind=_lib.SSW_FB_REG_VECTOR,
+                               pos_weight=pw, reg_weight=float(g[f"c{c}_lam"]) / n, margin=0, reg_norm_lambda=0,
+                               reg_data_lambda=0, reg_query_lambda=0)
+        W, L, G = g[f"c{c}_traj_w"], g[f"c{c}_traj_loss"], g[f"c{c}_traj_grad"]
+        for t in range(W.shape[0]):
+            loss, grad, _ = eng.lossgrad(obj, W[t])
+            assert abs(loss - L[t]) <= TOL * max(1.0, abs(L[t])), (c, t, loss, L[t])
+            assert np.abs(grad - G[t]).max() <= TOL * max(1.0, np.abs(G[t]).max()), (c, t)
+
+
+def test_multireg_fit_vs_reference_golden():
+    """Fitted coefficients against the reference's (seeded) fits, in rank scores of the labelled rows.
+    The fixture holds the reference's result for 3 shuffle seeds: where the reference reproduces itself
+    (spread <= 1e-5) ours is held to 1e-4 of it; where it does not -- its L-BFGS stops on an f32-noisy
+    loss, so the stopping point moves with the summation order -- ours must lie within 1e-4 of the
+    reference's own cloud (distance to the nearest seed <= spread + 1e-4) and of the f64 minimiser."""
+    import pandas as pd
+    from oracle import feedback_oracle as fo
+    from seesaw_amd.loops.multi_reg import RegModule
+    g = np.load(os.path.join(GOLDEN, "multireg.npz"))
+    held_directly = 0
+    for c in range(int(g["n_cases"])):
+        X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
+        lt = str(g[f"c{c}_loss_type"])
+        mod = RegModule(dim=512, xlx_matrix=g["xlx"], qvec=q, label_loss_type=lt,
                         rank_loss_margin=0.2, reg_data_lambda=float(g[f"c{c}_data_lam"]), reg_norm_lambda=100.0,
                         use_qvec_norm=None, reg_query_lambda=float(g[f"c{c}_query_lam"]), verbose=False,
                         max_iter=200, pos_weight="balanced", lr=1.0)
         mod.fit(X, y, pd.DataFrame({"dbidx": img, "ys": y}))
         coeff = mod.get_coeff()
-        ref = g[f"c{c}_coeff"]
-        # The reference stops when its f32-noisy loss stops changing and can end short of the
-        # minimiser (6.7e-4 in rank scores on c4); the HIP path evaluates the loss in f64 and
-        # converges.  So: ours is within 1e-4 of the exact minimiser, and no further from the
-        # reference than the reference is from the minimiser (+1e-4).
-        from oracle import feedback_oracle as fo
-        opt = fo.multireg_optimum(X, y, img, q, g["xlx"], loss_type=str(g[f"c{c}_loss_type"]),
-                                  l_data=float(g[f"c{c}_data_lam"]), l_query=float(g[f"c{c}_query_lam"]))
-        ref_gap = np.abs(X @ (ref - opt)).max()
-        assert np.abs(X @ (coeff - opt)).max() < TOL, (c, np.abs(X @ (coeff - opt)).max())
-        assert np.abs(X @ (coeff - ref)).max() < ref_gap + TOL, (c, np.abs(X @ (coeff - ref)).max(), ref_gap)
         assert abs(np.linalg.norm(coeff) - 1) < 1e-5
+        Xc = X - X.mean(axis=0)
+        seeds = g[f"c{c}_coeff_seeds"]
+        spread = _seed_spread(Xc, seeds)
+        nearest = min(_rank_scores(Xc, coeff, s_) for s_ in seeds)
+        to_ref = _rank_scores(Xc, coeff, g[f"c{c}_coeff"])
+        print(f"multireg c{c} {lt}: |ours - reference| = {to_ref:.2e} (nearest seed {nearest:.2e}), "
+              f"reference's own seed spread {spread:.2e}")
+        if spread <= REPRODUCIBLE:
+            held_directly += 1
+            assert to_ref <= TOL, (c, to_ref)
+        else:
+            assert nearest <= spread + TOL, (c, nearest, spread)
+        if lt != "pairwise_rank_loss":  # smooth objectives: the f64 minimiser is well defined
+            opt = fo.multireg_optimum(X, y, img, q, g["xlx"], loss_type=lt, l_data=float(g[f"c{c}_data_lam"]),
+                                      l_query=float(g[f"c{c}_query_lam"]))
+            assert _rank_scores(Xc, coeff, opt) < TOL, (c, _rank_scores(Xc, coeff, opt))
+    assert held_directly >= 3
 
 
 def test_logreg_fit_vs_reference_golden():
@@ -84,9 +161,13 @@ def test_logreg_fit_vs_reference_golden():
         coeff, ref = model.get_coeff(), g[f"c{c}_coeff"]
         assert coeff.shape == (1, 512)
         Xc = X - X.mean(axis=0)
-        assert np.abs(Xc @ (coeff - ref).reshape(-1)).max() < FIT_TOL, (c, np.abs(Xc @ (coeff - ref).reshape(-1)).max())
-        assert np.abs(coeff - ref).max() < 5e-4, c
-        assert np.abs(model.predict_proba(X).reshape(-1) - g[f"c{c}_proba"]).max() < FIT_TOL
+        spread = _seed_spread(Xc, g[f"c{c}_coeff_seeds"])
+        assert spread <= REPRODUCIBLE, (c, spread)  # these fits reproduce across shuffle seeds
+        to_ref = _rank_scores(Xc, coeff, ref)
+        print(f"logreg c{c}: |ours - reference| = {to_ref:.2e} in logits, {np.abs(coeff - ref).max():.2e} in "
+              f"coefficients; reference seed spread {spread:.2e}")
+        assert to_ref <= TOL, (c, to_ref)
+        assert np.abs(model.predict_proba(X).reshape(-1) - g[f"c{c}_proba"]).max() <= TOL
 
 
 def test_logreg_lossgrad_vs_oracle_with_intercept_and_pseudo_labels(oracle):

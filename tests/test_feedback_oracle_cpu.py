@@ -7,7 +7,6 @@ import pytest
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-FIT_TOL = 2.5e-4  # see test_multireg_oracle_vs_reference_golden
 
 
 def test_rank_loss_known_answers_and_reference_outputs():
@@ -59,10 +58,21 @@ def test_multireg_oracle_vs_reference_golden():
         loss.backward()
         assert abs(loss.item() - float(g[f"c{c}_loss0"])) <= 1e-5 * max(1, abs(loss.item()))
         assert np.abs(w.grad.numpy() - g[f"c{c}_grad0"]).max() < 1e-5
+        # the oracle's loss / gradient along the whole trajectory the reference's L-BFGS walked
+        W, L, G = g[f"c{c}_traj_w"], g[f"c{c}_traj_loss"], g[f"c{c}_traj_grad"]
+        for t in range(0, W.shape[0], max(1, W.shape[0] // 12)):
+            wt = torch.from_numpy(W[t]).clone().requires_grad_(True)
+            lo, _ = fo.multireg_loss(wt, Xc, y, vw, qhat, M, **kw)
+            lo.backward()
+            assert abs(lo.item() - L[t]) <= 1e-5 * max(1, abs(L[t])), (c, t)
+            assert np.abs(wt.grad.numpy() - G[t]).max() <= 1e-5 * max(1, np.abs(G[t]).max()), (c, t)
         coeff, raw = fo.multireg_fit(g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"], g["xlx"], **kw)
-        # L-BFGS stops on tolerances, not at the exact optimum.  The reference itself is only
-        # reproducible to 1.6e-4 in rank scores on the flattest case here (c5): its DataLoader
-        # shuffles the rows with torch's global RNG, which changes f32 summation order
-        # (measured: 4 seeds of the reference, coeff spread 1.16e-4, score spread 1.56e-4).
-        assert np.abs(g[f"c{c}_X"] @ (coeff - g[f"c{c}_coeff"])).max() < FIT_TOL, (c, lt)
-        assert np.abs(coeff - g[f"c{c}_coeff"]).max() < 5e-4, (c, lt)
+        # L-BFGS stops on tolerances, not at the exact optimum, and the reference's DataLoader shuffles the
+        # rows (f32 summation order): the fixture records its fits for 3 shuffle seeds.  Where it reproduces
+        # itself the oracle is held to 1e-4 of it, elsewhere to the reference's own spread + 1e-4.
+        Xc_np = g[f"c{c}_X"] - g[f"c{c}_X"].mean(axis=0)
+        seeds = g[f"c{c}_coeff_seeds"]
+        dist = lambda a, b: float(np.abs(Xc_np @ (a.astype(np.float64) - b.astype(np.float64))).max())  # noqa: E731
+        spread = max(dist(a, b) for a in seeds for b in seeds)
+        nearest = min(dist(coeff, s_) for s_ in seeds)
+        assert nearest <= (1e-4 if spread <= 1e-5 else spread + 1e-4), (c, lt, nearest, spread)
