@@ -25,6 +25,7 @@
 // 513-float vectors (pure latency, no bandwidth).  Bound: launch/sync latency, not HBM --
 // nothing here is GEMM-shaped enough for MFMA.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "ssw_common.h"
@@ -95,17 +96,28 @@ __device__ __forceinline__ double softplus_neg(double z) {  // log(1 + exp(-z)),
     return log1p(exp(-fabs(z))) + fmax(-z, 0.0);
 }
 __device__ __forceinline__ double sigmoidd(double z) { return 1.0 / (1.0 + exp(-z)); }
+// One BCE-with-logits item the way torch forms it with f32 logits and f64 targets
+// (binary_cross_entropy_with_logits: log_sigmoid(input) is an f32 tensor, multiplied IN PLACE by the f64
+// log_weight -- so the product is rounded to f32 again -- and only then subtracted from the f64
+// (1 - target) * input).  The values differ from the exact ones by ~1e-8 per item; L-BFGS's last line search
+// and its |loss - prev_loss| < 1e-9 stop sit on exactly that noise, so the rounding is reproduced here.
+__device__ __forceinline__ double bce_item(double z, double y, double lw, bool exact) {
+    if (exact) return (1.0 - y) * z + lw * softplus_neg(z);  // diagnostic mode (SSW_FB_EXACT_LOSS)
+    const float log_sig = (float)(-softplus_neg(z));
+    const float weighted = (float)((double)log_sig * lw);
+    return (1.0 - y) * z - (double)weighted;
+}
 
 // elementwise BCE-with-logits with pos_weight pw and per-item coefficient c_i:
 //   l = c [ (1-y) z + (1 + (pw-1) y) softplus(-z) ],  dl/dz = c [ (1-y) - (1 + (pw-1) y) sigmoid(-z) ]
 __global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__ y,
                           const float *__restrict__ coef, float pw, int64_t n,
-                          double *__restrict__ item_loss, float *__restrict__ r) {
+                          double *__restrict__ item_loss, float *__restrict__ r, int exact) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double zi = z[i], yi = y[i], ci = coef[i];
     const double lw = 1.0 + ((double)pw - 1.0) * yi;
-    item_loss[i] = ci * ((1.0 - yi) * zi + lw * softplus_neg(zi));
+    item_loss[i] = ci * bce_item(zi, yi, lw, exact != 0);
     r[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
 }
 
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(256) void k_fb_logits_arg(const float *__restrict__
         if (elem) {
             const double zi = zf, yi = y[row], ci = coef[row];
             const double lw = 1.0 + ((double)pw - 1.0) * yi;
-            item_loss[row] = ci * ((1.0 - yi) * zi + lw * softplus_neg(zi));
+            item_loss[row] = ci * bce_item(zi, yi, lw, elem == 2);
             r[row] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
         }
     }
@@ -229,6 +241,7 @@ struct FbObjDev {
     float scale;       // multiplies the data loss and its gradient (1/n for logreg, 1 for multireg)
     float reg_weight;  // logreg: lambda / n
     float l_norm, l_data, l_query;  // multireg
+    int exact;         // diagnostic (env SSW_FB_EXACT_LOSS): exact f64 loss values instead of torch's mixed f32/f64 rounding
 };
 
 // one workgroup of `dim` (<= 1024) threads: reduce partials in slab order, add the
@@ -348,8 +361,16 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
         reg_loss *= obj.reg_weight;
         greg *= obj.reg_weight;
     } else {
+        // The three regulariser VALUES are rounded the way the reference's f32 tensors round them
+        // (multi_reg.py:125-129): the label loss is f64 there (float64 targets promote) but these terms are
+        // f32, and cosh(log s) - 1 near s = 1 moves in steps of 2^-23 -- times l_norm = 100 that is a 1.2e-5
+        // staircase in the total loss.  torch's L-BFGS stops / accepts line-search points on that staircase
+        // (|loss - prev_loss| < 1e-9, Armijo), so an exact f64 value here walks a different path and ends up to
+        // 7e-4 (rank scores) away from the reference's fit -- measured on tests/golden/multireg.npz c4.
+        // Gradients stay analytic (autograd's f32 sinh(log s)/s * 2w equals l (1 - 1/s^2) w to rounding).
         // norm: l (cosh(log s) - 1), s = w.w ; d/dw = l (1 - 1/s^2) w
-        p_norm = obj.l_norm * (0.5 * (ww + 1.0 / ww) - 1.0);
+        p_norm = obj.exact ? obj.l_norm * (0.5 * (ww + 1.0 / ww) - 1.0)
+                           : (double)(obj.l_norm * (coshf(logf((float)ww)) - 1.f));
         // data: l w'Mw ; d/dw = l (M + M') w
         double mw = 0.0, mtw = 0.0;
         if (act && obj.l_data != 0.f && xlx) {
@@ -359,9 +380,10 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
             }
         }
         p_data = obj.l_data * block_sum(act ? (double)wc * mw : 0.0);
+        if (!obj.exact) p_data = (double)(float)p_data;
         // query: l (1 - w^.q^)/2 ; d/dw = -l/2 (q^ - (w^.q^) w^)/|w|
         const double whq = wq / nclamp;
-        p_query = obj.l_query * (1.0 - whq) * 0.5;
+        p_query = obj.exact ? obj.l_query * (1.0 - whq) * 0.5 : (double)(obj.l_query * ((1.f - (float)whq) / 2.f));
         if (act) {
             const double what_c = wc / nclamp;
             greg = (float)(obj.l_norm * (1.0 - 1.0 / (ww * ww)) * wc + obj.l_data * (mw + mtw) -
@@ -463,6 +485,7 @@ static ssw_status fb_prepare(ssw_fb *fb, const ssw_fb_objective *o, FbObjDev *de
     *pairwise_active = false;
     memset(dev, 0, sizeof(*dev));
     dev->kind = o->kind;
+    dev->exact = getenv("SSW_FB_EXACT_LOSS") != nullptr;
     if (o->kind == SSW_FB_LOGREG) {
         // mean over items of weight_i * bce(.; pos_weight)   (logistic_regression.py:98-105)
         for (int64_t i = 0; i < n; ++i) coef[(size_t)i] = fb->sw_host.empty() ? 1.f : fb->sw_host[(size_t)i];
@@ -545,14 +568,14 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
         nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
         if (by_arg)
             hipLaunchKernelGGL(k_fb_logits_arg, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, wv, n, dim,
-                               dev.has_bias, fb->z, pairwise ? 0 : 1, fb->y, fb->coef, pw, fb->item, fb->r);
+                               dev.has_bias, fb->z, pairwise ? 0 : (dev.exact ? 2 : 1), fb->y, fb->coef, pw, fb->item, fb->r);
         else
             hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->w, n, dim,
                                dev.has_bias, fb->z);
         if (!pairwise) {
             if (!by_arg)
                 hipLaunchKernelGGL(k_fb_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->z, fb->y, fb->coef,
-                                   pw, n, fb->item, fb->r);
+                                   pw, n, fb->item, fb->r, dev.exact);
         } else if (pairwise_active) {
             const size_t lds = (size_t)3 * n * sizeof(float);
             if (o->loss_type == SSW_FB_LOSS_PAIRWISE_LOGISTIC)

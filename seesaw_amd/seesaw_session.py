@@ -73,7 +73,9 @@ class Session:
         self.init_q = key
         self.loop.state.curr_str = key
         vec = self.index.string2vec(string=key)
-        self.loop.state.tvec = vec
+        # as in the reference, LoopState.tvec is never assigned (seesaw_session.py:96-103 sets curr_str only),
+        # so LogReg2 / PseudoLR build their scorers with regularizer_vector=None: no regulariser at all.
+        # Setting it here would "repair" them and change every result of those two loops.
         self.loop.set_text_vec(vec)
 
     def update_state(self, state: SessionState):
