@@ -331,6 +331,8 @@ def main():
     elapsed = time.perf_counter() - t0
     scan_ms = index.local.profile_read()
     index.local.profile(False)
+    # every message carried its shard's select-overflow flag: a set flag means some query's keys were not exact
+    index.xchg.assert_no_overflow_seen()
 
     # last result -> host (outside the timed region) as a sanity anchor
     from seesaw_amd.device_index import decode_keys

@@ -67,7 +67,9 @@ ssw_status ssw_index_create(int32_t device, int64_t n_rows, int32_t dim,
                             const float *dev_vectors_or_null, ssw_index **out);
 ssw_status ssw_index_destroy(ssw_index *idx);
 /* run all of this handle's work on an existing hipStream_t (e.g. torch's current
- * stream) instead of the handle's own stream. NULL restores the own stream. */
+ * stream) instead of the handle's own (non-blocking) stream.  NULL restores the own stream; to name the
+ * default stream -- whose handle IS NULL, e.g. torch.cuda.current_stream().cuda_stream == 0 -- pass
+ * hipStreamLegacy ((hipStream_t)1). */
 ssw_status ssw_index_set_stream(ssw_index *idx, void *hip_stream);
 ssw_status ssw_index_sync(ssw_index *idx);
 ssw_status ssw_index_shape(const ssw_index *idx, int64_t *n_rows, int32_t *dim, int64_t *n_images);
@@ -116,10 +118,16 @@ ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *ex
 ssw_status ssw_index_set_excluded(ssw_index *idx, const int64_t *excluded_images, int64_t n_excluded);
 ssw_status ssw_index_topk_dev(ssw_index *idx, const float *q_dev, int32_t k);
 /* device result buffers of the last topk: keys [SSW_MAX_TOPK] u64 =
- * (orderable(score) << 32) | (0xFFFFFFFF - image), sorted descending; count [1] i32;
- * best_rows [SSW_MAX_TOPK] u32. */
+ * (orderable(score) << 32) | (0xFFFFFFFF - image), sorted descending; count [2] i32 = {number of keys,
+ * overflow flag}; best_rows [SSW_MAX_TOPK] u32.  overflow != 0: more than 8192 images share the 24-bit score
+ * prefix of the k-th score (duplicated vectors) and the keys are NOT the exact top-k -- rerun with
+ * ssw_index_select_deep_dev (ssw_index_topk / ssw_index_topk_fetch do that by themselves). */
 ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_count,
                                  void **dev_best_rows);
+/* exact selection over the resident scores for the mass-tie case (host-synchronised radix descent over the
+ * full 64-bit composite key); leaves keys / count / best_rows in the same buffers, overflow cleared.
+ * No reference counterpart: np.argsort sorts all N keys (multiscale_index.py:171-172). */
+ssw_status ssw_index_select_deep_dev(ssw_index *idx, int32_t k);
 /* read the last device-side result back (synchronises). */
 ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, float *out_scores,
                                 int64_t *out_best_rows, int32_t *out_count);

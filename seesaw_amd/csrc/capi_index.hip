@@ -403,6 +403,21 @@ ssw_status ssw_index_topk_dev(ssw_index *idx, const float *q_dev, int32_t k) {
     return do_select(idx, k);
 }
 
+// The fast selection keeps at most 8192 candidates; when more images than that share the 24-bit score prefix
+// of the k-th score (duplicated vectors, mass ties) it raises the overflow word next to the count
+// (ssw_index_result_ptrs: count[1]).  The host-fetching entry points rerun the deep path by themselves;
+// callers of the device-resident form read the flag (e.g. after their exchange step) and call this.
+ssw_status ssw_index_select_deep_dev(ssw_index *idx, int32_t k) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    if (idx->n_images == 0) return SSW_OK;
+    DeviceGuard guard(idx->device);
+    SSW_TRY(ensure_ws(idx));
+    const float *values = idx->has_map ? idx->ws.img_score : idx->scores;
+    const uint32_t *best = idx->has_map ? idx->ws.img_best : nullptr;
+    return launch_select_topk_deep(idx->ws, values, idx->n_images, best, k, idx->device, idx->stream);
+}
+
 ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_count,
                                  void **dev_best_rows) {
     SSW_REQUIRE(idx != nullptr, "idx is NULL");

@@ -22,6 +22,8 @@
 // Excluded images (InteractiveQuery.returned, query_interface.py:43-48) are skipped in
 // steps 2-4 through a device bitmap.  Bound: reads 4 B/image three times -- < 0.6 % of
 // the scan's traffic at dim=512.
+#include <algorithm>
+
 #include "ssw_common.h"
 
 namespace ssw {
@@ -269,8 +271,9 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
         for (int i = t; i < n; i += 1024) s[i] = keys_in[i];
     } else {
         for (int l = 0; l < n_lists; ++l) {
-            const int c = min(counts[l], list_stride);
-            if (n + c > FINAL_CAP) break;  // launcher guarantees n_lists*stride <= FINAL_CAP
+            // lists arrive sorted (descending): only a list's first k keys can reach the global top-k
+            const int c = max(0, min(min(counts[l], list_stride), k));
+            if (n + c > FINAL_CAP) break;  // launcher guarantees n_lists * min(stride, k) <= FINAL_CAP
             for (int i = t; i < c; i += 1024) s[n + i] = keys_in[(int64_t)l * list_stride + i];
             n += c;
         }
@@ -482,12 +485,13 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
 ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t list_stride,
                              const int32_t *counts, int32_t k, uint64_t *keys_out,
                              int32_t *count_out, hipStream_t stream) {
-    if (n_lists < 1 || list_stride < 1 || (int64_t)n_lists * list_stride > FINAL_CAP) {
-        set_error("merge: %d lists x %d keys exceed %d candidates", n_lists, list_stride, FINAL_CAP);
-        return SSW_ERR_INVALID;
-    }
     if (k < 1 || k > SSW_MAX_TOPK) {
         set_error("merge: k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+        return SSW_ERR_INVALID;
+    }
+    // every list contributes its first min(stride, k) keys (lists are sorted): 8 shards x k = 1024 just fit
+    if (n_lists < 1 || list_stride < 1 || (int64_t)n_lists * std::min(list_stride, k) > FINAL_CAP) {
+        set_error("merge: %d lists x %d keys exceed %d candidates", n_lists, std::min(list_stride, k), FINAL_CAP);
         return SSW_ERR_INVALID;
     }
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,

@@ -86,8 +86,16 @@ class DeviceIndex:
         _lib.call("ssw_index_device_ptrs", self._h, ctypes.byref(v), ctypes.byref(s))
         return v.value, s.value
 
+    HIP_STREAM_LEGACY = 1  # hipStreamLegacy: the handle that names the default (NULL) stream explicitly
+
     def set_stream(self, stream_ptr: int):
-        _lib.call("ssw_index_set_stream", self._h, ctypes.c_void_p(stream_ptr) if stream_ptr else None)
+        """run this handle's work on the caller's stream.  torch's default stream has the handle 0, which the
+        C-ABI reads as "back to the handle's own stream": it is passed as hipStreamLegacy instead, so the scan
+        and the selection are ordered with the torch ops issued around them."""
+        _lib.call("ssw_index_set_stream", self._h, ctypes.c_void_p(int(stream_ptr) or self.HIP_STREAM_LEGACY))
+
+    def restore_own_stream(self):
+        _lib.call("ssw_index_set_stream", self._h, None)
 
     def sync(self):
         _lib.call("ssw_index_sync", self._h)
@@ -164,6 +172,10 @@ class DeviceIndex:
 
     def topk_dev(self, q_dev_ptr: int, k: int):
         _lib.call("ssw_index_topk_dev", self._h, ctypes.c_void_p(q_dev_ptr) if q_dev_ptr else None, int(k))
+
+    def select_deep_dev(self, k: int):
+        """exact selection for the mass-tie case (result_ptrs' overflow word set): same result buffers"""
+        _lib.call("ssw_index_select_deep_dev", self._h, int(k))
 
     def scan_dev(self, q_dev_ptr: int):
         _lib.call("ssw_index_scan_dev", self._h, ctypes.c_void_p(q_dev_ptr))

@@ -60,51 +60,88 @@ def merge_keys_hip(device: int, stream_ptr: int, keys, counts, k: int, out_keys,
 
 
 class ShardedTopK:
-    """Exchange + merge step shared by every sharded index.  `local_topk(k)` must leave the
-    shard's sorted composite keys / count in (keys_ptr, count_ptr) device buffers."""
+    """Exchange + merge step shared by every sharded index.  A shard's local selection leaves its sorted
+    composite keys and the pair (count, overflow) in device buffers (ssw_index_result_ptrs); one message per
+    rank -- k_max keys followed by one word holding count | overflow << 32 -- travels in a single all-gather.
+    The overflow flags of all ranks stay on the device (`flags`); `overflowed()` reads them (synchronises)."""
 
     def __init__(self, *, rank: int, world: int, device, image_offset: int, k_max: int,
-                 group=None, merge=merge_keys_hip):
+                 group=None, merge=merge_keys_hip, force_collective: bool = False):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
+        self.force_collective = force_collective  # run the all-gather even at world size 1 (RCCL smoke test)
         self.device = device
         self.image_offset = int(image_offset)
         self.group = group
         self.merge = merge
         self.k_max = int(k_max)
         dev = device
-        # one message per rank: k_max keys followed by the count (as an int64 word), so the exchange is a
-        # single all-gather
         self.send_buf = torch.zeros(self.k_max + 1, dtype=torch.int64, device=dev)
         self.send_keys = self.send_buf[:self.k_max]
         self.all_buf = torch.zeros((world, self.k_max + 1), dtype=torch.int64, device=dev)
         self.all_keys = self.all_buf  # rows are read with stride k_max + 1
         self.all_counts = torch.zeros(world, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(world, dtype=torch.int64, device=dev)      # overflow flag of every rank, last exchange
+        self.flags_seen = torch.zeros(1, dtype=torch.int64, device=dev)    # OR over all exchanges since reset
         self.out_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def exchange(self, local_keys, local_count, k: int):
-        """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys), local ids.
-        Returns (out_keys[k_max], out_count[1]) holding the global top-k on every rank."""
+    def pack(self, local_keys, local_count, k: int, image_offset: Optional[int] = None):
+        """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys, local image positions);
+        local_count: int32 tensor [1] = count or [2] = (count, overflow).  Fills this rank's message."""
         torch = self.torch
-        assert k <= self.k_max
+        assert 1 <= k <= self.k_max
+        off = self.image_offset if image_offset is None else int(image_offset)
         # globalise: low 32 bits hold 0xFFFFFFFF - local_id, so subtracting the shard's
         # first image position yields 0xFFFFFFFF - global_id (no borrow: ids < 2^32)
-        self.send_keys[:k] = local_keys[:k] - self.image_offset
-        self.send_buf[self.k_max:] = local_count.to(torch.int64)
-        if self.world > 1:
+        self.send_keys[:k] = local_keys[:k] - off
+        word = local_count[:1].to(torch.int64)
+        if local_count.shape[0] > 1:
+            word = word | (local_count[1:2].to(torch.int64) << 32)
+        self.send_buf[self.k_max:] = word
+        return self.send_buf
+
+    def gather(self):
+        if self.world > 1 or self.force_collective:
             import torch.distributed as dist
             # flat (concatenating) form: accepted by both RCCL and gloo
             dist.all_gather_into_tensor(self.all_buf.view(-1), self.send_buf, group=self.group)
         else:
             self.all_buf[0] = self.send_buf
-        self.all_counts.copy_(self.all_buf[:, self.k_max])
+
+    def merge_gathered(self, k: int):
+        """global top-k of the gathered messages (all_buf) on every rank -> (out_keys[k_max], out_count[1])"""
+        torch = self.torch
+        words = self.all_buf[:, self.k_max]
+        self.all_counts.copy_(words & 0xFFFFFFFF)
+        self.flags.copy_(words >> 32)
+        self.flags_seen |= self.flags.max()
         stream_ptr = torch.cuda.current_stream().cuda_stream if self.all_keys.is_cuda else 0
         dev_index = self.all_keys.device.index if self.all_keys.is_cuda else -1
         self.merge(dev_index, stream_ptr, self.all_keys, self.all_counts, k, self.out_keys,
                    self.out_count)
         return self.out_keys, self.out_count
+
+    def exchange(self, local_keys, local_count, k: int):
+        self.pack(local_keys, local_count, k)
+        self.gather()
+        return self.merge_gathered(k)
+
+    def overflowed(self):
+        """ranks whose last local selection overflowed its fast path (host read: synchronises).  Every rank
+        sees the same list, so all of them can agree to repeat the exchange after the deep selection."""
+        return [int(r) for r in self.torch.nonzero(self.flags.cpu()).reshape(-1)]
+
+    def assert_no_overflow_seen(self):
+        """for callers of the asynchronous form: fail loudly if any exchange since the last reset carried an
+        overflow flag (the merged keys of that query were not the exact top-k)"""
+        if int(self.flags_seen.cpu().item()) != 0:
+            raise RuntimeError("sharded top-k: a shard's fast selection overflowed (mass ties / duplicated vectors); "
+                               "use the synchronous topk(), which reruns the exact deep selection")
+
+    def reset_overflow_seen(self):
+        self.flags_seen.zero_()
 
 
 class ShardedSyntheticIndex:
@@ -112,7 +149,7 @@ class ShardedSyntheticIndex:
     over the ranks of the default process group; each rank generates its slice in place."""
 
     def __init__(self, n_total: int, dim: int, seed: int, rank: int, world: int,
-                 local_device: int, k_max: int = 128, group=None):
+                 local_device: int, k_max: int = 128, group=None, force_collective: bool = False):
         import torch
         from .device_index import DeviceIndex
         self.torch = torch
@@ -129,12 +166,14 @@ class ShardedSyntheticIndex:
         keys_ptr, count_ptr, _ = self.local.result_ptrs()
         self.local_keys = torch.as_tensor(_DevArray(keys_ptr, (_lib.SSW_MAX_TOPK,), "<i8"),
                                           device=self.device)
-        self.local_count = torch.as_tensor(_DevArray(count_ptr, (1,), "<i4"), device=self.device)
+        self.local_count = torch.as_tensor(_DevArray(count_ptr, (2,), "<i4"), device=self.device)  # count, overflow
         self.xchg = ShardedTopK(rank=rank, world=world, device=self.device,
-                                image_offset=self.row_lo, k_max=k_max, group=group)
+                                image_offset=self.row_lo, k_max=k_max, group=group,
+                                force_collective=force_collective)
 
     def topk_async(self, q_dev_ptr: int, k: int):
-        """scan + local select + all-gather + merge, all enqueued on the current stream."""
+        """scan + local select + all-gather + merge, all enqueued on the current stream.  The overflow flags
+        travel with the message; check `xchg.assert_no_overflow_seen()` after synchronising."""
         self.local.topk_dev(q_dev_ptr, k)
         return self.xchg.exchange(self.local_keys, self.local_count, k)
 
@@ -142,6 +181,14 @@ class ShardedSyntheticIndex:
         from .device_index import decode_keys
         keys, count = self.topk_async(q_dev_ptr, k)
         self.torch.cuda.synchronize(self.device)
+        over = self.xchg.overflowed()
+        if over:  # the same list on every rank: the overflowing ones redo their selection exactly, all re-exchange
+            if self.rank in over:
+                self.local.select_deep_dev(k)
+            keys, count = self.xchg.exchange(self.local_keys, self.local_count, k)
+            self.torch.cuda.synchronize(self.device)
+            assert not self.xchg.overflowed()
+            self.xchg.reset_overflow_seen()
         c = int(count.item())
         imgs, scores = decode_keys(keys[:c].cpu().numpy().view(np.uint64))
         return imgs, scores

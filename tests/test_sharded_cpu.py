@@ -49,7 +49,12 @@ def _worker(rank, world, port, n_total, k, tmpdir):
     out_keys, out_count = x.exchange(keys, count, k)
     c = int(out_count.item())
     imgs, scores = decode_keys(out_keys[:c].numpy().view(np.uint64))
-    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), imgs=imgs, scores=scores)
+    clean = x.overflowed()
+    # the select-overflow flag rides in the same message: rank 1 raises it, every rank learns of it
+    flagged = torch.tensor([ids.shape[0], 1 if rank == 1 else 0], dtype=torch.int32)
+    x.exchange(keys, flagged, k)
+    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), imgs=imgs, scores=scores, clean=np.asarray(clean, dtype=np.int64),
+             flagged=np.asarray(x.overflowed(), dtype=np.int64), seen=int(x.flags_seen.item()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,6 +70,7 @@ def test_two_rank_exchange_matches_single_index(tmp_path, oracle, n_total, k):
         g = np.load(tmp_path / f"rank{r}.npz")
         assert np.array_equal(g["imgs"], ref_ids), r            # every rank holds the global answer
         assert np.array_equal(g["scores"].view(np.uint32), ref_sc.view(np.uint32))
+        assert g["clean"].size == 0 and g["flagged"].tolist() == [1] and int(g["seen"]) == 1
 
 
 def test_bench_replica_aggregation():
