@@ -142,6 +142,25 @@ ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int
 ssw_status ssw_index_score_rows(ssw_index *idx, const float *q_host, const int64_t *rows_host,
                                 int64_t n, float *out_scores_host);
 
+/* ------------------------------------------------------------------------- */
+/* Second stage of the multiscale lookup: `avg_score` aggregation on the device */
+/* replaces: score_frame2 (aug_weight='level_max') + box_join as driven by      */
+/*           rescore_candidates   seesaw/indices/multiscale/multiscale_index.py */
+/*           :112-150, 379-403;   seesaw/box_utils.py:336-372                   */
+/* ------------------------------------------------------------------------- */
+/* tile geometry of every row: boxes [n_rows, 4] f32 = x1, y1, x2, y2 (vector_meta's columns, original-image
+ * pixels) and zoom_level [n_rows] i32 in [0, 31]. */
+ssw_status ssw_index_set_tile_meta(ssw_index *idx, const float *boxes_host, const int32_t *zoom_host);
+/* for each of m candidate images (positions as returned by ssw_index_topk): tile i's score := mean over zoom
+ * levels of the score of the best-overlapping (IoU > 0, first maximum) tile of that level, levels restricted by
+ * aug_larger (0 'all', 1 'greater': partner level >= own, 2 'adjacent': partner level == own); the image is
+ * represented by its first tile with the highest aggregated score.  Tile scores are the ones the last scan left
+ * on the device, minus minus_scores (optional; one value per candidate tile, candidates in the given order, tiles
+ * in row order: the `vector2` form, multiscale_index.py:347-349).  IoU in f32 as torchvision forms it, mean as
+ * pandas' float32 group mean (Kahan sum): bit-identical to the reference on identical tile scores. */
+ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions, int32_t m, int32_t aug_larger,
+                                 const float *minus_scores_or_null, float *out_scores, int64_t *out_best_rows);
+
 /* merge several sorted key lists (e.g. the all-gathered per-shard top-k of a
  * row-sharded index; keys as in ssw_index_result_ptrs but with GLOBAL image ids
  * added by the caller via id_offsets) into the global top-k.  All pointers device. */

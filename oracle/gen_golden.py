@@ -65,6 +65,30 @@ def synth_vector_meta(n_images, tiles_per_image, dbidx_of_position, rng):
     return df
 
 
+def synth_pyramid_meta(n_images, dbidx_of_position, rng):
+    """tiles of a 3-level pyramid in original-image pixels, like the reference's tiler output
+    (multiscale_tools.py:96-117): level z has square tiles of side 224 * 2**z at half-tile stride, the last level
+    is clipped to the image; image sizes vary, rows sorted by dbidx."""
+    import pandas as pd
+    rows = []
+    sizes = [(640, 480), (500, 375), (1024, 768), (448, 448), (224, 224), (800, 300)]
+    for pos in range(n_images):
+        w, h = sizes[int(rng.integers(0, len(sizes)))]
+        for zoom in range(3):
+            side = 224.0 * (2 ** zoom)
+            if zoom > 0 and side / 2 >= max(w, h):
+                break
+            stride = side / 2
+            xs = np.arange(0, max(w - side, 0) + 1e-6, stride) if w > side else np.array([0.0])
+            ys = np.arange(0, max(h - side, 0) + 1e-6, stride) if h > side else np.array([0.0])
+            for y1 in ys:
+                for x1 in xs:
+                    rows.append((int(dbidx_of_position[pos]), zoom, x1, y1, min(x1 + side, w), min(y1 + side, h)))
+    df = pd.DataFrame(rows, columns=["dbidx", "zoom_level", "x1", "y1", "x2", "y2"])
+    return df.assign(zoom_level=df.zoom_level.astype("int16"),
+                     **{c: df[c].astype("float32") for c in ["x1", "y1", "x2", "y2"]})
+
+
 # ------------------------------------------------------------------------------------
 def gen_scan_topk():
     """(i) _query_prelim(force_exact=True) and CoarseIndex.query on seeded vectors."""
@@ -150,6 +174,44 @@ def gen_multiscale_query():
                       agg_method="plain_score", aug_larger="all", rescore_method=None)
     out["v2_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
     out["v2_scores"] = np.array([a.score.values[0] for a in res["activations"]], dtype=np.float64)
+
+    # agg_method='avg_score' (score_frame2 / box_join, multiscale_index.py:112-150, box_utils.py:336-372): the
+    # aggregation scripts/configs/std_bench.yaml uses.  A second index with a real 3-level tile pyramid (tiles of
+    # neighbouring zoom levels overlap), all three aug_larger modes, plus the vector2 form.  The candidate tiles'
+    # scores as the reference formed them are captured too, so the CPU oracle can be pinned on identical inputs.
+    pseed, pn = 311, 300
+    prng = np.random.default_rng(pseed)
+    pmeta = synth_pyramid_meta(pn, np.arange(pn) * 3 + 1, prng)
+    PX = orc.synth_rows(pseed, 0, pmeta.shape[0], 512)
+    pq = orc.synth_query(pseed)
+    pindex = msi.MultiscaleIndex(embedding=None, vectors=PX, vector_meta=pmeta, vec_index=None)
+    out["pyr_seed"], out["pyr_n_images"] = np.asarray(pseed), np.asarray(pn)
+    out["pyr_meta"] = pmeta[["dbidx", "zoom_level", "x1", "y1", "x2", "y2"]].values.astype(np.float64)
+    orig_rescore = msi.rescore_candidates
+    for aug in ["all", "greater", "adjacent"]:
+        seen = {}
+
+        def recording(fullmeta, topk, _o=orig_rescore, **kw):
+            seen["rows"] = fullmeta.index.values.astype(np.int64).copy()
+            seen["scores"] = fullmeta.score.values.astype(np.float32).copy()
+            return _o(fullmeta, topk, **kw)
+
+        msi.rescore_candidates = recording
+        try:
+            res = pindex.query(vector=pq, topk=10, shortlist_size=50, exclude=pr.BitMap(pmeta.dbidx.values[:40]),
+                               force_exact=True, agg_method="avg_score", aug_larger=aug, rescore_method=None)
+        finally:
+            msi.rescore_candidates = orig_rescore
+        out[f"avg_{aug}_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+        out[f"avg_{aug}_activations"] = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64)
+                                                  for a in res["activations"]])
+        out[f"avg_{aug}_cand_rows"], out[f"avg_{aug}_cand_scores"] = seen["rows"], seen["scores"]
+    pq2 = orc.synth_query(pseed + 1)
+    res = pindex.query(vector=pq, vector2=pq2, topk=10, shortlist_size=50, exclude=pr.BitMap(), force_exact=True,
+                       agg_method="avg_score", aug_larger="greater", rescore_method=None)
+    out["avg_v2_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+    out["avg_v2_activations"] = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64)
+                                          for a in res["activations"]])
     save("multiscale_query", **out)
 
 

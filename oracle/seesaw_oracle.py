@@ -271,3 +271,72 @@ def label_propagation(W, *, label_ids, label_values, reg_lambda, reg_values=None
             break
         old = new
     return old, sweeps, converged
+
+
+# ---- avg_score aggregation: score_frame2 / box_join ---------------------------------------
+def box_iou_f32(boxes: np.ndarray):
+    """all-pairs IoU of one image's tile boxes [T, 4] = x1, y1, x2, y2 in f32, op for op as box_utils.box_iou
+    (box_utils.py:336-350) forms it through torchvision's _box_inter_union on float32 tensors:
+    area = (x2-x1)*(y2-y1); wh = clamp(min(rb) - max(lt), 0); inter = w*h; union = (a_i + a_j) - inter."""
+    b = np.asarray(boxes, dtype=np.float32)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    w = np.maximum(np.minimum(b[:, None, 2], b[None, :, 2]) - np.maximum(b[:, None, 0], b[None, :, 0]), np.float32(0))
+    h = np.maximum(np.minimum(b[:, None, 3], b[None, :, 3]) - np.maximum(b[:, None, 1], b[None, :, 1]), np.float32(0))
+    inter = (w * h).astype(np.float32)
+    union = ((area[:, None] + area[None, :]).astype(np.float32) - inter).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (inter / union).astype(np.float32)
+
+
+def _kahan_mean_f32(values):
+    """pandas' groupby mean of a float32 column: Kahan-compensated f32 sum in row order, f32 division"""
+    s = np.float32(0)
+    c = np.float32(0)
+    for x in values:
+        y = np.float32(np.float32(x) - c)
+        t = np.float32(s + y)
+        c = np.float32(np.float32(t - s) - y)
+        s = t
+    return np.float32(s / np.float32(len(values)))
+
+
+def avg_score_image(boxes: np.ndarray, zoom: np.ndarray, scores: np.ndarray, aug_larger: str):
+    """score_frame2 with aug_weight='level_max' for ONE image (multiscale_index.py:112-150): tile i's score becomes
+    the mean, over the zoom levels z allowed by aug_larger, of the score of the tile of level z overlapping i most
+    (first such tile on ties; only pairs with IoU > 0 take part).  -> (index of the first tile with the highest
+    aggregated score, that score f32, all aggregated scores)."""
+    iou = box_iou_f32(boxes)
+    zoom = np.asarray(zoom).astype(np.int64)
+    scores = np.asarray(scores, dtype=np.float32)
+    T = zoom.shape[0]
+    agg = np.empty(T, dtype=np.float32)
+    for i in range(T):
+        winners = []
+        for z in np.unique(zoom):  # ascending: the order pandas sums the groups' rows in
+            if aug_larger == "greater" and z < zoom[i]:
+                continue
+            if aug_larger == "adjacent" and z != zoom[i]:
+                continue
+            assert aug_larger in ("all", "greater", "adjacent")
+            js = np.nonzero((zoom == z) & (iou[i] > 0))[0]
+            if js.size:
+                winners.append(scores[js[np.argmax(iou[i, js])]])  # argmax: first maximum
+        agg[i] = _kahan_mean_f32(winners) if winners else np.float32(np.nan)
+    best = int(np.flatnonzero(agg == np.nanmax(agg))[0])
+    return best, agg[best], agg
+
+
+def rescore_avg_score(row_dbidx, boxes, zoom, scores, topk: int, aug_larger: str):
+    """rescore_candidates for agg_method='avg_score' (multiscale_index.py:379-403): candidate tiles (sorted by
+    image) -> (dbidxs [topk], best tile position in the inputs [topk], aggregated score [topk])."""
+    row_dbidx = np.asarray(row_dbidx)
+    ids, starts = np.unique(row_dbidx, return_index=True)
+    bounds = list(starts) + [row_dbidx.shape[0]]
+    best_rows, best_scores = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        j, sc, _ = avg_score_image(boxes[a:b], zoom[a:b], scores[a:b], aug_larger)
+        best_rows.append(a + j)
+        best_scores.append(sc)
+    dbscores = np.asarray(best_scores, dtype=np.float64)
+    top = np.argsort(-dbscores)[:topk]
+    return ids[top], np.asarray(best_rows)[top], np.asarray(best_scores, dtype=np.float32)[top]

@@ -58,6 +58,8 @@ _SIGNATURES = {
                                c_void_p, c_i32_p]),
     "ssw_index_set_excluded": (c_i32, [c_void_p, c_void_p, c_i64]),
     "ssw_index_topk_dev": (c_i32, [c_void_p, c_void_p, c_i32]),
+    "ssw_index_set_tile_meta": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_index_rescore_avg": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "ssw_index_select_deep_dev": (c_i32, [c_void_p, c_i32]),
     "ssw_index_result_ptrs": (c_i32, [c_void_p, c_void_pp, c_void_pp, c_void_pp]),
     "ssw_index_topk_fetch": (c_i32, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32_p]),

@@ -14,18 +14,23 @@ _XYXY = ["x1", "y1", "x2", "y2"]
 
 
 def _xyxy(df) -> np.ndarray:
-    return np.stack([np.asarray(df[c].values, dtype=np.float64) for c in _XYXY], axis=1)
+    """[n, 4] in the dtype np.stack gives the four columns (the reference's df2tensor, box_utils.py:326-333):
+    float32 tile boxes stay float32, python-float label boxes are float64"""
+    arr = np.stack([np.asarray(df[c].values) for c in _XYXY], axis=1)
+    return arr if arr.dtype.kind == "f" else arr.astype(np.float32)
 
 
 def box_iou(df1, df2, return_containment: bool = False):
-    """pairwise IoU [len(df1), len(df2)]; containment = intersection / area(df1 box)."""
+    """pairwise IoU [len(df1), len(df2)]; containment = intersection / area(df1 box).  Dtypes follow the
+    reference (torchvision's _box_inter_union on the two tensors): each side's areas in its own dtype,
+    intersections and the quotient in the promoted dtype -- float32 throughout for two float32 frames."""
     a, b = _xyxy(df1), _xyxy(df2)
     area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
     area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     w = np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0])
     h = np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1])
     inter = np.clip(w, 0, None) * np.clip(h, 0, None)
-    union = area_a[:, None] + area_b[None, :] - inter
+    union = (area_a[:, None] + area_b[None, :]) - inter
     with np.errstate(divide="ignore", invalid="ignore"):
         iou = inter / union
         cont = inter / area_a[:, None]

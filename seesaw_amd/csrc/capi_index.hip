@@ -1,4 +1,5 @@
 // capi_index.hip -- C-ABI of the resident vector index (see include/seesaw_hip.h).
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -91,6 +92,14 @@ struct ssw_index {
     void *res_host = nullptr;  // pinned result mirror
     float *q2_dev = nullptr;  // second query vector (score_rows)
     PinnedStage q2_stage;
+    // tile geometry + staging of the avg_score aggregation (rescore.hip)
+    std::vector<int64_t> row_start_host;  // host mirror of row_start
+    float *tile_boxes = nullptr;   // [n, 4] x1, y1, x2, y2
+    int32_t *tile_zoom = nullptr;  // [n]
+    int64_t *rs_pos = nullptr, *rs_off = nullptr, *rs_row = nullptr;  // [rs_cap]
+    float *rs_score = nullptr;     // [rs_cap]
+    float *rs_minus = nullptr;     // [rs_minus_cap]
+    int64_t rs_cap = 0, rs_minus_cap = 0;
     // profiling of the scan kernel
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -230,6 +239,13 @@ ssw_status ssw_index_destroy(ssw_index *idx) {
     (void)hipFree(idx->scores);
     (void)hipFree(idx->q_dev);
     idx->q_stage.release();
+    (void)hipFree(idx->tile_boxes);
+    (void)hipFree(idx->tile_zoom);
+    (void)hipFree(idx->rs_pos);
+    (void)hipFree(idx->rs_off);
+    (void)hipFree(idx->rs_row);
+    (void)hipFree(idx->rs_score);
+    (void)hipFree(idx->rs_minus);
     (void)hipFree(idx->row_start);
     (void)hipFree(idx->gather_idx);
     (void)hipFree(idx->gather_out);
@@ -316,6 +332,7 @@ ssw_status ssw_index_set_row2image(ssw_index *idx, const int32_t *row2image_host
     }
     (void)hipFree(idx->row_start);
     idx->row_start = nullptr;
+    idx->row_start_host.clear();
     if (row2image_host == nullptr) {
         idx->has_map = false;
         idx->n_images = idx->n;
@@ -345,8 +362,85 @@ ssw_status ssw_index_set_row2image(ssw_index *idx, const int32_t *row2image_host
     SSW_HIP_TRY(hipMalloc((void **)&idx->row_start, ((size_t)n_images + 1) * sizeof(int64_t)));
     SSW_HIP_TRY(hipMemcpy(idx->row_start, start.data(), ((size_t)n_images + 1) * sizeof(int64_t),
                           hipMemcpyHostToDevice));
+    idx->row_start_host = std::move(start);
     idx->has_map = true;
     idx->n_images = n_images;
+    return SSW_OK;
+}
+
+ssw_status ssw_index_set_tile_meta(ssw_index *idx, const float *boxes_host, const int32_t *zoom_host) {
+    SSW_REQUIRE(idx != nullptr && boxes_host != nullptr && zoom_host != nullptr, "NULL argument");
+    DeviceGuard guard(idx->device);
+    for (int64_t r = 0; r < idx->n; ++r)
+        SSW_REQUIRE(zoom_host[r] >= 0 && zoom_host[r] <= SSW_RESCORE_MAX_ZOOM, "zoom_level[%lld]=%d outside [0, %d]",
+                    (long long)r, zoom_host[r], SSW_RESCORE_MAX_ZOOM);
+    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (!idx->tile_boxes) SSW_HIP_TRY(hipMalloc((void **)&idx->tile_boxes, (size_t)std::max<int64_t>(idx->n, 1) * 16));
+    if (!idx->tile_zoom) SSW_HIP_TRY(hipMalloc((void **)&idx->tile_zoom, (size_t)std::max<int64_t>(idx->n, 1) * 4));
+    SSW_HIP_TRY(hipMemcpy(idx->tile_boxes, boxes_host, (size_t)idx->n * 16, hipMemcpyHostToDevice));
+    SSW_HIP_TRY(hipMemcpy(idx->tile_zoom, zoom_host, (size_t)idx->n * 4, hipMemcpyHostToDevice));
+    return SSW_OK;
+}
+
+ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions, int32_t m, int32_t aug_larger,
+                                 const float *minus_scores_or_null, float *out_scores, int64_t *out_best_rows) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (m <= 0) return SSW_OK;
+    SSW_REQUIRE(image_positions && out_scores && out_best_rows, "NULL argument");
+    SSW_REQUIRE(aug_larger >= 0 && aug_larger <= 2, "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent)", aug_larger);
+    SSW_REQUIRE(idx->has_map && idx->tile_boxes && idx->tile_zoom,
+                "rescore_avg needs ssw_index_set_row2image and ssw_index_set_tile_meta first");
+    DeviceGuard guard(idx->device);
+    std::vector<int64_t> off((size_t)m);
+    int64_t total = 0, max_tiles = 0;
+    for (int32_t c = 0; c < m; ++c) {
+        const int64_t p = image_positions[c];
+        SSW_REQUIRE(p >= 0 && p < idx->n_images, "image position %lld outside [0, %lld)", (long long)p,
+                    (long long)idx->n_images);
+        const int64_t t = idx->row_start_host[(size_t)p + 1] - idx->row_start_host[(size_t)p];
+        off[(size_t)c] = total;
+        total += t;
+        max_tiles = std::max(max_tiles, t);
+    }
+    SSW_REQUIRE(max_tiles <= SSW_RESCORE_MAX_TILES, "an image with %lld tiles exceeds the %d the kernel keeps in LDS",
+                (long long)max_tiles, SSW_RESCORE_MAX_TILES);
+    hipStream_t s = idx->stream;
+    if (m > idx->rs_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(s));
+        for (void *q : {(void *)idx->rs_pos, (void *)idx->rs_off, (void *)idx->rs_row, (void *)idx->rs_score}) (void)hipFree(q);
+        idx->rs_pos = idx->rs_off = idx->rs_row = nullptr;
+        idx->rs_score = nullptr;
+        idx->rs_cap = 0;
+        int64_t cap = 256;
+        while (cap < m) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&idx->rs_pos, (size_t)cap * 8));
+        SSW_HIP_TRY(hipMalloc((void **)&idx->rs_off, (size_t)cap * 8));
+        SSW_HIP_TRY(hipMalloc((void **)&idx->rs_row, (size_t)cap * 8));
+        SSW_HIP_TRY(hipMalloc((void **)&idx->rs_score, (size_t)cap * 4));
+        idx->rs_cap = cap;
+    }
+    if (minus_scores_or_null && total > idx->rs_minus_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(idx->rs_minus);
+        idx->rs_minus = nullptr;
+        idx->rs_minus_cap = 0;
+        int64_t cap = 4096;
+        while (cap < total) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&idx->rs_minus, (size_t)cap * 4));
+        idx->rs_minus_cap = cap;
+    }
+    // inputs are a few hundred bytes: plain synchronous copies from the caller's buffers (ordered before the launch)
+    SSW_HIP_TRY(hipMemcpyAsync(idx->rs_pos, image_positions, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    SSW_HIP_TRY(hipMemcpyAsync(idx->rs_off, off.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
+    if (minus_scores_or_null)
+        SSW_HIP_TRY(hipMemcpyAsync(idx->rs_minus, minus_scores_or_null, (size_t)total * 4, hipMemcpyHostToDevice, s));
+    SSW_HIP_TRY(hipStreamSynchronize(s));  // `off` is a local; pageable sources are staged by now
+    SSW_TRY(launch_avg_score(idx->tile_boxes, idx->tile_zoom, idx->scores, minus_scores_or_null ? idx->rs_minus : nullptr,
+                             idx->row_start, idx->rs_pos, idx->rs_off, m, (int32_t)max_tiles, aug_larger,
+                             idx->rs_score, idx->rs_row, s));
+    SSW_HIP_TRY(hipMemcpyAsync(out_scores, idx->rs_score, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    SSW_HIP_TRY(hipMemcpyAsync(out_best_rows, idx->rs_row, (size_t)m * 8, hipMemcpyDeviceToHost, s));
+    SSW_HIP_TRY(hipStreamSynchronize(s));
     return SSW_OK;
 }
 

@@ -164,4 +164,11 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
 ssw_status launch_gather_f32(const float *src, const int64_t *idx_dev, int64_t n, float *dst,
                              hipStream_t stream);
 
+// rescore.hip: avg_score aggregation of candidate images' tiles (score_frame2 / box_join).
+constexpr int SSW_RESCORE_MAX_TILES = 2048;  // tiles of one image held in LDS (28 B each)
+constexpr int SSW_RESCORE_MAX_ZOOM = 31;     // zoom levels index a 32-bit presence mask
+ssw_status launch_avg_score(const float *boxes, const int32_t *zoom, const float *scores, const float *minus_or_null,
+                            const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
+                            int32_t max_tiles, int32_t aug, float *out_score, int64_t *out_row, hipStream_t stream);
+
 }  // namespace ssw

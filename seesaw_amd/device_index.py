@@ -159,6 +159,28 @@ class DeviceIndex:
         _lib.call("ssw_index_score_rows", self._h, _ptr(q), _ptr(rows), rows.shape[0], _ptr(out))
         return out
 
+    # -- second stage: avg_score aggregation ------------------------------------------
+    AUG_LARGER = {"all": 0, "greater": 1, "adjacent": 2}
+
+    def set_tile_meta(self, boxes: np.ndarray, zoom_level: np.ndarray):
+        """tile boxes [n_rows, 4] = x1, y1, x2, y2 (f32) and zoom levels [n_rows] of every row"""
+        b = np.ascontiguousarray(boxes, dtype=np.float32)
+        z = np.ascontiguousarray(zoom_level, dtype=np.int32)
+        assert b.shape == (self.n_rows, 4) and z.shape == (self.n_rows,)
+        _lib.call("ssw_index_set_tile_meta", self._h, _ptr(b), _ptr(z))
+
+    def rescore_avg(self, image_positions: np.ndarray, aug_larger: str, minus_scores: Optional[np.ndarray] = None):
+        """score_frame2's `avg_score` for the given candidate images over the resident tile scores:
+        -> (aggregated score of the image's best tile f32 [m], that tile's row int64 [m])"""
+        pos = np.ascontiguousarray(image_positions, dtype=np.int64)
+        m = pos.shape[0]
+        minus = None if minus_scores is None else np.ascontiguousarray(minus_scores, dtype=np.float32)
+        scores = np.empty(m, dtype=np.float32)
+        rows = np.empty(m, dtype=np.int64)
+        _lib.call("ssw_index_rescore_avg", self._h, _ptr(pos), m, self.AUG_LARGER[aug_larger], _ptr(minus),
+                  _ptr(scores), _ptr(rows))
+        return scores, rows
+
     # -- device-resident forms (bench / sharded index) --------------------------------
     def set_excluded(self, excluded: Optional[Iterable[int]]):
         ex = None

@@ -134,6 +134,10 @@ class MultiscaleIndex(AccessMethod):
         self.all_indices = FrozenBitMap(self._dbidx) - self.excluded
         self.device = device
         self._dev = DeviceIndex.from_numpy(self.vectors, row2image=self._row2pos.astype(np.int32), device=device)
+        self._has_tile_meta = "zoom_level" in self.vector_meta and int(self.vector_meta.zoom_level.max()) <= 31 \
+            and int(self.vector_meta.zoom_level.min()) >= 0 and self._box.dtype == np.float32
+        if self._has_tile_meta:  # tile geometry next to the vectors: the avg_score aggregation runs on the device
+            self._dev.set_tile_meta(self._box, self.vector_meta.zoom_level.values)
         self._resident_q = None
 
     # ---- construction -----------------------------------------------------------------
@@ -253,14 +257,32 @@ class MultiscaleIndex(AccessMethod):
             # shortlist is already in (score desc, dbidx asc) order -- the order rescore_candidates
             # would produce -- so the stage-2 gather is not needed
             return self._activations_from_best(candidate_df, topk)
+        agg_method = kwargs.get("agg_method")
+        if agg_method != "plain_score" and kwargs.get("aug_weight", "level_max") == "level_max" and self._has_tile_meta:
+            # score_frame2 takes every agg_method other than plain_score down its averaging branch
+            # (multiscale_index.py:112-150: 'avg_vector' included): ssw_index_rescore_avg over the resident scores
+            return self._rescore_avg_on_device(candidate_df, topk, kwargs["aug_larger"], vector2)
         ilocs = self._candidate_rows(candidate_df.attrs["positions"])
         scores = self._dev.gather_scores(ilocs)  # tile scores of the scan that just ran
         if vector2 is not None:
             scores = scores - self._dev.score_rows(vector2, ilocs)
         fullmeta = self.vector_meta.iloc[ilocs].assign(score=scores)
-        if kwargs.get("agg_method") == "avg_vector":
-            raise NotImplementedError("agg_method='avg_vector' is not part of the accelerated path")
         return rescore_candidates(fullmeta, topk, **kwargs)
+
+    def _rescore_avg_on_device(self, candidate_df, topk, aug_larger, vector2=None):
+        """rescore_candidates for the averaging aggregation (multiscale_index.py:379-403): frames in ascending
+        dbidx order, per frame the first tile with the highest aggregated score, then the topk frames by
+        np.argsort(-score) -- the per-frame work runs in one kernel launch instead of a pandas loop"""
+        positions = np.sort(np.asarray(candidate_df.attrs["positions"], dtype=np.int64))
+        minus = None
+        if vector2 is not None:
+            minus = self._dev.score_rows(vector2, self._candidate_rows(positions))
+        scores, rows = self._dev.rescore_avg(positions, aug_larger, minus)
+        top = np.argsort(-scores.astype(np.float64))[:topk]
+        acts = [pd.DataFrame({"x1": [self._box[r, 0]], "y1": [self._box[r, 1]], "x2": [self._box[r, 2]],
+                              "y2": [self._box[r, 3]], "dbidx": [self._row_dbidx[r]], "score": [sc]})
+                for r, sc in zip(rows[top], scores[top])]
+        return {"dbidxs": self._dbidx[positions[top]].astype("int"), "activations": acts}
 
     def new_query(self):
         return BoxFeedbackQuery(self)

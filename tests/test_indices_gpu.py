@@ -112,6 +112,91 @@ def test_multiscale_query_matches_reference(oracle):
     assert np.abs(got - g["v2_scores"]).max() <= 2 * band
 
 
+def _pyramid_index(g, oracle):
+    from seesaw_amd.indices.multiscale.multiscale_index import MultiscaleIndex
+    m = g["pyr_meta"]
+    meta = pd.DataFrame({"dbidx": m[:, 0].astype(np.int64), "zoom_level": m[:, 1].astype(np.int16),
+                         "x1": m[:, 2].astype(np.float32), "y1": m[:, 3].astype(np.float32),
+                         "x2": m[:, 4].astype(np.float32), "y2": m[:, 5].astype(np.float32)})
+    seed = int(g["pyr_seed"])
+    X = oracle.synth_rows(seed, 0, meta.shape[0], 512)
+    return MultiscaleIndex(embedding=None, vectors=X, vector_meta=meta), meta, X, oracle.synth_query(seed)
+
+
+@pytest.mark.parametrize("aug", ["all", "greater", "adjacent"])
+def test_avg_score_query_matches_reference(oracle, aug):
+    """MultiscaleIndex.query(agg_method='avg_score') = the aggregation scripts/configs/std_bench.yaml uses, on a
+    3-level tile pyramid: dbidxs and the activation boxes equal the reference's, scores to 1e-6 (the tile scores
+    under the average come from the scan kernel instead of BLAS, hence not bit-identical)."""
+    from seesaw_amd.bitmap import BitMap
+    g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
+    index, meta, X, q = _pyramid_index(g, oracle)
+    res = index.query(vector=q, topk=10, shortlist_size=50, exclude=BitMap(meta.dbidx.values[:40]), force_exact=True,
+                      agg_method="avg_score", aug_larger=aug, rescore_method=None)
+    ref = g[f"avg_{aug}_activations"]
+    assert np.array_equal(res["dbidxs"], g[f"avg_{aug}_dbidxs"])
+    acts = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64) for a in res["activations"]])
+    assert np.array_equal(acts[:, :5], ref[:, :5])
+    assert np.abs(acts[:, 5] - ref[:, 5]).max() <= 1e-6
+    assert res["activations"][0].score.dtype == np.float32
+
+
+def test_avg_score_vector2_matches_reference(oracle):
+    from seesaw_amd.bitmap import BitMap
+    g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
+    index, meta, X, q = _pyramid_index(g, oracle)
+    q2 = oracle.synth_query(int(g["pyr_seed"]) + 1)
+    res = index.query(vector=q, vector2=q2, topk=10, shortlist_size=50, exclude=BitMap(), force_exact=True,
+                      agg_method="avg_score", aug_larger="greater", rescore_method=None)
+    ref = g["avg_v2_activations"]
+    assert np.array_equal(res["dbidxs"], g["avg_v2_dbidxs"])
+    acts = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64) for a in res["activations"]])
+    assert np.array_equal(acts[:, :5], ref[:, :5])
+    assert np.abs(acts[:, 5] - ref[:, 5]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("aug", ["all", "greater", "adjacent"])
+def test_avg_score_kernel_bit_exact_vs_oracle_on_every_image(oracle, aug):
+    """ssw_index_rescore_avg over ALL images of the index against the numpy oracle fed the device's own tile
+    scores: same best tile, aggregated f32 score identical bit for bit (IoU and the Kahan mean are the
+    reference's arithmetic, op for op)."""
+    g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
+    index, meta, X, q = _pyramid_index(g, oracle)
+    tile_scores = index._dev.scores(q)                      # leaves the scores resident
+    n_images = index._dbidx.shape[0]
+    scores, rows = index._dev.rescore_avg(np.arange(n_images), aug)
+    boxes = meta[["x1", "y1", "x2", "y2"]].values.astype(np.float32)
+    zoom = meta.zoom_level.values
+    for p in range(n_images):
+        a, b = index._row_start[p], index._row_start[p + 1]
+        j, sc, _ = oracle.avg_score_image(boxes[a:b], zoom[a:b], tile_scores[a:b], aug)
+        assert rows[p] == a + j, (p, rows[p], a + j)
+        assert np.float32(sc).view(np.uint32) == scores[p:p + 1].view(np.uint32)[0], (p, sc, scores[p])
+    # the vector2 form subtracts a second score per tile before aggregating
+    minus = np.linspace(-0.01, 0.01, X.shape[0]).astype(np.float32)
+    scores2, rows2 = index._dev.rescore_avg(np.arange(n_images), aug, minus)
+    for p in (0, 17, n_images - 1):
+        a, b = index._row_start[p], index._row_start[p + 1]
+        j, sc, _ = oracle.avg_score_image(boxes[a:b], zoom[a:b], tile_scores[a:b] - minus[a:b], aug)
+        assert rows2[p] == a + j and np.float32(sc).view(np.uint32) == scores2[p:p + 1].view(np.uint32)[0]
+
+
+def test_avg_score_host_and_device_paths_agree(oracle):
+    """float64 tile boxes keep the reference's float64 IoU on the host; float32 boxes run on the device:
+    same images either way on this data"""
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.indices.multiscale.multiscale_index import MultiscaleIndex
+    g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
+    index, meta, X, q = _pyramid_index(g, oracle)
+    meta64 = meta.assign(**{c: meta[c].astype(np.float64) for c in ("x1", "y1", "x2", "y2")})
+    host = MultiscaleIndex(embedding=None, vectors=X, vector_meta=meta64)
+    assert index._has_tile_meta and not host._has_tile_meta
+    kw = dict(vector=q, topk=10, shortlist_size=50, exclude=BitMap(), force_exact=True, agg_method="avg_score",
+              aug_larger="all", rescore_method=None)
+    a, b = index.query(**kw), host.query(**kw)
+    assert np.array_equal(a["dbidxs"], b["dbidxs"])
+
+
 def test_vector_index(oracle, tmp_path):
     from seesaw_amd.vector_index import VectorIndex, build_annoy_idx
     X = oracle.synth_rows(1, 0, 5000, 512)
