@@ -133,12 +133,16 @@ class MultiscaleIndex(AccessMethod):
         self._row_start = np.concatenate(([0], np.cumsum(np.bincount(self._row2pos))))
         self.all_indices = FrozenBitMap(self._dbidx) - self.excluded
         self.device = device
-        self._dev = DeviceIndex.from_numpy(self.vectors, row2image=self._row2pos.astype(np.int32), device=device)
         self._has_tile_meta = "zoom_level" in self.vector_meta and int(self.vector_meta.zoom_level.max()) <= 31 \
             and int(self.vector_meta.zoom_level.min()) >= 0 and self._box.dtype == np.float32
+        self._resident_q = None
+        self._init_device()
+
+    def _init_device(self):
+        """the whole matrix into HBM (a sharded index overrides this with its own slice)"""
+        self._dev = DeviceIndex.from_numpy(self.vectors, row2image=self._row2pos.astype(np.int32), device=self.device)
         if self._has_tile_meta:  # tile geometry next to the vectors: the avg_score aggregation runs on the device
             self._dev.set_tile_meta(self._box, self.vector_meta.zoom_level.values)
-        self._resident_q = None
 
     # ---- construction -----------------------------------------------------------------
     @staticmethod

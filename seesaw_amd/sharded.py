@@ -62,11 +62,16 @@ def merge_keys_hip(device: int, stream_ptr: int, keys, counts, k: int, out_keys,
 class ShardedTopK:
     """Exchange + merge step shared by every sharded index.  A shard's local selection leaves its sorted
     composite keys and the pair (count, overflow) in device buffers (ssw_index_result_ptrs); one message per
-    rank -- k_max keys followed by one word holding count | overflow << 32 -- travels in a single all-gather.
-    The overflow flags of all ranks stay on the device (`flags`); `overflowed()` reads them (synchronises)."""
+    rank -- k_max keys [, k_max best-row numbers], then one word holding count | overflow << 32 -- travels in a
+    single all-gather.  The overflow flags of all ranks stay on the device (`flags`); `overflowed()` reads them
+    (synchronises).
+
+    comm_device: where the collective's tensors live.  None = `device` (backend nccl = RCCL over xGMI: the
+    production path).  "cpu" with a gloo group: the message makes a host round trip around the collective."""
 
     def __init__(self, *, rank: int, world: int, device, image_offset: int, k_max: int,
-                 group=None, merge=merge_keys_hip, force_collective: bool = False):
+                 group=None, merge=merge_keys_hip, force_collective: bool = False, with_best: bool = False,
+                 comm_device=None):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
@@ -76,44 +81,60 @@ class ShardedTopK:
         self.group = group
         self.merge = merge
         self.k_max = int(k_max)
+        self.with_best = bool(with_best)
+        self.msg_len = (2 if with_best else 1) * self.k_max + 1
         dev = device
-        self.send_buf = torch.zeros(self.k_max + 1, dtype=torch.int64, device=dev)
+        self.comm_device = torch.device(comm_device) if comm_device is not None else None
+        self.send_buf = torch.zeros(self.msg_len, dtype=torch.int64, device=dev)
         self.send_keys = self.send_buf[:self.k_max]
-        self.all_buf = torch.zeros((world, self.k_max + 1), dtype=torch.int64, device=dev)
-        self.all_keys = self.all_buf  # rows are read with stride k_max + 1
+        self.all_buf = torch.zeros((world, self.msg_len), dtype=torch.int64, device=dev)
+        self.all_keys = self.all_buf  # rows are read with stride msg_len
         self.all_counts = torch.zeros(world, dtype=torch.int32, device=dev)
         self.flags = torch.zeros(world, dtype=torch.int64, device=dev)      # overflow flag of every rank, last exchange
         self.flags_seen = torch.zeros(1, dtype=torch.int64, device=dev)    # OR over all exchanges since reset
         self.out_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def pack(self, local_keys, local_count, k: int, image_offset: Optional[int] = None):
+    def pack(self, local_keys, local_count, k: int, image_offset: Optional[int] = None, best_rows=None):
         """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys, local image positions);
-        local_count: int32 tensor [1] = count or [2] = (count, overflow).  Fills this rank's message."""
+        local_count: int32 tensor [1] = count or [2] = (count, overflow); best_rows (with_best): int64 tensor
+        [>=k], already global.  Fills this rank's message."""
         torch = self.torch
         assert 1 <= k <= self.k_max
         off = self.image_offset if image_offset is None else int(image_offset)
         # globalise: low 32 bits hold 0xFFFFFFFF - local_id, so subtracting the shard's
         # first image position yields 0xFFFFFFFF - global_id (no borrow: ids < 2^32)
         self.send_keys[:k] = local_keys[:k] - off
+        if self.with_best:
+            self.send_buf[self.k_max:self.k_max + k] = best_rows[:k]
         word = local_count[:1].to(torch.int64)
         if local_count.shape[0] > 1:
             word = word | (local_count[1:2].to(torch.int64) << 32)
-        self.send_buf[self.k_max:] = word
+        self.send_buf[self.msg_len - 1:] = word
+        return self.send_buf
+
+    def pack_empty(self):
+        """a rank without images still takes part in the collective: count 0"""
+        self.send_buf[self.msg_len - 1:] = 0
         return self.send_buf
 
     def gather(self):
         if self.world > 1 or self.force_collective:
             import torch.distributed as dist
             # flat (concatenating) form: accepted by both RCCL and gloo
-            dist.all_gather_into_tensor(self.all_buf.view(-1), self.send_buf, group=self.group)
+            if self.comm_device is None or self.comm_device == self.send_buf.device:
+                dist.all_gather_into_tensor(self.all_buf.view(-1), self.send_buf, group=self.group)
+            else:
+                out = self.torch.empty(self.world * self.msg_len, dtype=self.torch.int64, device=self.comm_device)
+                dist.all_gather_into_tensor(out, self.send_buf.to(self.comm_device), group=self.group)
+                self.all_buf.view(-1).copy_(out)
         else:
             self.all_buf[0] = self.send_buf
 
     def merge_gathered(self, k: int):
         """global top-k of the gathered messages (all_buf) on every rank -> (out_keys[k_max], out_count[1])"""
         torch = self.torch
-        words = self.all_buf[:, self.k_max]
+        words = self.all_buf[:, self.msg_len - 1]
         self.all_counts.copy_(words & 0xFFFFFFFF)
         self.flags.copy_(words >> 32)
         self.flags_seen |= self.flags.max()
@@ -123,10 +144,22 @@ class ShardedTopK:
                    self.out_count)
         return self.out_keys, self.out_count
 
-    def exchange(self, local_keys, local_count, k: int):
-        self.pack(local_keys, local_count, k)
+    def exchange(self, local_keys, local_count, k: int, best_rows=None):
+        self.pack(local_keys, local_count, k, best_rows=best_rows)
         self.gather()
         return self.merge_gathered(k)
+
+    def best_rows_of(self, merged_keys: np.ndarray) -> np.ndarray:
+        """the best-row number every rank sent along with each of the merged keys (keys are unique)"""
+        assert self.with_best
+        buf = self.all_buf.cpu().numpy()
+        counts = (buf[:, self.msg_len - 1] & 0xFFFFFFFF).astype(np.int64)
+        keys = np.concatenate([buf[r, :counts[r]] for r in range(self.world)]).view(np.uint64)
+        rows = np.concatenate([buf[r, self.k_max:self.k_max + counts[r]] for r in range(self.world)])
+        order = np.argsort(keys)
+        at = np.searchsorted(keys[order], np.asarray(merged_keys, dtype=np.uint64))
+        assert np.array_equal(keys[order][at], merged_keys)
+        return rows[order][at]
 
     def overflowed(self):
         """ranks whose last local selection overflowed its fast path (host read: synchronises).  Every rank
