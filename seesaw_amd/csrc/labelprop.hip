@@ -24,6 +24,8 @@
 // The convergence test runs on the device (block max -> u64 atomicMax of the non-negative
 // f64 bit pattern; a 1-thread check kernel flips a `done` flag that turns the remaining
 // enqueued sweeps into no-ops), so the host polls once per batch of sweeps, not per sweep.
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "ssw_common.h"
@@ -33,6 +35,8 @@ namespace {
 
 constexpr int LP_BLOCK = 256;
 constexpr int LP_CHUNK = 4096;  // products staged in LDS per pass (32 KiB)
+constexpr int64_t LP_BLOCKED_ABOVE_BYTES = 5 << 20;  // iterates larger than this take the column-blocked sweep
+constexpr int64_t LP_SLICE_BYTES = 2 << 20;  // f_old bytes one pass of the column-blocked sweep gathers from (L2 = 4 MiB per XCD)
 
 struct LpState {           // device-resident control block
     unsigned long long maxdiff_bits;  // max (f_new - f_old)^2 of the current sweep
@@ -100,6 +104,110 @@ __global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep(
         d2 = __dmul_rn(d, d);
     }
     // block max of d2 (non-negative or NaN; NaN compares false and is caught by the bounds)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off, 64));
+    if ((t & 63) == 0) red[t >> 6] = d2;
+    __syncthreads();
+    if (t == 0) {
+        double m = red[0];
+        for (int i = 1; i < LP_BLOCK / 64; ++i) m = fmax(m, red[i]);
+        atomicMax(&st->maxdiff_bits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// Column-blocked form of the sweep for graphs whose iterate does not fit an XCD's L2 (4 MiB).
+//
+// Measured on the 1.56 M-node graph (profiles/r02_labelprop_pmc.csv): the plain sweep's 21.8 M gathers of f_old hit
+// L2 27 % of the time (the 12.5 MB iterate against 4 MiB of L2) and the other 18 M leave as fabric requests
+// (TCC_EA0_RDREQ), one line per 8 useful bytes: the sweep is bound by random lines from the Infinity Cache, not by
+// its 300 MB of streams.  Here the columns are cut into slices of <= LP_SLICE_BYTES of f_old and the non-zeros are
+// stored slice-major (slice, row, column): while a slice is being worked on, the gathers come from f_old[slice],
+// which stays in every XCD's L2 after the first touch (hit rate 85 %, fabric requests / 4.8).  Since columns ascend
+// within a row, "slice 0's terms, then slice 1's, ..." IS scipy's left-to-right order: the result is bit-identical
+// to the unblocked kernel and to the CPU.  The streams use non-temporal loads so they do not evict the slice.
+//
+// ONE launch per sweep: a workgroup owns LP_GROUPS x 256 consecutive rows for the whole sweep and walks the slices
+// in order, thread t keeping the running sums of its LP_GROUPS rows (t, t + 256, ...) in registers.  LP_GROUPS is
+// chosen so that the whole grid is resident at once (<= 4 workgroups per CU): all workgroups do the same amount
+// of work per slice, so the grid moves through the slices together and the slice being gathered from is the one
+// in L2.  Measured alternatives at 1.56 M nodes (plain sweep 0.310 ms): this kernel 0.165 ms; one launch per
+// slice with the running sums carried through HBM 0.21 ms; 4 / 8 / 12 row groups per workgroup 0.21 / 0.17 / 0.21 ms;
+// a three-deep software pipeline of the stages (next stage's non-zeros and row offsets in flight during the
+// gather, counted waits verified in the ISA) 0.20-0.22 ms -- SLOWER: the gathers already run at about half of the
+// L2's line rate (21.8 M lines of 128 B in 165 us = 17 TB/s of its 34.5), more loads in flight only add pressure.
+template <int LP_GROUPS, int FCHUNK>
+__global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep_fused(
+    int64_t n, int nblk, const uint32_t *__restrict__ bptr /* [nblk][n+1] */, const int64_t *__restrict__ base,
+    const int32_t *__restrict__ indices, const double *__restrict__ data, const double *__restrict__ wsum,
+    const double *__restrict__ prior, const double *__restrict__ f_old, double *__restrict__ f_new,
+    const unsigned char *__restrict__ is_label, const double *__restrict__ label_val, double lambda,
+    double low_bound, double high_bound, LpState *__restrict__ st) {
+    __shared__ double prod[FCHUNK];
+    __shared__ double red[LP_BLOCK / 64];
+    if (st->done) return;
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * (LP_GROUPS * LP_BLOCK);
+    double sum[LP_GROUPS];
+#pragma unroll
+    for (int g = 0; g < LP_GROUPS; ++g) sum[g] = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const uint32_t *bp = bptr + (size_t)b * (size_t)(n + 1);
+        const int32_t *ind = indices + base[b];
+        const double *dat = data + base[b];
+#pragma unroll
+        for (int g = 0; g < LP_GROUPS; ++g) {
+            const int64_t row0 = r0 + (int64_t)g * LP_BLOCK;
+            if (row0 >= n) continue;  // uniform across the workgroup
+            const int64_t row = row0 + t;
+            const int64_t rend = min(row0 + LP_BLOCK, n);
+            const int64_t p_begin = bp[row0], p_end = bp[rend];
+            int64_t my_lo = 0, my_hi = 0;
+            if (row < n) {
+                my_lo = __builtin_nontemporal_load(&bp[row]);
+                my_hi = __builtin_nontemporal_load(&bp[row + 1]);
+            }
+            double acc = sum[g];
+            for (int64_t cb = p_begin; cb < p_end; cb += FCHUNK) {
+                const int64_t lim = min(cb + FCHUNK, p_end);
+                for (int64_t p = cb + t; p < lim; p += 4 * LP_BLOCK) {
+                    int32_t col[4];
+                    double w[4], f[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t q = p + (int64_t)u * LP_BLOCK;
+                        col[u] = q < lim ? __builtin_nontemporal_load(&ind[q]) : -1;
+                        w[u] = q < lim ? __builtin_nontemporal_load(&dat[q]) : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) f[u] = col[u] >= 0 ? f_old[col[u]] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t q = p + (int64_t)u * LP_BLOCK;
+                        if (q < lim) prod[q - cb] = __dmul_rn(w[u], f[u]);
+                    }
+                }
+                __syncthreads();
+                const int64_t lo = max(my_lo, cb), hi = min(my_hi, lim);
+                for (int64_t p = lo; p < hi; ++p) acc = __dadd_rn(acc, prod[p - cb]);
+                __syncthreads();
+            }
+            sum[g] = acc;
+        }
+    }
+    double d2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < LP_GROUPS; ++g) {
+        const int64_t row = r0 + (int64_t)g * LP_BLOCK + t;
+        if (row < n) {
+            const double weighted = __dadd_rn(sum[g], __dmul_rn(lambda, prior[row]));
+            double v = weighted / __dadd_rn(wsum[row], lambda);
+            if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
+            if (is_label[row]) v = label_val[row];
+            f_new[row] = v;
+            const double d = __dadd_rn(v, -f_old[row]);
+            d2 = fmax(d2, __dmul_rn(d, d));
+        }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off, 64));
     if ((t & 63) == 0) red[t >> 6] = d2;
@@ -252,6 +360,14 @@ struct ssw_lp {
     int last_result = -1;
     LpState *state = nullptr;
     hipStream_t stream = nullptr;
+    // column-blocked copy of the matrix (nblk > 1 only): slice-major non-zeros, per-slice row offsets
+    int nblk = 1;
+    uint32_t *bl_ptr = nullptr;      // [nblk][n + 1]
+    int32_t *bl_indices = nullptr;   // [nnz] sorted by (slice, row, column)
+    double *bl_data = nullptr;       // [nnz]
+    std::vector<int64_t> bl_base;    // [nblk + 1] first non-zero of every slice
+    int64_t *bl_base_dev = nullptr;  // device copy
+    int groups = 6;                  // row groups of 256 per workgroup of k_lp_sweep_fused (grid just resident)
 };
 
 extern "C" {
@@ -272,6 +388,10 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
     (void)hipFree(lp->ids);
     (void)hipFree(lp->vals);
     (void)hipFree(lp->state);
+    (void)hipFree(lp->bl_ptr);
+    (void)hipFree(lp->bl_indices);
+    (void)hipFree(lp->bl_data);
+    (void)hipFree(lp->bl_base_dev);
     if (lp->stream) (void)hipStreamDestroy(lp->stream);
     delete lp;
     return SSW_OK;
@@ -339,8 +459,91 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
         set_error("labelprop: graph upload failed");
         return bail(SSW_ERR_HIP);
     }
+    // column-blocked copy when the iterate (8 B per node) exceeds what stays resident in one XCD's L2
+    int64_t slice_bytes = LP_SLICE_BYTES;
+    if (const char *e = getenv("SSW_LP_SLICE_KB")) slice_bytes = std::max<int64_t>(1, atoll(e)) * 1024;  // tuning / A-B runs / tests
+    const int64_t cols_per_slice = std::max<int64_t>(1, slice_bytes / (int64_t)sizeof(double));
+    int64_t nblk = (n + cols_per_slice - 1) / cols_per_slice;
+    // an iterate that (nearly) fits L2 is better served by the plain kernel (measured: 400 k nodes = 3.2 MB plain
+    // 50 us vs blocked 58 us; 800 k = 6.4 MB 120 vs 112 us; 1.56 M = 12.5 MB 305 vs 161 us; 3 M 693 vs 387 us)
+    if (!getenv("SSW_LP_SLICE_KB") && n * (int64_t)sizeof(double) <= LP_BLOCKED_ABOVE_BYTES) nblk = 1;
+    if (nblk > 1 && nblk <= 4096 && nnz < (int64_t)0xffffffffll) {
+        std::vector<uint32_t> bptr((size_t)nblk * (size_t)(n + 1), 0u);
+        std::vector<int64_t> base((size_t)nblk + 1, 0);
+        // per (slice, row) counts -> offsets inside the slice
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t p = indptr_host[i]; p < indptr_host[i + 1]; ++p)
+                bptr[(size_t)(indices_host[p] / cols_per_slice) * (size_t)(n + 1) + (size_t)i + 1]++;
+        for (int64_t b = 0; b < nblk; ++b) {
+            uint32_t *row = bptr.data() + (size_t)b * (size_t)(n + 1);
+            for (int64_t i = 0; i < n; ++i) row[i + 1] += row[i];
+            base[(size_t)b + 1] = base[(size_t)b] + row[n];
+        }
+        std::vector<int32_t> bind((size_t)nnz);
+        std::vector<double> bdat((size_t)nnz);
+        std::vector<uint32_t> fill((size_t)nblk, 0u);
+        for (int64_t i = 0; i < n; ++i) {
+            for (int64_t b = 0; b < nblk; ++b) fill[(size_t)b] = bptr[(size_t)b * (size_t)(n + 1) + (size_t)i];
+            for (int64_t p = indptr_host[i]; p < indptr_host[i + 1]; ++p) {  // columns ascend: order inside a slice kept
+                const int64_t b = indices_host[p] / cols_per_slice;
+                const size_t at = (size_t)base[(size_t)b] + fill[(size_t)b]++;
+                bind[at] = indices_host[p];
+                bdat[at] = data_host[p];
+            }
+        }
+        if (hipMalloc((void **)&lp->bl_ptr, bptr.size() * sizeof(uint32_t) + 16) != hipSuccess ||
+            hipMalloc((void **)&lp->bl_indices, (size_t)nnz * sizeof(int32_t) + 16) != hipSuccess ||
+            hipMalloc((void **)&lp->bl_data, (size_t)nnz * sizeof(double) + 16) != hipSuccess ||
+            hipMemcpy(lp->bl_ptr, bptr.data(), bptr.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(lp->bl_indices, bind.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(lp->bl_data, bdat.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("labelprop: column-blocked copy of the graph failed");
+            return bail(SSW_ERR_NOMEM);
+        }
+        if (hipMalloc((void **)&lp->bl_base_dev, base.size() * sizeof(int64_t)) != hipSuccess ||
+            hipMemcpy(lp->bl_base_dev, base.data(), base.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("labelprop: column-blocked copy of the graph failed");
+            return bail(SSW_ERR_NOMEM);
+        }
+        lp->nblk = (int)nblk;
+        lp->bl_base = std::move(base);
+        // smallest row-group count whose grid is resident all at once: 4 workgroups of 32 KiB LDS per CU
+        const int64_t resident = (int64_t)num_cus(device) * 4;
+        lp->groups = 16;
+        for (int g : {2, 3, 4, 6, 8, 12, 16})
+            if ((n + (int64_t)g * LP_BLOCK - 1) / ((int64_t)g * LP_BLOCK) <= resident) {
+                lp->groups = g;
+                break;
+            }
+    }
     *out = lp;
     return SSW_OK;
+}
+
+// one sweep f[src] -> f[src ^ 1]: the plain kernel, or the column-blocked one (same result, bit for bit)
+static void lp_launch_sweep(ssw_lp *lp, int src, double reg_lambda, double lo, double hi) {
+    const int64_t n = lp->n;
+    hipStream_t s = lp->stream;
+    if (lp->nblk <= 1) {
+        const unsigned grid = (unsigned)((n + LP_BLOCK - 1) / LP_BLOCK);
+        hipLaunchKernelGGL(k_lp_sweep, dim3(grid), dim3(LP_BLOCK), 0, s, n, lp->indptr, lp->indices, lp->data, lp->wsum,
+                           lp->prior, lp->f[src], lp->f[src ^ 1], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state);
+        return;
+    }
+#define LP_FUSED(G)                                                                                                        \
+    hipLaunchKernelGGL((k_lp_sweep_fused<G, LP_CHUNK>), dim3((unsigned)((n + (int64_t)(G) * LP_BLOCK - 1) / ((int64_t)(G) * LP_BLOCK))), \
+                       dim3(LP_BLOCK), 0, s, n, lp->nblk, lp->bl_ptr, lp->bl_base_dev, lp->bl_indices, lp->bl_data, lp->wsum,       \
+                       lp->prior, lp->f[src], lp->f[src ^ 1], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state)
+    switch (lp->groups) {
+        case 2: LP_FUSED(2); break;
+        case 3: LP_FUSED(3); break;
+        case 4: LP_FUSED(4); break;
+        case 6: LP_FUSED(6); break;
+        case 8: LP_FUSED(8); break;
+        case 12: LP_FUSED(12); break;
+        default: LP_FUSED(16); break;
+    }
+#undef LP_FUSED
 }
 
 // Shared body of ssw_labelprop_run / ssw_labelprop_run_resident.  prior: uploaded from
@@ -410,7 +613,6 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
     }
     SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
     // the host buffers above must be consumed before this call returns: we synchronise below
-    const unsigned grid = (unsigned)((n + LP_BLOCK - 1) / LP_BLOCK);
     LpState st;
     memset(&st, 0, sizeof(st));
     int issued = 0;
@@ -419,9 +621,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
         const int upto = (issued + batch < max_iter) ? issued + batch : max_iter;
         for (; issued < upto; ++issued) {
             const int src = issued & 1;
-            hipLaunchKernelGGL(k_lp_sweep, dim3(grid), dim3(LP_BLOCK), 0, s, n, lp->indptr, lp->indices,
-                               lp->data, lp->wsum, lp->prior, lp->f[src], lp->f[src ^ 1], lp->is_label,
-                               lp->label_val, reg_lambda, lo, hi, lp->state);
+            lp_launch_sweep(lp, src, reg_lambda, lo, hi);
             hipLaunchKernelGGL(k_lp_check, dim3(1), dim3(1), 0, s, lp->state, eps, src);
         }
         SSW_HIP_TRY(hipGetLastError());

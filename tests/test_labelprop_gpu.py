@@ -141,3 +141,55 @@ def test_resident_chaining_equals_host_round_trip(oracle):
     assert np.array_equal(rows, order) and np.array_equal(scores, s32[order])
     dev.close()
     lp.close()
+
+
+@pytest.fixture
+def tiny_slices(monkeypatch):
+    """ssw_labelprop_create reads SSW_LP_SLICE_KB: 2 KB of f_old per column slice = 256 columns, so even the
+    1500-node golden graph runs through the column-blocked sweep (6 passes per sweep)"""
+    monkeypatch.setenv("SSW_LP_SLICE_KB", "2")
+
+
+def test_column_blocked_sweep_bit_exact_vs_reference_golden(tiny_slices):
+    """the multi-pass (column-sliced, carried running sum) form of the sweep: same f64 bits and the same sweep
+    counts as the reference on all nine golden runs"""
+    test_fit_transform_bit_exact_vs_reference_golden()
+    test_ranker_matches_reference_golden()
+
+
+@pytest.mark.parametrize("slice_kb", ["1", "8", "64"])
+def test_column_blocked_equals_plain_sweep_on_a_large_graph(monkeypatch, oracle, slice_kb):
+    """150 k nodes with a hub row and an empty row: blocked (various slice widths, up to 1172 slices) == plain, bit
+    for bit, over 25 sweeps; spot rows against the CPU oracle"""
+    from seesaw_amd.label_propagation import LabelPropagation
+    n, deg = 150_000, 9
+    rng = np.random.default_rng(3)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, n * deg)
+    vals = rng.uniform(0.05, 1.0, n * deg)
+    hub = rng.integers(0, n, 9000)
+    keep = rows != 7
+    rows = np.concatenate([rows[keep], np.full(9000, 5)])
+    cols = np.concatenate([cols[keep], hub])
+    vals = np.concatenate([vals[keep], rng.uniform(0.05, 1.0, 9000)])
+    A = sp.coo_array((vals, (rows, cols)), shape=(n, n)).tocsr()
+    W = (A + A.T).tocsr()
+    W.sort_indices()
+    prior = rng.uniform(0, 1, n)
+    ids = rng.choice(n, 300, replace=False).astype(np.int64)
+    lab = (rng.uniform(size=300) > 0.5).astype(np.float64)
+    kw = dict(label_ids=ids, label_values=lab, reg_values=prior, start_value=prior)
+    monkeypatch.delenv("SSW_LP_SLICE_KB", raising=False)
+    plain = LabelPropagation(W, reg_lambda=1.0, max_iter=25, epsilon=-1.0)
+    want = plain.fit_transform(**kw)
+    plain.close()
+    monkeypatch.setenv("SSW_LP_SLICE_KB", slice_kb)
+    blocked = LabelPropagation(W, reg_lambda=1.0, max_iter=25, epsilon=-1.0)
+    got = blocked.fit_transform(**kw)
+    assert blocked.last_sweeps == 25
+    blocked.close()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    ref = oracle.label_propagation(W, label_ids=ids, label_values=lab, reg_lambda=1.0, reg_values=prior,
+                                   start_value=prior, max_iter=25, epsilon=-1.0)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.array_equal(np.asarray(ref).view(np.uint64), got.view(np.uint64))
