@@ -51,6 +51,20 @@ def cpu_baseline(local_index, k, sample_rows, n_queries):
     for q in qs:
         orc.topk_images_reference(X, q, row_dbidx, None, k)
     dt = time.perf_counter() - t0
+
+    def argpartition_topk(q):
+        """the fairer CPU variant of SURVEY section 8d: no full sort -- np.argpartition for the k best, then an
+        ordering of those k (one vector per image here, so the k best rows are the k best images)"""
+        scores = X @ q
+        part = np.argpartition(-scores, k)[:k]
+        return part[np.argsort(-scores[part], kind="stable")]
+
+    ref_ids = orc.topk_images_reference(X, qs[0], row_dbidx, None, k)[0]
+    assert np.array_equal(np.sort(argpartition_topk(qs[0])), np.sort(np.asarray(ref_ids))), "argpartition variant disagrees"
+    t0 = time.perf_counter()
+    for q in qs:
+        argpartition_topk(q)
+    dt_part = time.perf_counter() - t0
     return {
         "value": n * n_queries / dt,
         "unit": "vectors/s",
@@ -60,7 +74,63 @@ def cpu_baseline(local_index, k, sample_rows, n_queries):
                   f"X@q + np.argsort(-scores) + distinct-image top-{k}, numpy {np.__version__}, "
                   f"os.cpu_count()={os.cpu_count()}",
         "seconds": dt,
+        "argpartition_variant": {"value": n * n_queries / dt_part, "unit": "vectors/s", "seconds": dt_part,
+                                 "what": f"X@q + np.argpartition(-scores, {k}) + sort of the {k} kept: same rows, same queries"},
     }
+
+
+class PhaseTimers:
+    """Per-phase wall time of a feedback loop: the product's entry points are wrapped for the
+    duration of one session -- index top-k (scan kernel by HIP events + selection/fetch), label propagation, the
+    L-BFGS fit -- and what is left of the iteration latency is host code (session bookkeeping, pandas records)."""
+
+    def __init__(self):
+        self.t = {"topk_call": 0.0, "label_prop": 0.0, "fit": 0.0}
+        self._saved = []
+
+    def _wrap(self, cls, name, key):
+        orig = getattr(cls, name)
+        timers = self.t
+
+        def timed(obj, *a, **k):
+            t0 = time.perf_counter()
+            try:
+                return orig(obj, *a, **k)
+            finally:
+                timers[key] += time.perf_counter() - t0
+
+        self._saved.append((cls, name, orig))
+        setattr(cls, name, timed)
+
+    def __enter__(self):
+        from seesaw_amd.device_index import DeviceIndex
+        from seesaw_amd.label_propagation import LabelPropagation
+        from seesaw_amd.logistic_regression import LogisticRegressionPT
+        from seesaw_amd.loops.multi_reg import RegModule
+        self._wrap(DeviceIndex, "topk", "topk_call")
+        for m in ("fit_transform", "fit_resident", "scores_to_index", "fetch"):
+            self._wrap(LabelPropagation, m, "label_prop")
+        self._wrap(RegModule, "fit", "fit")
+        self._wrap(LogisticRegressionPT, "fit", "fit")
+        return self
+
+    def __exit__(self, *exc):
+        for cls, name, orig in self._saved:
+            setattr(cls, name, orig)
+        self._saved = []
+
+    def per_iteration_ms(self, dev_index, latencies):
+        n = max(1, len(latencies))
+        scan = dev_index.profile_read()
+        total = 1e3 * float(sum(latencies)) / n
+        scan_ms = float(scan.sum()) / n if len(scan) else 0.0
+        topk = 1e3 * self.t["topk_call"] / n
+        lp, fit = 1e3 * self.t["label_prop"] / n, 1e3 * self.t["fit"] / n
+        return {"iteration": total, "scan_kernel": scan_ms, "select_and_fetch": max(0.0, topk - scan_ms),
+                "label_prop": lp, "fit": fit, "host_other": max(0.0, total - topk - lp - fit),
+                "note": "ms per iteration of the reported session; scan_kernel by HIP events around the scan launches, the "
+                        "other phases by host wall time around the C-ABI calls (they synchronise); the timed session is a "
+                        "third one, run after the reported one (the wrappers cost ~1 us per call)"}
 
 
 def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
@@ -91,7 +161,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                                                  sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4,
                                                  prior_weight=1.0)),
     }
-    cpu_legs = ("plain", "multi_reg", "knn_prop2")  # loops oracle/cpu_loop.py restates
+    cpu_legs = ("plain", "multi_reg", "knn_prop2", "pseudo_lr")  # loops oracle/cpu_loop.py restates
     out = {}
     import contextlib
     import io
@@ -125,12 +195,21 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
                              "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])), "iters": len(g["latencies"]),
                              "hip_nfound": g["nfound"]}
+                if with_cpu:  # per-phase ms (rank 0 at N = 1 only)
+                    ret = make_session(gdm, p, b=b)
+                    dev = ds.load_index()._dev
+                    dev.profile(True)
+                    np.random.seed(0)
+                    with PhaseTimers() as ph:
+                        gp = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+                    res[name]["phases_ms"] = ph.per_iteration_ms(dev, gp["latencies"])
+                    dev.profile(False)
                 if not with_cpu or name not in cpu_legs:
                     continue
                 from oracle import cpu_loop  # the CPU leg: the reference's expressions on the host cores
                 qvec = ds.load_index().string2vec("a c1")
                 # bounded CPU sample: scipy label propagation over 1.56 M nodes takes seconds per round
-                cpu_rounds = 4 if (full and name == "knn_prop2") else 30
+                cpu_rounds = 4 if (full and name in ("knn_prop2", "pseudo_lr")) else 30
                 c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=cpu_rounds,
                                          max_results=10 ** 6, knn_df=ds.knn_graph().restrict_k(k=10).knn_df if knn_k else None)
             res[name].update({"cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])),
@@ -250,6 +329,37 @@ def c2_extras(device: int):
     return out
 
 
+SCAN_KERNEL = "scan_scores_kernel<2,2,nt>"          # what launch_scan runs by default (scan.hip)
+SCAN_SOURCES = ("seesaw_amd/csrc/scan.hip",)
+
+
+def scan_source_sha256() -> str:
+    """identity of the scan kernel's source: profiles/traffic.json is only valid for the tree it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in SCAN_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(rows_per_launch: int):
+    """HBM bytes per scan launch from the PMC pass committed under profiles/ (rocprofv3 cannot run inside the bench):
+    used only when the record was taken on THIS kernel source, variant and launch shape; otherwise null + the reason"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+    except Exception as e:
+        return None, f"no usable profiles/traffic.json ({type(e).__name__})"
+    if tj.get("kernel") != SCAN_KERNEL:
+        return None, f"traffic.json is for kernel {tj.get('kernel')!r}, the bench ran {SCAN_KERNEL!r}"
+    if int(tj.get("rows_per_launch", -1)) != int(rows_per_launch):
+        return None, f"traffic.json was measured at {tj.get('rows_per_launch')} rows per launch, this run has {rows_per_launch}"
+    if tj.get("kernel_source_sha256") != scan_source_sha256():
+        return None, "the scan kernel's source changed since profiles/traffic.json was measured (re-run tools/collect_profiles.sh)"
+    return tj.get("hbm_bytes_per_launch"), f"PMC pass of git {tj.get('git_head', '?')[:12]}, same kernel source (sha256 match)"
+
+
 def aggregate_replicas(replicas, world: int):
     """N > 1: sum of the per-GPU feedback-loop rates (every rank ran its own replica of the sessions)."""
     agg = {}
@@ -364,15 +474,7 @@ def main():
         n_local = index.n_local
         avg_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
         achieved = n_local * ROW_BYTES / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if int(tj.get("rows_per_launch", -1)) == n_local:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_note = measured_traffic(n_local)
         out = {
             "metric": "vectors scanned/sec (100M×512 top-k)",
             "value": n_total * args.steps / elapsed,
@@ -398,7 +500,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "scan_scores_kernel<2,2,nt>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                 "avg_launch_ms": avg_ms, "launches": int(len(scan_ms)),
                 "algorithmic_bytes_per_launch": n_local * ROW_BYTES,
             },

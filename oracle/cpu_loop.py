@@ -30,8 +30,11 @@ def _rbf_weight_matrix(knn_df, edist):
 
 
 def run_session(vectors, vector_meta, box_data, category, qvec, *, loop="multi_reg", n_batches=30, shortlist=50,
-                max_results=None, knn_df=None, edist=0.05, reg_norm_lambda=100.0, max_iter=200):
-    """Returns dict(nfound, nseen, latencies, shown).  loop in {plain, multi_reg, knn_prop2}."""
+                max_results=None, knn_df=None, edist=0.05, reg_norm_lambda=100.0, max_iter=200, sample_size=10000):
+    """Returns dict(nfound, nseen, latencies, shown).  loop in {plain, multi_reg, knn_prop2, pseudo_lr}.
+    pseudo_lr (loops/pseudo_lr.py:10-54): label propagation, then an (unregularised: LoopState.tvec is never set)
+    logistic fit on the real labels plus `sample_size` pseudo-labelled vectors drawn with np.random.permutation;
+    the graph ranks the batches until both classes have a real label (switch_over)."""
     row_dbidx = vector_meta.dbidx.values.astype(np.int64)
     boxes = box_data[box_data.category == category]
     positives = set(boxes.dbidx.tolist())
@@ -43,7 +46,8 @@ def run_session(vectors, vector_meta, box_data, category, qvec, *, loop="multi_r
     q0 = curr.copy()
     lp_scores = None
     W = None
-    if loop == "knn_prop2":
+    graph = loop in ("knn_prop2", "pseudo_lr")
+    if graph:
         W = _rbf_weight_matrix(knn_df, edist)
         from scipy.special import expit
         prior = expit(10.0 * ((vectors @ q0).astype(np.float64) - 0.4))
@@ -55,7 +59,8 @@ def run_session(vectors, vector_meta, box_data, category, qvec, *, loop="multi_r
     for it in range(1, n_batches + 1):
         t0 = time.time()
         # ---- next(): scan + full sort + distinct non-returned images, best tile per image
-        if loop == "knn_prop2" and started:
+        both = bool(labelled_y) and (np.asarray(labelled_y) > 0).any() and (np.asarray(labelled_y) == 0).any()
+        if (loop == "knn_prop2" and started) or (loop == "pseudo_lr" and started and not both):
             s = np.where(is_labeled, -np.inf, lp_scores)
             order = np.argsort(-s)
             d, sc, rows = orc.get_top_dbidxs(vec_idxs=order, scores=s[order], row_dbidx=row_dbidx, exclude=returned,
@@ -92,12 +97,22 @@ def run_session(vectors, vector_meta, box_data, category, qvec, *, loop="multi_r
                                        loss_type="ce_loss", l_norm=reg_norm_lambda, l_data=0.0, l_query=0.0,
                                        max_iter=max_iter)
             curr = coeff
-        elif loop == "knn_prop2":
+        elif graph:
             is_labeled[rows_a] = True
             labels[rows_a] = y_a
             if (y_a == 0).any():
                 ids = np.nonzero(is_labeled)[0]
                 lp_scores, _, _ = orc.label_propagation(W, label_ids=ids, label_values=labels[ids], reg_lambda=1.0,
                                                         reg_values=prior, start_value=prior)
+            if loop == "pseudo_lr":  # makeXy (loops/util.py:4-23) + LogisticRegressionPT.fit (class_weights 1.0)
+                import torch
+                unl = np.nonzero(~is_labeled)[0]
+                pick = unl[np.random.permutation(unl.shape[0])[:sample_size]]
+                Xs = np.concatenate((vectors[is_labeled], vectors[pick]))
+                ys = np.concatenate((labels[is_labeled], lp_scores[pick]))
+                w0 = torch.nn.Linear(vectors.shape[1], 1, bias=False).weight.detach().numpy().reshape(-1)
+                coeff, _ = fo.logreg_fit(Xs, ys, None, w0=w0, reg_lambda=1.0, class_weights=1.0,
+                                         sample_weights=np.ones(ys.shape[0]), max_iter=max_iter, reg_kind=None)
+                curr = coeff
         latencies.append(time.time() - t0)
     return dict(nfound=nfound, nseen=len(shown), latencies=latencies, shown=shown)

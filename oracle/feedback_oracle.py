@@ -52,7 +52,7 @@ def logreg_loss(w, b, Xc, y, sample_weight, pos_weight, reg_weight, qhat, reg_ki
 
 
 def logreg_fit(X, y, q, *, w0, reg_lambda, class_weights="balanced", sample_weights=None, max_iter=200, lr=1.0,
-               fit_intercept=False):
+               fit_intercept=False, reg_kind="vector"):
     """LogisticRegressionPT.fit -> get_coeff(), with the start weights given explicitly."""
     X = np.asarray(X, dtype=np.float32)
     mu = X.astype(np.float64).mean(axis=0).astype(np.float32)  # StandardScaler(with_std=False)
@@ -62,7 +62,7 @@ def logreg_fit(X, y, q, *, w0, reg_lambda, class_weights="balanced", sample_weig
         pos_weight = max(int((y == 0).sum()), 1) / max(int((y == 1).sum()), 1)
     else:
         pos_weight = float(class_weights)
-    qhat = F.normalize(torch.from_numpy(np.asarray(q, dtype=np.float32)).reshape(1, -1), dim=-1).reshape(-1)
+    qhat = None if q is None else F.normalize(torch.from_numpy(np.asarray(q, dtype=np.float32)).reshape(1, -1), dim=-1).reshape(-1)
     sw = None if sample_weights is None else torch.from_numpy(np.asarray(sample_weights, dtype=np.float64).reshape(-1, 1))
     w = torch.tensor(np.asarray(w0, dtype=np.float32)[: X.shape[1]].reshape(-1), requires_grad=True)
     params = [w]
@@ -75,7 +75,7 @@ def logreg_fit(X, y, q, *, w0, reg_lambda, class_weights="balanced", sample_weig
 
     def closure():
         opt.zero_grad()
-        loss = logreg_loss(w, b, Xc, yt, sw, pos_weight, reg_weight, qhat)
+        loss = logreg_loss(w, b, Xc, yt, sw, pos_weight, reg_weight, qhat, reg_kind=reg_kind)
         loss.backward()
         return loss
 

@@ -2,7 +2,7 @@
 # Regenerates the files under profiles/ on an MI355X box (run from the repo root; see profiles/README.md).
 # PMC passes run on their own, never together with a trace domain; the program follows `--` directly.
 set -eo pipefail
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/collect
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
@@ -23,8 +23,15 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn -- \
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
+python3 tools/make_traffic_json.py "$OUT" 100000000 > "$OUT/traffic.log" 2>&1   # -> profiles/traffic.json (stamp git locally)
+python3 tools/summarise_pmc.py "$OUT/bench_fetch" scan_scores > "$OUT/fetch_summary.csv"
+python3 tools/summarise_pmc.py "$OUT/bench_write" scan_scores > "$OUT/write_summary.csv"
+( echo "# mean per launch of scan_scores_kernel, rocprofv3 --pmc (two passes), bench.py --steps 3 --warmup 1"; cat "$OUT/fetch_summary.csv"; grep WRITE_SIZE "$OUT/write_summary.csv" ) > "profiles/${R}_bench_100M_pmc_fetch_write.csv"
+python3 tools/summarise_pmc.py "$OUT/clip_pmc" "" > "profiles/${R}_clip_b200_pmc_summary.csv"
+mkdir -p gpurun_out/traffic && cp profiles/traffic.json gpurun_out/traffic/traffic.json   # profiles/ is not merged back: copy out
 cp "$OUT/bench.json" "profiles/${R}_bench_100M_output.json"
 cp "$OUT/bench_trace/bench_kernel_stats.csv" "profiles/${R}_bench_100M_kernel_stats.csv"
 cp "$OUT/clip_trace/clip_kernel_stats.csv" "profiles/${R}_clip_b200_kernel_stats.csv"
 cp "$OUT/knn_trace/knn_kernel_stats.csv" "profiles/${R}_knn_1560k_kernel_stats.csv"
-echo "raw PMC collections are under $OUT (bench_fetch, bench_write, clip_pmc): summarise as profiles/README.md describes"
+for f in profiles/${R}_*; do cp "$f" "gpurun_out/collect/$(basename "$f")"; done   # the box's profiles/ does not travel back
+echo "summaries copied to gpurun_out/collect/: move them to profiles/ and run tools/make_traffic_json.py --stamp-git"
