@@ -244,12 +244,13 @@ ssw_status ssw_xlx(ssw_index *index, ssw_lp *laplacian, double *out_host);
 /* ------------------------------------------------------------------------- */
 typedef struct ssw_fb ssw_fb;
 
-enum { SSW_FB_LOGREG = 0, SSW_FB_MULTIREG = 1 };
+enum { SSW_FB_LOGREG = 0, SSW_FB_MULTIREG = 1, SSW_FB_RANKREG = 2 };
 enum { SSW_FB_LOSS_CE = 0, SSW_FB_LOSS_PAIRWISE_HINGE = 1, SSW_FB_LOSS_PAIRWISE_LOGISTIC = 2 };
 enum { SSW_FB_REG_NONE = 0, SSW_FB_REG_VECTOR = 1, SSW_FB_REG_NORM = 2, SSW_FB_REG_NORM1 = 3 };
 
 typedef struct ssw_fb_objective {
-    int32_t kind;          /* SSW_FB_LOGREG | SSW_FB_MULTIREG                                  */
+    int32_t kind;          /* SSW_FB_LOGREG | SSW_FB_MULTIREG | SSW_FB_RANKREG (RankRegressionPT:  */
+                           /* cheap pairwise rank loss + reg_kind / reg_weight as LOGREG)      */
     int32_t loss_type;     /* MULTIREG: label_loss_type (multi_reg.py:34-35)                   */
     int32_t fit_intercept; /* LOGREG: extra bias parameter after the dim weights               */
     int32_t reg_kind;      /* LOGREG: regulariser (logistic_regression.py:304-330)             */
@@ -297,6 +298,17 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
 ssw_status ssw_rank_pairwise(int32_t device, int32_t logistic, const float *target_host, const float *scores_host,
                              const float *coef_host_or_null, int32_t n, float margin, double *out_item_loss,
                              float *out_grad);
+
+/* The sort-based rank functions as counting kernels (exact integers, ties as the reference's stable sorts):
+ * quick_pairwise_gradient_zero_margin(target, scores, return_max_inversions=True) -> gradient [n] (= 2 x net
+ * position change between the (target, score) order and the (score, -target) order), max_reversals [n],
+ * total_pairs; seesaw/rank_loss.py:109-161.  _CheapPairwiseRankingLoss (:164-187) is |gradient| / total_pairs. */
+ssw_status ssw_rank_quick_gradient(int32_t device, const float *target_host, const float *scores_host, int32_t n,
+                                   float *out_grad, float *out_max_reversals_or_null, int64_t *out_total_pairs_or_null);
+/* compute_inversions(labs, scores), seesaw/pairwise_rank_loss.py:24-43: in descending score order (ties by index) a
+ * positive counts the negatives before it, a negative the positives after it. */
+ssw_status ssw_rank_inversions(int32_t device, const uint8_t *labels_host, const float *scores_host, int32_t n,
+                               int64_t *out_inversions);
 
 /* ------------------------------------------------------------------------- */
 /* CLIP ViT-B/32 image / text towers (bf16 MFMA forward)                       */

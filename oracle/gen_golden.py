@@ -350,23 +350,75 @@ def gen_rank_loss():
         out[f"r{i}_quick_grad"], out[f"r{i}_quick_maxrev"], out[f"r{i}_quick_total"] = g.numpy(), maxrev.numpy(), np.asarray(total)
         out[f"r{i}_cheap_loss"] = rl.cheap_pairwise_rank_loss(target, scores=scores).numpy()
     out["n_random"] = np.asarray(6)
+
+    # ---- the rest of the rank-loss code: compute_inversions, RankAndLoss (pairwise_rank_loss.py:24-135) and
+    # RankRegressionPT.fit over RankingRegModule / cheap_pairwise_rank_loss (logistic_regression.py:16-65,126-267)
+    prl = R.ref("seesaw.pairwise_rank_loss")
+    lr = R.ref("seesaw.logistic_regression")
+    for i in range(4):
+        n = [7, 40, 200, 1000][i]
+        labs = rng.integers(0, 2, n).astype(np.float64)
+        scores = rng.standard_normal(n).astype(np.float32)
+        out[f"inv{i}_labs"], out[f"inv{i}_scores"] = labs, scores
+        out[f"inv{i}_inversions"] = np.asarray(prl.compute_inversions(labs, scores), dtype=np.int64)
+    k = 0
+    for (n, n_pos, margin) in [(30, 5, 0.0), (200, 40, 0.05), (200, 3, 0.2), (64, 63, 0.1), (50, 0, 0.1)]:
+        X, y, q = _labelled_set(900 + k, n, max(n_pos, 1), q_noise=3.0)  # a poor w: inversions exist
+        if n_pos == 0:
+            y[:] = 0.0
+        w = torch.from_numpy(q).clone().requires_grad_(True)
+        loss = prl.RankAndLoss.apply(w, torch.from_numpy(X), torch.from_numpy(y).float(), torch.tensor(margin))
+        if loss.requires_grad:
+            loss.backward()
+            grad = w.grad.numpy().copy()
+        else:
+            grad = np.zeros(512, np.float32)
+        out[f"ral{k}_set"] = np.asarray([900 + k, n, max(n_pos, 1)])  # oracle.labelled_set(seed, n, n_pos, q_noise=3.0)
+        out[f"ral{k}_y"] = y
+        out[f"ral{k}_margin"], out[f"ral{k}_loss"], out[f"ral{k}_grad"] = np.asarray(margin), np.asarray(loss.item()), grad
+        k += 1
+    out["n_ral"] = np.asarray(k)
+    # VecState (the old_seesaw loop's online update: one SGD step per call, dummy forward)
+    X, y, q = _labelled_set(950, 120, 15)
+    vs = prl.VecState(q.copy(), margin=0.1, opt_class=torch.optim.SGD, opt_params={"lr": 0.01}, renormalize=True)
+    import contextlib
+    import io
+    for step in range(3):
+        with contextlib.redirect_stdout(io.StringIO()):
+            vs.update(X, y)
+        out[f"vs_w{step}"] = vs.get_vec().copy()
+    out["vs_set"] = np.asarray([950, 120, 15])
+    # RankRegressionPT
+    kk = 0
+    for (n, n_pos, lam) in [(80, 12, 1.0), (300, 40, 10.0)]:
+        X, y, q = _labelled_set(970 + kk, n, n_pos, q_noise=2.0)
+        captured = {}
+        orig_init = lr.RankingRegModule.__init__
+
+        def patched(self, *a, _o=orig_init, **kw):
+            _o(self, *a, **kw)
+            captured["w0"] = self.linear.weight.detach().clone().numpy()
+            captured["traj"] = _Trajectory(self, self.linear.weight)
+            torch.manual_seed(0)
+
+        lr.RankingRegModule.__init__ = patched
+        try:
+            torch.manual_seed(2000 + kk)
+            model = lr.RankRegressionPT(scale="centered", reg_lambda=lam, regularizer_vector=q, max_iter=60, lr=1.0)
+            model.fit(X, y.reshape(-1, 1).astype(np.float32))
+        finally:
+            lr.RankingRegModule.__init__ = orig_init
+        tw, tl, tg = captured["traj"].arrays()
+        out[f"rr{kk}_set"], out[f"rr{kk}_lam"] = np.asarray([970 + kk, n, n_pos]), np.asarray(lam)  # q_noise=2.0
+        out[f"rr{kk}_w0"], out[f"rr{kk}_coeff"] = captured["w0"], model.get_coeff()
+        out[f"rr{kk}_traj_w"], out[f"rr{kk}_traj_loss"], out[f"rr{kk}_traj_grad"] = tw, tl, tg
+        kk += 1
+    out["n_rr"] = np.asarray(kk)
     save("rank_loss", **out)
 
 
 # ------------------------------------------------------------------------------------
-def _labelled_set(seed, n, n_pos, dim=512, q_noise=0.8):
-    """A small labelled set shaped like q.getXy(): tile vectors of seen images."""
-    rng = np.random.default_rng(seed)
-    target = orc.synth_query(seed)
-    X = orc.synth_rows(seed, 0, n, dim)
-    y = np.zeros(n)
-    pos = rng.choice(n, n_pos, replace=False)
-    X[pos] = X[pos] + 0.6 * target
-    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
-    y[pos] = 1.0
-    q = target + q_noise * orc.synth_query(seed + 77)
-    q = (q / np.linalg.norm(q)).astype(np.float32)
-    return X, y, q
+_labelled_set = orc.labelled_set
 
 
 class _Trajectory:

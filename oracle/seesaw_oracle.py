@@ -340,3 +340,19 @@ def rescore_avg_score(row_dbidx, boxes, zoom, scores, topk: int, aug_larger: str
     dbscores = np.asarray(best_scores, dtype=np.float64)
     top = np.argsort(-dbscores)[:topk]
     return ids[top], np.asarray(best_rows)[top], np.asarray(best_scores, dtype=np.float32)[top]
+
+
+# ---- seeded labelled sets shared by the golden generator and the tests (inputs regenerate from three integers)
+def labelled_set(seed, n, n_pos, dim=512, q_noise=0.8):
+    """A small labelled set shaped like q.getXy(): tile vectors of seen images."""
+    rng = np.random.default_rng(seed)
+    target = synth_query(seed)
+    X = synth_rows(seed, 0, n, dim)
+    y = np.zeros(n)
+    pos = rng.choice(n, n_pos, replace=False)
+    X[pos] = X[pos] + 0.6 * target
+    X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+    y[pos] = 1.0
+    q = target + q_noise * synth_query(seed + 77)
+    q = (q / np.linalg.norm(q)).astype(np.float32)
+    return X, y, q

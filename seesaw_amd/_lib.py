@@ -88,6 +88,8 @@ _SIGNATURES = {
     "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_scores": (c_i32, [c_void_p, c_void_p, c_i32, c_void_p]),
     "ssw_fb_fit": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_i32_p, c_i32_p, c_void_p]),
+    "ssw_rank_quick_gradient": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
+    "ssw_rank_inversions": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p]),
     "ssw_rank_pairwise": (c_i32, [c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_void_p, c_void_p]),
     "ssw_clip_create": (c_i32, [c_i32, c_void_p, ctypes.c_size_t, c_void_pp]),
     "ssw_clip_destroy": (c_i32, [c_void_p]),
@@ -113,7 +115,7 @@ class FbObjective(ctypes.Structure):
                 ("reg_query_lambda", ctypes.c_float)]
 
 
-SSW_FB_LOGREG, SSW_FB_MULTIREG = 0, 1
+SSW_FB_LOGREG, SSW_FB_MULTIREG, SSW_FB_RANKREG = 0, 1, 2
 SSW_FB_LOSS_CE, SSW_FB_LOSS_PAIRWISE_HINGE, SSW_FB_LOSS_PAIRWISE_LOGISTIC = 0, 1, 2
 SSW_FB_REG_NONE, SSW_FB_REG_VECTOR, SSW_FB_REG_NORM, SSW_FB_REG_NORM1 = 0, 1, 2, 3
 

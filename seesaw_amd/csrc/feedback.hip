@@ -24,6 +24,7 @@
 // and the L-BFGS two-loop recursion / cubic-interpolation line search run on the host over
 // 513-float vectors (pure latency, no bandwidth).  Bound: launch/sync latency, not HBM --
 // nothing here is GEMM-shaped enough for MFMA.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -209,6 +210,18 @@ __global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ 
         item_loss[k] = (double)ck * loss_k;
         r[k] = (float)rk;
     }
+}
+
+// RankingRegModule (logistic_regression.py:16-65): per-item "loss" |g_i| / total_pairs and the pseudo-gradient
+// g_i / total_pairs that _CheapPairwiseRankingLoss.backward hands to autograd (rank_loss.py:164-187), g = the
+// quick zero-margin gradient of rank.hip
+__global__ void k_fb_rank_items(const float *__restrict__ g, float factor, int64_t n, double *__restrict__ item_loss,
+                                float *__restrict__ r) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = g[i] * factor;  // f32, as torch forms grads * factor
+    item_loss[i] = (double)fabsf(v);
+    r[i] = v;
 }
 
 // partial gradient of one slab of rows: thread c owns column c
@@ -434,6 +447,7 @@ struct ssw_fb {
     std::vector<float> y_host, sw_host;
     // diagnostics of the last fit
     int last_iters = 0, last_evals = 0;
+    float rank_factor = 0.f;   // 1 / total_pairs of the installed targets (SSW_FB_RANKREG)
 };
 
 static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
@@ -537,6 +551,33 @@ static ssw_status fb_prepare(ssw_fb *fb, const ssw_fb_objective *o, FbObjDev *de
                 return SSW_ERR_UNSUPPORTED;
             }
         }
+    } else if (o->kind == SSW_FB_RANKREG) {
+        // sum_i |g_i| / total_pairs + (lambda / n) R(w): RankRegressionPT.fit (logistic_regression.py:216-255)
+        dev->kind = SSW_FB_LOGREG;  // the regulariser terms are LogisticRegressionPT's
+        dev->reg_kind = o->reg_kind;
+        dev->scale = 1.f;
+        dev->reg_weight = o->reg_weight;
+        if (o->reg_kind == 1 && !fb->has_q) {
+            set_error("feedback: vector regulariser needs ssw_fb_set_query first");
+            return SSW_ERR_INVALID;
+        }
+        if (n > SSW_RANK_MAX_ITEMS) {
+            set_error("feedback: the rank objective takes at most %d items, got %lld", SSW_RANK_MAX_ITEMS, (long long)n);
+            return SSW_ERR_UNSUPPORTED;
+        }
+        // total_pairs = n^2 - sum over distinct targets of (class size)^2 (rank_loss.py:152)
+        std::vector<float> ys(fb->y_host.begin(), fb->y_host.begin() + n);
+        std::sort(ys.begin(), ys.end());
+        double total = (double)n * (double)n;
+        for (int64_t i = 0; i < n;) {
+            int64_t j = i;
+            while (j < n && ys[(size_t)j] == ys[(size_t)i]) ++j;
+            total -= (double)(j - i) * (double)(j - i);
+            i = j;
+        }
+        fb->rank_factor = total > 0 ? (float)(1.0 / total) : 0.f;
+        *pw_out = 1.f;
+        return SSW_OK;  // no per-item coefficients
     } else {
         set_error("feedback: unknown objective kind %d", o->kind);
         return SSW_ERR_INVALID;
@@ -564,7 +605,8 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     }
     int nslabs = 0;
     if (n > 0) {
-        const bool pairwise = o->kind == SSW_FB_MULTIREG && o->loss_type != SSW_FB_LOSS_CE;
+        const bool rankreg = o->kind == SSW_FB_RANKREG;
+        const bool pairwise = rankreg || (o->kind == SSW_FB_MULTIREG && o->loss_type != SSW_FB_LOSS_CE);
         nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
         if (by_arg)
             hipLaunchKernelGGL(k_fb_logits_arg, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, wv, n, dim,
@@ -576,6 +618,11 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
             if (!by_arg)
                 hipLaunchKernelGGL(k_fb_elem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->z, fb->y, fb->coef,
                                    pw, n, fb->item, fb->r, dev.exact);
+        } else if (rankreg) {
+            // z is ready: net position changes by counting (rank.hip), then |g| / total_pairs and g / total_pairs
+            SSW_TRY(launch_rank_quick(fb->y, fb->z, (int)n, fb->partial /* scratch: [n] floats */, nullptr, nullptr, s));
+            hipLaunchKernelGGL(k_fb_rank_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->partial,
+                               fb->rank_factor, n, fb->item, fb->r);
         } else if (pairwise_active) {
             const size_t lds = (size_t)3 * n * sizeof(float);
             if (o->loss_type == SSW_FB_LOSS_PAIRWISE_LOGISTIC)

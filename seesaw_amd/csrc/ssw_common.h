@@ -164,6 +164,12 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
 ssw_status launch_gather_f32(const float *src, const int64_t *idx_dev, int64_t n, float *dst,
                              hipStream_t stream);
 
+constexpr int SSW_RANK_MAX_ITEMS = 65536;    // rank.hip: items of one counting launch (O(n^2) compares)
+
+// rank.hip: quick zero-margin pairwise gradient on device-resident targets / scores (feedback engine)
+ssw_status launch_rank_quick(const float *target_dev, const float *scores_dev, int n, float *grad_dev,
+                             float *maxrev_dev_or_null, unsigned long long *total_dev_or_null, hipStream_t stream);
+
 // rescore.hip: avg_score aggregation of candidate images' tiles (score_frame2 / box_join).
 constexpr int SSW_RESCORE_MAX_TILES = 2048;  // tiles of one image held in LDS (28 B each)
 constexpr int SSW_RESCORE_MAX_ZOOM = 31;     // zoom levels index a 32-bit presence mask

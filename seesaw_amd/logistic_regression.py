@@ -124,3 +124,35 @@ class LogisticRegressionPT:
             X = X - self.mu_.reshape(1, -1)
         z = X @ self.coef_[: self._dim] + (self.coef_[self._dim] if self.fit_intercept else 0.0)
         return (1.0 / (1.0 + np.exp(-z))).reshape(-1, 1).astype(np.float32)
+
+
+class RankRegressionPT(LogisticRegressionPT):
+    """linear scorer fitted on the cheap pairwise rank loss (seesaw/logistic_regression.py:126-267 over
+    RankingRegModule :16-65): sum_i |g_i| / total_pairs + (reg_lambda / n) R(w), g the zero-margin pairwise gradient;
+    the regulariser options and get_coeff / predict_proba are LogisticRegressionPT's.  One L-BFGS step per fit, the
+    "gradient" being what _CheapPairwiseRankingLoss.backward returns (g / total_pairs through X)."""
+
+    def __init__(self, scale, reg_lambda, regularizer_vector, verbose=False, max_iter=100, lr=1.0, device: int = 0, **kwargs):
+        super().__init__(class_weights=1.0, scale=scale, reg_lambda=reg_lambda, regularizer_vector=regularizer_vector,
+                         fit_intercept=False, verbose=verbose, max_iter=max_iter, lr=lr, device=device, **kwargs)
+
+    def _objective(self, n_examples: int, pos_weight: float) -> FbObjective:
+        obj = super()._objective(n_examples, pos_weight)
+        obj.kind = _lib.SSW_FB_RANKREG
+        return obj
+
+    def fit(self, X, y, sample_weights=None, w0: np.ndarray = None, index=None, rows=None):
+        if sample_weights is not None:
+            raise NotImplementedError("handle weights later on")  # as the reference (logistic_regression.py:37)
+        return super().fit(X, y, None, w0=w0, index=index, rows=rows)
+
+    def lossgrad(self, w):
+        """one closure evaluation at w on the installed data (for tests / diagnostics)"""
+        return self._engine.lossgrad(self._objective(self._engine.n, 1.0), w)
+
+    def predict_proba(self, X):
+        """RankingRegModule.forward is the raw linear score (no sigmoid)"""
+        X = np.asarray(X, dtype=np.float32)
+        if self.scale == "centered":
+            X = X - self.mu_.reshape(1, -1)
+        return (X @ self.coef_[: self._dim]).reshape(-1, 1).astype(np.float32)

@@ -59,3 +59,26 @@ def ref_pairwise_rank_loss_gradient(target, *, scores, margin, device: int = 0):
     _, grad = pairwise_sums(target, scores=scores, margin=margin, logistic=False, coef=max_inversions(target),
                             device=device)
     return grad
+
+
+def quick_pairwise_gradient_zero_margin(target, *, scores, return_max_inversions=False, device: int = 0):
+    """gradient of the zero-margin pairwise rank loss in O(n log n) in the reference (two lexicographic sorts,
+    rank_loss.py:109-161); here ssw_rank_quick_gradient counts the two ranks directly -- same integers, ties
+    included.  -> 2 x net position change [, max_reversals, total_pairs]"""
+    t, s = _f32(target), _f32(scores)
+    assert t.shape == s.shape
+    n = t.shape[0]
+    grad = np.zeros(n, dtype=np.float32)
+    maxrev = np.zeros(n, dtype=np.float32)
+    total = ctypes.c_int64(0)
+    _lib.call("ssw_rank_quick_gradient", int(device), ctypes.c_void_p(t.ctypes.data), ctypes.c_void_p(s.ctypes.data), n,
+              ctypes.c_void_p(grad.ctypes.data), ctypes.c_void_p(maxrev.ctypes.data), ctypes.byref(total))
+    return (grad, maxrev, int(total.value)) if return_max_inversions else grad
+
+
+def cheap_pairwise_rank_loss(target, *, scores, normalized=True, device: int = 0):
+    """_CheapPairwiseRankingLoss (rank_loss.py:164-187): forward |gradient| x factor and the backward it hands to
+    autograd, gradient x factor (x the incoming gradient).  -> (per-item loss [n], d(sum of the losses) / d scores [n])"""
+    grad, _, total = quick_pairwise_gradient_zero_margin(target, scores=scores, return_max_inversions=True, device=device)
+    factor = np.float32(1.0) if not normalized else (np.float32(1.0) / np.float32(total) if total else np.float32(np.inf))
+    return np.abs(grad) * factor, grad * factor

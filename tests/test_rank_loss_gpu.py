@@ -69,3 +69,71 @@ def test_normalised_form_is_what_regmodule_sums(g):
     mx = g[f"r{i}_max_inv"].astype(np.float64)
     want = np.where(mx > 0, sw * g[f"r{i}_hinge_sum"] / np.maximum(mx, 1), 0.0)
     assert np.abs(item - want).max() <= TOL
+
+
+def test_quick_gradient_on_the_table_and_random_cases(g):
+    """quick_pairwise_gradient_zero_margin (counting kernel) on the reference's margin-0 table rows and on the
+    random cases: gradient, max_reversals and total_pairs are exact integers"""
+    from seesaw_amd import rank_loss as rl
+    n_checked = 0
+    for i in range(int(g["n_table"])):
+        if float(g[f"t{i}_margin"]) != 0.0 or g[f"t{i}_target"].shape[0] == 0:
+            continue
+        grad, mx, _ = rl.quick_pairwise_gradient_zero_margin(g[f"t{i}_target"], scores=g[f"t{i}_scores"], return_max_inversions=True)
+        assert np.array_equal(grad, 2.0 * np.asarray(g[f"t{i}_expected_gradient"], dtype=np.float32).reshape(-1)), i
+        assert np.array_equal(mx, np.asarray(g[f"t{i}_expected_max_inversions"], dtype=np.float32).reshape(-1)), i
+        n_checked += 1
+    assert n_checked >= 4
+    for i in range(int(g["n_random"])):
+        grad, mx, total = rl.quick_pairwise_gradient_zero_margin(g[f"r{i}_target"], scores=g[f"r{i}_scores"], return_max_inversions=True)
+        assert np.array_equal(grad, g[f"r{i}_quick_grad"]), i       # scores rounded to 1 decimal: many exact ties
+        assert np.array_equal(mx, g[f"r{i}_quick_maxrev"]) and total == int(g[f"r{i}_quick_total"])
+        loss, back = rl.cheap_pairwise_rank_loss(g[f"r{i}_target"], scores=g[f"r{i}_scores"])
+        assert np.allclose(loss, g[f"r{i}_cheap_loss"], rtol=1e-6, atol=0)
+    assert rl.quick_pairwise_gradient_zero_margin(np.zeros(0), scores=np.zeros(0)).shape == (0,)
+
+
+def test_compute_inversions_matches_reference(g):
+    from seesaw_amd.pairwise_rank_loss import compute_inversions
+    for i in range(4):
+        got = compute_inversions(g[f"inv{i}_labs"], g[f"inv{i}_scores"])
+        assert np.array_equal(got, g[f"inv{i}_inversions"]), i
+
+
+def test_rank_and_loss_and_vecstate_match_reference(g, oracle):
+    from seesaw_amd.pairwise_rank_loss import VecState, rank_and_loss
+    for k in range(int(g["n_ral"])):
+        seed, n, n_pos = (int(v) for v in g[f"ral{k}_set"])
+        X, _, q = oracle.labelled_set(seed, n, n_pos, q_noise=3.0)
+        y = g[f"ral{k}_y"]
+        loss, grad = rank_and_loss(q, X, y, float(g[f"ral{k}_margin"]))
+        assert abs(loss - float(g[f"ral{k}_loss"])) <= 1e-6, (k, loss, float(g[f"ral{k}_loss"]))
+        assert np.abs(grad - g[f"ral{k}_grad"]).max() <= 1e-6, k
+    seed, n, n_pos = (int(v) for v in g["vs_set"])
+    X, y, q = oracle.labelled_set(seed, n, n_pos)
+    vs = VecState(q.copy(), margin=0.1, opt_params={"lr": 0.01}, renormalize=True)
+    for step in range(3):
+        vs.update(X, y)
+        assert np.abs(vs.get_vec() - g[f"vs_w{step}"]).max() <= 1e-6, step
+
+
+def test_rank_regression_lossgrad_along_reference_trajectory_and_fit(g, oracle):
+    """RankRegressionPT: the loss (net inversions / total_pairs + regulariser) and the pseudo-gradient at every
+    point the reference's L-BFGS evaluated, within 1e-4; and a fit from the reference's own start weights ends
+    at a loss no worse than the reference's"""
+    from seesaw_amd.logistic_regression import RankRegressionPT
+    for k in range(int(g["n_rr"])):
+        seed, n, n_pos = (int(v) for v in g[f"rr{k}_set"])
+        X, y, q = oracle.labelled_set(seed, n, n_pos, q_noise=2.0)
+        model = RankRegressionPT(scale="centered", reg_lambda=float(g[f"rr{k}_lam"]), regularizer_vector=q, max_iter=60, lr=1.0)
+        model.fit(X, y.reshape(-1, 1), w0=g[f"rr{k}_w0"].reshape(-1))
+        W, L, G = g[f"rr{k}_traj_w"], g[f"rr{k}_traj_loss"], g[f"rr{k}_traj_grad"]
+        for t in range(W.shape[0]):
+            loss, grad, _ = model.lossgrad(W[t])
+            assert abs(loss - L[t]) <= TOL * max(1.0, abs(L[t])), (k, t, loss, L[t])
+            assert np.abs(grad - G[t]).max() <= TOL * max(1.0, np.abs(G[t]).max()), (k, t)
+        ours, _, _ = model.lossgrad(model.get_coeff().reshape(-1))
+        assert ours <= L[-1] + 1e-4, (k, ours, L[-1])
+        Xc = X - X.mean(axis=0)
+        print(f"rank regression {k}: final loss ours {ours:.3e} vs reference {L[-1]:.3e}; |scores diff| = "
+              f"{np.abs(Xc @ (model.get_coeff().reshape(-1) - g[f'rr{k}_coeff'].reshape(-1))).max():.2e}")
