@@ -311,6 +311,23 @@ ssw_status ssw_rank_inversions(int32_t device, const uint8_t *labels_host, const
                                int64_t *out_inversions);
 
 /* ------------------------------------------------------------------------- */
+/* L-KNN active search: two-step look-ahead value of every node                 */
+/* replaces: _top_sum / _opt_expected_utility_helper_lknn2                      */
+/*           seesaw/research/active_search/efficient_nonmyopic_search.py:94-205 */
+/*           (model state: seesaw/loops/LKNN_model.py:76-281)                   */
+/* ------------------------------------------------------------------------- */
+typedef struct ssw_lknn ssw_lknn;
+/* neighbors_sorted: [n, D] i32, every row ascending (np.sort(matrix.indices.reshape(-1, D))), D <= 32. */
+ssw_status ssw_lknn_create(int32_t device, int64_t n, int32_t D, const int32_t *neighbors_sorted_host, ssw_lknn **out);
+ssw_status ssw_lknn_destroy(ssw_lknn *h);
+/* numer = numerators + gamma with -inf at labelled nodes, denom = denominators + 1 (both [n] f64);
+ * top_ids_desc = the K + D nodes of highest numer/denom, best first.  value[i] = s_i (1 + E1_i) + (1 - s_i) E0_i with
+ * E_y = sum of the K best scores among the other nodes after labelling i with y (only i's neighbours change).
+ * Returns np.nanargmax(value) and its value; out_values (optional) receives all n values.  K <= 128. */
+ssw_status ssw_lknn_top_sum(ssw_lknn *h, const double *numer_host, const double *denom_host, const int32_t *top_ids_desc,
+                            int32_t K, double *out_values_or_null, int64_t *out_best_idx, double *out_best_value);
+
+/* ------------------------------------------------------------------------- */
 /* CLIP ViT-B/32 image / text towers (bf16 MFMA forward)                       */
 /* replaces: transformers.CLIPModel.get_text_features                          */
 /*               seesaw/models/embeddings.py:441-455 (HGWrapper.from_string)   */

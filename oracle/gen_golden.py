@@ -729,7 +729,65 @@ def gen_bench_loop():
     save("bench_loop", **out)
 
 
-FAMILIES = {"scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
+def gen_lknn():
+    """(f-4) L-KNN active search: the reference's ring-graph known answers (loops/LKNN_model_test.py:7-45) and the
+    vectorised two-step look-ahead (_top_sum / efficient_nonmyopic_search 'vectorized') over a planning session on
+    a random 10-regular graph: the node chosen and its value every round, the full value vector at some rounds."""
+    import contextlib
+    import io
+    import scipy.sparse as sp
+    lm = R.ref("seesaw.loops.LKNN_model")
+    ens = R.ref("seesaw.research.active_search.efficient_nonmyopic_search")
+    common = R.ref("seesaw.research.active_search.common")
+    out = {}
+    # ring graph of the reference's own test (loops/LKNN_model_test.py:7-45; the test file passes gamma as a bare
+    # float, which LKNNModel.from_dataset no longer accepts -- same graph, gamma = 0.5 per node): its stated answers
+    mat = np.zeros((5, 5))
+    for i in range(5):
+        mat[i, (i + 1) % 5] = 1
+    model = lm.LKNNModel.from_dataset(common.Dataset.from_vectors(np.random.default_rng(0).random((5, 10))),
+                                      weight_matrix=sp.csr_array(mat + mat.T), gamma=np.full(5, 0.5))
+    assert np.isclose(model.predict_proba(np.arange(5)), 0.5).all()
+    assert 0.75 <= model.probability_bound(1) and 2.5 / 3 <= model.probability_bound(2)
+    out["ring_probs"] = model.predict_proba(np.arange(5))
+    out["ring_cond1_ids"], out["ring_cond1"] = model.condition(2, 1).top_k_remaining(top_k=4)
+    out["ring_cond0_ids"], out["ring_cond0"] = model.condition(2, 0).top_k_remaining(top_k=4)
+    out["ring_bounds"] = np.array([model.probability_bound(1), model.probability_bound(2)])
+    # planning session on a random regular graph
+    N, D, seed = 3000, 10, 77
+    rng = np.random.default_rng(seed)
+    nbr = np.stack([rng.choice(N, D, replace=False) for _ in range(N)]).astype(np.int32)
+    W = sp.csr_array((np.ones(N * D), nbr.reshape(-1), np.arange(0, N * D + 1, D)), shape=(N, N))
+    truth = (rng.random(N) < 0.08).astype(np.int64)
+    out["graph_seed"], out["N"], out["D"] = np.asarray(seed), np.asarray(N), np.asarray(D)
+    out["truth"] = truth
+    r = 0
+    for horizon in (2, 9, 20, 101):
+        gamma = lm.initial_gamma_array(0.1, N)
+        model = lm.LKNNModel.from_dataset(common.Dataset.from_vectors(np.zeros((N, 1))), weight_matrix=W, gamma=gamma)
+        picks, values = [], []
+        for rnd in range(12):
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = ens.efficient_nonmyopic_search(model, reward_horizon=horizon, lookahead_limit=2, pruning_on=False,
+                                                     implementation="vectorized")
+            picks.append(int(res.index))
+            values.append(float(res.value))
+            if rnd in (0, 5, 11):  # the whole value vector, straight from _top_sum
+                numer = model.numerators + model.gamma
+                denom = model.denominators + 1
+                numer[np.array(model.dataset.seen_indices, dtype=np.int64)] = -np.inf
+                with np.errstate(invalid="ignore"):
+                    full = ens._top_sum(numerators=numer, denominators=denom, scores=numer / denom,
+                                        neighbor_ids_sorted=np.sort(nbr), N=N, K=horizon - 1, D=D)
+                out[f"h{horizon}_values_r{rnd}"] = full
+            model.condition_(int(res.index), int(truth[int(res.index)]))
+        out[f"h{horizon}_picks"], out[f"h{horizon}_values"] = np.asarray(picks), np.asarray(values)
+        r += 1
+    out["horizons"] = np.asarray([2, 9, 20, 101])
+    save("lknn", **out)
+
+
+FAMILIES = {"lknn": gen_lknn, "scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
             "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop}
 
 def main(argv):

@@ -356,3 +356,33 @@ def labelled_set(seed, n, n_pos, dim=512, q_noise=0.8):
     q = target + q_noise * synth_query(seed + 77)
     q = (q / np.linalg.norm(q)).astype(np.float32)
     return X, y, q
+
+
+# ---- L-KNN two-step look-ahead: _top_sum ------------------------------------------------------
+def lknn_top_sum(numerators, denominators, neighbor_ids_sorted, K):
+    """_top_sum (seesaw/research/active_search/efficient_nonmyopic_search.py:94-169) row by row.  numerators already
+    hold + gamma (-inf at labelled nodes), denominators + 1.  For node i the candidates are the K + D globally best
+    scores -- minus i itself and minus those of its neighbours that are among them -- plus the neighbours' scores
+    had i been labelled y (i itself excluded); E_y = sum of the K best (numpy's row sum of the descending values);
+    value = s (1 + E_1) + (1 - s) E_0."""
+    num, den = np.asarray(numerators, np.float64), np.asarray(denominators, np.float64)
+    nbr = np.asarray(neighbor_ids_sorted)
+    N, D = nbr.shape
+    scores = num / den
+    top = np.argsort(scores)[-(K + D):]
+    top_scores = scores[top]
+    new_den = den + 1
+    given = {0: num / new_den, 1: (num + 1) / new_den}
+    out = np.empty(N)
+    for i in range(N):
+        keep = ~(np.isin(top, nbr[i]) | (top == i))
+        e = {}
+        for y in (0, 1):
+            ns = given[y][nbr[i]].copy()
+            ns[nbr[i] == i] = -np.inf
+            cand = np.concatenate([np.where(keep, top_scores, -np.inf), ns])
+            best = np.sort(cand)[::-1][:K].reshape(1, -1).copy()
+            e[y] = best.sum(axis=1)[0]
+        with np.errstate(invalid="ignore"):
+            out[i] = scores[i] * (1 + e[1]) + (1 - scores[i]) * e[0]
+    return out

@@ -90,6 +90,9 @@ _SIGNATURES = {
     "ssw_fb_fit": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_i32_p, c_i32_p, c_void_p]),
     "ssw_rank_quick_gradient": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
     "ssw_rank_inversions": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p]),
+    "ssw_lknn_create": (c_i32, [c_i32, c_i64, c_i32, c_void_p, c_void_pp]),
+    "ssw_lknn_destroy": (c_i32, [c_void_p]),
+    "ssw_lknn_top_sum": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
     "ssw_rank_pairwise": (c_i32, [c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i32, ctypes.c_float, c_void_p, c_void_p]),
     "ssw_clip_create": (c_i32, [c_i32, c_void_p, ctypes.c_size_t, c_void_pp]),
     "ssw_clip_destroy": (c_i32, [c_void_p]),

@@ -20,6 +20,10 @@ class GroundTruthCalibrator:
     def __init__(self, X, y):
         assert X.shape[0] == y.shape[0]
         self.X, self.y = X, y
+        self._mean = y.mean()
+
+    def get_mean(self):
+        return self._mean
 
     def get_probabilities(self, vector_scorer, vectors):
         from sklearn.calibration import _SigmoidCalibration

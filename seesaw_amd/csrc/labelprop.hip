@@ -30,6 +30,9 @@
 
 #include "ssw_common.h"
 
+// Compiled with -ffp-contract=off (csrc/Makefile): results of this file are compared bit for bit with numpy /
+// scipy / torch, so every product and sum must round on its own (hipcc would contract a * b + c into an fma).
+
 namespace ssw {
 namespace {
 

@@ -21,6 +21,9 @@
 // Explicitly rounded intrinsics keep the compiler from contracting w*h into the union's subtraction.
 #include "ssw_common.h"
 
+// Compiled with -ffp-contract=off (csrc/Makefile): results of this file are compared bit for bit with numpy /
+// scipy / torch, so every product and sum must round on its own (hipcc would contract a * b + c into an fma).
+
 namespace ssw {
 namespace {
 

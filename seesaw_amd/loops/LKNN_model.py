@@ -1,0 +1,184 @@
+"""LKNNModel: the L-KNN probability model of the active-search loops (seesaw/loops/LKNN_model.py:76-281).
+
+p_i = (gamma_i + sum of the labels of i's labelled neighbours) / (1 + number of labelled neighbours).  The state is
+three host arrays (numerators, denominators, gamma) over the nodes and the CSR neighbour lists; conditioning on a
+label touches one row of neighbours.  What is expensive in the reference -- the look-ahead value of every node,
+an N x (K + 2D) argsort per planning step -- runs on the GPU (`top_sum`, ssw_lknn_top_sum)."""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from .. import _lib
+from ..bitmap import FrozenBitMap
+from ..research.active_search.common import Dataset, ProbabilityModel
+
+
+def initial_gamma_array(gamma, shape):
+    """the prior, jittered by 1e-6 so that no two nodes tie (LKNN_model.py:70-73)"""
+    return np.random.default_rng(seed=0).normal(loc=gamma, scale=1e-6, size=shape)
+
+
+class LKNNModel(ProbabilityModel):
+    def __init__(self, dataset: Dataset, gamma, matrix: sp.csr_array, numerators, denominators, score, desc_idx, desc_score,
+                 desc_changed_idx, desc_changed_score, device: int = 0, _gpu=None):
+        super().__init__(dataset)
+        self.matrix, self.numerators, self.denominators, self.score, self.gamma = matrix, numerators, denominators, score, gamma
+        assert gamma.shape == self.numerators.shape
+        assert ((0 < gamma) & (gamma < 1)).all(), "this could fail by chance, decrase var. or fix properly by applying sigmoid"
+        self.desc_idx, self.desc_score = desc_idx, desc_score
+        self.desc_changed_idx, self.desc_changed_score = desc_changed_idx, desc_changed_score  # filled by condition()
+        self.device = device
+        self._gpu = _gpu if _gpu is not None else {}  # shared by the models derived from one another: one device handle
+        self._init_sets()
+
+    def _init_sets(self):
+        self.changed_idx_set = FrozenBitMap(self.desc_changed_idx) if self.desc_changed_idx is not None else FrozenBitMap()
+        self.ignore_set = self.dataset.seen_indices.union(self.changed_idx_set)
+
+    @staticmethod
+    def from_dataset(dataset: Dataset, weight_matrix: sp.csr_array, gamma: np.ndarray, device: int = 0):
+        assert weight_matrix.format == "csr"
+        assert len(dataset.idx2label) == 0, "not implemented other case"
+        sz = weight_matrix.shape[0]
+        assert gamma.shape == (sz,)
+        init_scores = (np.zeros(sz) + gamma) / (np.zeros(sz) + 1)
+        order = np.argsort(-init_scores)
+        return LKNNModel(dataset, gamma=gamma, matrix=weight_matrix, numerators=np.zeros(sz), denominators=np.zeros(sz),
+                         score=init_scores, desc_idx=order, desc_score=init_scores[order], desc_changed_idx=None,
+                         desc_changed_score=None, device=device)
+
+    def _derive(self, **kw):
+        base = dict(dataset=self.dataset, gamma=self.gamma, matrix=self.matrix, numerators=self.numerators,
+                    denominators=self.denominators, score=self.score, desc_idx=self.desc_idx, desc_score=self.desc_score,
+                    desc_changed_idx=self.desc_changed_idx, desc_changed_score=self.desc_changed_score, device=self.device,
+                    _gpu=self._gpu)
+        base.update(kw)
+        return LKNNModel(**base)
+
+    # ---- conditioning -------------------------------------------------------------------------
+    def _condition_shared(self, idx, y, ret_num_denom=False):
+        start, end = self.matrix.indptr[idx:idx + 2]
+        neighbors = self.matrix.indices[start:end]
+        assert self.dataset.idx2label.get(idx, None) is None, "no benchmark scenario should reach this"
+        num, den, gam = self.numerators[neighbors], self.denominators[neighbors], self.gamma[neighbors]
+        change = (num + y + gam) / (den + 1 + 1)
+        order = np.argsort(-change)
+        nd = (num + y, den + 1) if ret_num_denom else (None, None)
+        return self.dataset.with_label(idx, y), neighbors, neighbors[order], change[order], change, nd[0], nd[1]
+
+    def condition(self, idx, y) -> "LKNNModel":
+        """a NEW model with idx labelled y: the base arrays are shared, the changed neighbours ride along sorted"""
+        assert self.desc_changed_idx is None
+        ds, _, chg_idx, chg_score, _, _, _ = self._condition_shared(idx, y)
+        return self._derive(dataset=ds, desc_changed_idx=chg_idx, desc_changed_score=chg_score)
+
+    def with_gamma(self, new_gamma: np.ndarray) -> "LKNNModel":
+        assert self.desc_changed_idx is None, "check this is correct"
+        scores = (self.numerators + new_gamma) / (self.denominators + 1)
+        order = np.argsort(-scores)
+        return self._derive(gamma=new_gamma, score=scores, desc_idx=order, desc_score=scores[order])
+
+    def condition_(self, idx, y):
+        """in place (after the user's answer): neighbours' counts and scores, then the descending order"""
+        assert self.desc_changed_idx is None
+        ds, neighbors, _, _, change, num, den = self._condition_shared(idx, y, ret_num_denom=True)
+        self.dataset = ds
+        self.numerators[neighbors], self.denominators[neighbors], self.score[neighbors] = num, den, change
+        self.desc_idx = np.argsort(-self.score)
+        self.desc_score = self.score[self.desc_idx]
+        self._init_sets()
+
+    # ---- queries ------------------------------------------------------------------------------
+    def predict_proba(self, idxs) -> np.ndarray:
+        assert self.desc_changed_idx is None, "is this ever called after first round"
+        return self.score[np.asarray(idxs, dtype=np.int64)]
+
+    def _iter_desc_scores(self):
+        for idx, score in zip(self.desc_idx, self.desc_score):
+            if idx not in self.ignore_set:
+                yield idx, score
+
+    def _iter_changed_scores(self):
+        for idx, score in zip(self.desc_changed_idx, self.desc_changed_score):
+            if idx not in self.dataset.seen_indices:
+                yield idx, score
+
+    def iter_desc(self):
+        """both streams merged in descending order, without the nodes already seen"""
+        if self.desc_changed_idx is None:
+            yield from self._iter_desc_scores()
+            return
+        it1, it2 = self._iter_desc_scores(), self._iter_changed_scores()
+        end = (-1, -math.inf)
+        (i1, s1), (i2, s2) = next(it1, end), next(it2, end)
+        while i1 > -1 or i2 > -1:
+            if s1 >= s2:
+                yield i1, s1
+                i1, s1 = next(it1, end)
+            else:
+                yield i2, s2
+                i2, s2 = next(it2, end)
+
+    def top_k_remaining(self, top_k: int) -> Tuple[np.ndarray, np.ndarray]:
+        idxs, vals = [], []
+        for i, (idx, val) in enumerate(self.iter_desc()):
+            if i >= top_k:
+                break
+            idxs.append(idx)
+            vals.append(val)
+        return np.array(idxs), np.array(vals)
+
+    def probability_bound(self, n):
+        idxs = np.asarray(self.dataset.remaining_indices(), dtype=np.int64)
+        return np.max((self.gamma[idxs] + n + self.numerators[idxs]) / (1 + n + self.denominators[idxs]))
+
+    # ---- the look-ahead on the GPU --------------------------------------------------------------
+    def regular_degree(self) -> int:
+        deltas = np.diff(self.matrix.indptr)
+        assert (deltas == deltas[0]).all(), "the vectorised look-ahead needs the same number of neighbours for every node"
+        return int(deltas[0])
+
+    def top_sum(self, K: int, return_values: bool = False):
+        """_top_sum (efficient_nonmyopic_search.py:94-169) for the current state: value of labelling every node next,
+        K further picks into the future.  -> (best index, best value[, all values])"""
+        D = self.regular_degree()
+        N = self.matrix.shape[0]
+        h = self._gpu.get("handle")
+        if h is None:
+            nbr = np.ascontiguousarray(np.sort(self.matrix.indices.reshape(-1, D)), dtype=np.int32)
+            h = ctypes.c_void_p()
+            _lib.call("ssw_lknn_create", int(self.device), N, D, ctypes.c_void_p(nbr.ctypes.data), ctypes.byref(h))
+            self._gpu["handle"] = h
+            self._gpu["owner"] = _Handle(h)
+        numer = self.numerators + self.gamma
+        denom = self.denominators + 1
+        seen = np.asarray(self.dataset.seen_indices, dtype=np.int64)
+        numer[seen] = -math.inf  # will rank lowest
+        assert (numer <= denom).all()
+        scores = numer / denom
+        L = K + D
+        part = np.argpartition(-scores, L - 1)[:L]          # the K + D best, then ordered: O(N) instead of a full sort
+        top = part[np.argsort(-scores[part], kind="stable")].astype(np.int32)
+        numer, denom = np.ascontiguousarray(numer), np.ascontiguousarray(denom)
+        values = np.empty(N, dtype=np.float64) if return_values else None
+        best_i, best_v = ctypes.c_int64(-1), ctypes.c_double(0.0)
+        _lib.call("ssw_lknn_top_sum", h, ctypes.c_void_p(numer.ctypes.data), ctypes.c_void_p(denom.ctypes.data),
+                  ctypes.c_void_p(top.ctypes.data), int(K), None if values is None else ctypes.c_void_p(values.ctypes.data),
+                  ctypes.byref(best_i), ctypes.byref(best_v))
+        return (int(best_i.value), float(best_v.value), values) if return_values else (int(best_i.value), float(best_v.value))
+
+
+class _Handle:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            _lib.load().ssw_lknn_destroy(self.h)
+        except Exception:
+            pass

@@ -1,9 +1,9 @@
-"""name -> loop class (seesaw/loops/registry.py:7-37).  The active-search planners
-(`active_search`, `lknn`) and `multi_reg_neg` of the reference are outside the accelerated
-hot path and are not registered."""
+"""name -> loop class (seesaw/loops/registry.py:7-37).  `multi_reg_neg` of the reference is outside the
+accelerated hot path and is not registered."""
 
 
 def build_loop_from_params(gdm, q, params):
+    from .active_search import ActiveSearch, LKNNSearch
     from .graph_based import KnnProp2
     from .log_reg import LogReg2
     from .multi_reg import MultiReg
@@ -20,6 +20,8 @@ def build_loop_from_params(gdm, q, params):
         "multi_reg": MultiReg,
         "rocchio_update": RocchioUpdate,
         "random": RandomResults,
+        "active_search": ActiveSearch,
+        "lknn": LKNNSearch,
     }
     cls = cls_dict.get(params.interactive)
     if cls is None:
