@@ -32,22 +32,41 @@ except ImportError:
         return np.unique(arr)
 
     class _IntSet:
-        __slots__ = ("_v",)
+        """two interchangeable representations, each built from the other on demand: a sorted int64 array
+        (`_v`: ordered iteration, rank, numpy set algebra) and a python set (`_s`: O(1) membership / add -- the
+        session's bookkeeping adds one id at a time, every round)"""
+        __slots__ = ("_arr", "_set")
 
         def __init__(self, values: Iterable[int] = None):
-            self._v = _as_sorted(values)
+            self._arr = _as_sorted(values)
+            self._set = None
+
+        @property
+        def _v(self) -> np.ndarray:
+            if self._arr is None:
+                self._arr = np.fromiter(self._set, dtype=np.int64, count=len(self._set))
+                self._arr.sort()
+            return self._arr
+
+        @property
+        def _s(self) -> set:
+            if self._set is None:
+                self._set = set(self._arr.tolist())
+            return self._set
 
         # ---- queries
         def __len__(self):
-            return int(self._v.shape[0])
+            return len(self._set) if self._arr is None else int(self._arr.shape[0])
 
         def __iter__(self):
             return iter(self._v.tolist())
 
         def __contains__(self, x):
             x = int(x)
-            i = np.searchsorted(self._v, x)
-            return bool(i < self._v.shape[0] and self._v[i] == x)
+            if self._set is not None:
+                return x in self._set
+            i = np.searchsorted(self._arr, x)
+            return bool(i < self._arr.shape[0] and self._arr[i] == x)
 
         def __array__(self, dtype=None, copy=None):
             return self._v if dtype is None else self._v.astype(dtype)
@@ -81,7 +100,8 @@ except ImportError:
         # ---- algebra (results keep the left operand's type)
         def _new(self, arr):
             out = type(self).__new__(type(self))
-            out._v = arr
+            out._arr = arr
+            out._set = None
             return out
 
         def union(self, *others):
@@ -114,27 +134,32 @@ except ImportError:
         __sub__ = difference
 
         def copy(self):
-            return self._new(self._v.copy())
+            out = self._new(None if self._arr is None else self._arr.copy())
+            out._set = None if self._set is None else set(self._set)
+            return out
 
     class FrozenBitMap(_IntSet):
         """immutable"""
 
     class BitMap(_IntSet):
         def add(self, x):
+            s = self._s
             x = int(x)
-            i = np.searchsorted(self._v, x)
-            if not (i < self._v.shape[0] and self._v[i] == x):
-                self._v = np.insert(self._v, i, x)
+            if x not in s:
+                s.add(x)
+                self._arr = None  # rebuilt (sorted) when an ordered view is next asked for
 
         def update(self, *others):
             for o in others:
-                self._v = np.union1d(self._v, _as_sorted(o))
+                self._arr = np.union1d(self._v, _as_sorted(o))
+                self._set = None
 
         def discard(self, x):
+            s = self._s
             x = int(x)
-            i = np.searchsorted(self._v, x)
-            if i < self._v.shape[0] and self._v[i] == x:
-                self._v = np.delete(self._v, i)
+            if x in s:
+                s.discard(x)
+                self._arr = None
 
         def remove(self, x):
             if x not in self:
@@ -142,6 +167,7 @@ except ImportError:
             self.discard(x)
 
         def clear(self):
-            self._v = np.zeros(0, dtype=np.int64)
+            self._arr = np.zeros(0, dtype=np.int64)
+            self._set = None
 
         __hash__ = None  # mutable

@@ -25,6 +25,7 @@
 // 513-float vectors (pure latency, no bandwidth).  Bound: launch/sync latency, not HBM --
 // nothing here is GEMM-shaped enough for MFMA.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
                                                    const float *__restrict__ w_or_null, FbW wv,
                                                    const float *__restrict__ qhat,
                                                    const float *__restrict__ xlx, FbObjDev obj,
-                                                   float *__restrict__ out, double *__restrict__ out_loss) {
+                                                   float *__restrict__ out, double *__restrict__ out_loss,
+                                                   unsigned *__restrict__ done_flag, unsigned seqno) {
     __shared__ double red[1024], red2[1024], red3[1024], red4[1024];
     __shared__ float sw_[1024];
     __shared__ double scal[8];
@@ -415,6 +417,15 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
         parts[2] = (float)p_query;
         parts[3] = (float)data_loss;
     }
+    // completion signal for the host's spin-wait (cheaper than waking up from hipStreamSynchronize, which costs
+    // ~10 us per closure evaluation): every thread's result stores are released to the system, then one flag word
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (c == 0) {
+            __hip_atomic_store(done_flag, seqno, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
@@ -441,6 +452,8 @@ struct ssw_fb {
     float *out_host = nullptr;  // pinned mirror
     float *out_host_dev = nullptr;     // the same memory through the device's address space
     double *loss_host_dev = nullptr;
+    unsigned *flag_host = nullptr, *flag_host_dev = nullptr;  // mapped pinned completion word of the closure evaluation
+    unsigned seqno = 0;
     float *w_host = nullptr;    // pinned staging
     hipStream_t stream = nullptr;
     // targets (host copies, for the objective set-up)
@@ -646,9 +659,25 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim,
                        by_arg ? (const float *)nullptr : (const float *)fb->w, wv,
                        fb->has_q ? fb->qhat : (const float *)nullptr, fb->has_xlx ? fb->xlx : (const float *)nullptr,
-                       dev, fb->out_host_dev, fb->loss_host_dev);
+                       dev, fb->out_host_dev, fb->loss_host_dev, fb->flag_host_dev, ++fb->seqno);
     SSW_HIP_TRY(hipGetLastError());
-    SSW_HIP_TRY(hipStreamSynchronize(s));
+    {   // spin on the completion word (the results are in host memory when it flips); the stream wait is the fallback
+        const unsigned want = fb->seqno;
+        bool seen = false;
+        if (!getenv("SSW_FB_NO_SPIN")) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned it = 0;; ++it) {
+                if (__atomic_load_n(fb->flag_host, __ATOMIC_ACQUIRE) == want) {
+                    seen = true;
+                    break;
+                }
+                if ((it & 1023u) == 1023u &&
+                    std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                    break;  // long evaluation (thousands of rows): sleep in the runtime instead
+            }
+        }
+        if (!seen) SSW_HIP_TRY(hipStreamSynchronize(s));
+    }
     fb->last_evals++;
     return SSW_OK;
 }
@@ -834,6 +863,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     if (fb->loss_host) (void)hipHostFree(fb->loss_host);
     if (fb->out_host) (void)hipHostFree(fb->out_host);
     if (fb->w_host) (void)hipHostFree(fb->w_host);
+    if (fb->flag_host) (void)hipHostFree(fb->flag_host);
     if (fb->stream) (void)hipStreamDestroy(fb->stream);
     delete fb;
     return SSW_OK;
@@ -865,13 +895,15 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipMalloc((void **)&fb->loss_dev, sizeof(double)) != hipSuccess ||
         hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&fb->flag_host, 64, hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->w_host, (size_t)(dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("feedback: allocation failed");
         ssw_fb_destroy(fb);
         return SSW_ERR_NOMEM;
     }
     if (hipHostGetDevicePointer((void **)&fb->out_host_dev, fb->out_host, 0) != hipSuccess ||
-        hipHostGetDevicePointer((void **)&fb->loss_host_dev, fb->loss_host, 0) != hipSuccess) {
+        hipHostGetDevicePointer((void **)&fb->loss_host_dev, fb->loss_host, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&fb->flag_host_dev, fb->flag_host, 0) != hipSuccess) {
         set_error("feedback: pinned host memory is not mapped into the device address space");
         ssw_fb_destroy(fb);
         return SSW_ERR_HIP;

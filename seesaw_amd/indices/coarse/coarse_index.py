@@ -17,7 +17,7 @@ import pandas as pd
 from ...bitmap import BitMap, FrozenBitMap
 from ...device_index import DeviceIndex
 from ...query_interface import AccessMethod, InteractiveQuery
-from ..interface import resolve_path
+from ..interface import ActivationFrames, resolve_path
 
 
 def _positions_of(sorted_dbidx: np.ndarray, ids) -> np.ndarray:
@@ -82,9 +82,10 @@ class CoarseIndex(AccessMethod):
             pos, scores, _ = self._dev.topk(vector, topk, excluded=excl_pos)
         ret = self._dbidx[pos]
         assert ret.shape[0] == topk
-        acts = [pd.DataFrame.from_records([dict(x1=0, y1=0, x2=224, y2=224, dbidx=d, score=s)])
-                for s, d in zip(scores, ret)]
-        return {"dbidxs": ret, "nextstartk": len(exclude) + ret.shape[0], "activations": acts}
+        # one whole-image box per result (coarse_index.py:88-93), as lazily built one-row frames
+        boxes = np.tile(np.array([[0, 0, 224, 224]], dtype=np.int64), (ret.shape[0], 1))
+        return {"dbidxs": ret, "nextstartk": len(exclude) + ret.shape[0],
+                "activations": ActivationFrames(boxes, ret, np.asarray(scores))}
 
     def new_query(self):
         return CoarseQuery(self)

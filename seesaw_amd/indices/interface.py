@@ -29,6 +29,47 @@ def _not_here(what: str):
     return stub
 
 
+class ActivationFrames:
+    """the `activations` entry of a query result: one one-row DataFrame [x1, y1, x2, y2, dbidx, score] per returned
+    image, as the reference builds them (multiscale_index.py:389-392) -- materialised only when somebody indexes or
+    iterates.  A pandas frame costs ~150 us to construct; the session layer, the one consumer on the interactive
+    path, only wants the numbers (`records()`), so a batch-size-1 round no longer builds a frame at all."""
+
+    _COLS = ["x1", "y1", "x2", "y2", "dbidx", "score"]
+
+    def __init__(self, boxes, dbidx, scores):
+        self._boxes, self._dbidx, self._scores = np.asarray(boxes), np.asarray(dbidx), np.asarray(scores)
+        self._frames = {}
+
+    def __len__(self):
+        return int(self._dbidx.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        f = self._frames.get(i)
+        if f is None:
+            import pandas as pd
+            b = self._boxes[i]
+            f = self._frames[i] = pd.DataFrame({"x1": [b[0]], "y1": [b[1]], "x2": [b[2]], "y2": [b[3]],
+                                                "dbidx": [self._dbidx[i]], "score": [self._scores[i]]})
+        return f
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def records(self):
+        """[(x1, y1, x2, y2, score)] as python floats"""
+        b = self._boxes.astype(np.float64)
+        s = self._scores.astype(np.float64)
+        return [(float(b[i, 0]), float(b[i, 1]), float(b[i, 2]), float(b[i, 3]), float(s[i])) for i in range(len(self))]
+
+
 class AccessMethod:
     path: str = None
 

@@ -24,7 +24,7 @@ from ...device_index import DeviceIndex
 from ...labeldb import LabelDB
 from ...query_interface import AccessMethod, InteractiveQuery
 from ..coarse.coarse_index import _positions_of
-from ..interface import resolve_path
+from ..interface import ActivationFrames, resolve_path
 
 _ACT_COLS = ["x1", "y1", "x2", "y2", "dbidx", "score"]
 
@@ -105,6 +105,28 @@ def rescore_candidates(fullmeta: pd.DataFrame, topk: int, **kwargs):
     dbscores = np.asarray(dbscores, dtype=np.float64)
     top = np.argsort(-dbscores, kind="stable")[:topk]
     return {"dbidxs": dbidxs[top].astype("int"), "activations": [activations[i] for i in top]}
+
+
+class _Candidates:
+    """what _query_prelim hands to the second stage: the reference's two-column frame (dbidx, max_score) as plain
+    arrays plus the image positions and best rows that came back with the selection; `.df` builds the DataFrame
+    for callers that want the reference's return type"""
+    __slots__ = ("dbidx", "max_score", "attrs", "_df")
+
+    def __init__(self, dbidx, max_score, positions, best_rows):
+        self.dbidx, self.max_score = dbidx, max_score
+        self.attrs = {"positions": positions, "best_rows": best_rows}
+        self._df = None
+
+    @property
+    def df(self) -> pd.DataFrame:
+        if self._df is None:
+            self._df = pd.DataFrame({"dbidx": self.dbidx, "max_score": self.max_score})
+            self._df.attrs.update(self.attrs)
+        return self._df
+
+    def __len__(self):
+        return len(self.dbidx)
 
 
 class MultiscaleIndex(AccessMethod):
@@ -190,6 +212,11 @@ class MultiscaleIndex(AccessMethod):
     def _query_prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
         """top `topk_dbidx` distinct non-excluded images by their best tile: DataFrame
         (dbidx, max_score) in descending score order (multiscale_index.py:291-312)."""
+        cand = self._prelim(vector=vector, topk_dbidx=topk_dbidx, exclude_dbidx=exclude_dbidx, force_exact=force_exact)
+        return cand if isinstance(cand, tuple) else cand.df
+
+    def _prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
+        """_query_prelim without the DataFrame (query() consumes the arrays directly)"""
         excl_pos = self._excluded_positions(exclude_dbidx)
         n_included = self._dbidx.shape[0] - excl_pos.shape[0]
         topk_dbidx = min(int(topk_dbidx), n_included)
@@ -198,10 +225,7 @@ class MultiscaleIndex(AccessMethod):
             return [], [], []
         pos, scores, best_rows = self._dev.topk(vector, topk_dbidx, excluded=excl_pos)
         self._resident_q = np.asarray(vector, dtype=np.float32).reshape(-1).copy()
-        df = pd.DataFrame({"dbidx": self._dbidx[pos], "max_score": scores})
-        df.attrs["positions"] = pos
-        df.attrs["best_rows"] = best_rows
-        return df
+        return _Candidates(self._dbidx[pos], scores, pos, best_rows)
 
     def topk_from_scores(self, row_scores: np.ndarray, *, topk_dbidx, exclude_dbidx=None, skip_rows=None):
         """same selection as _query_prelim but ranking by caller-supplied per-row scores
@@ -234,12 +258,9 @@ class MultiscaleIndex(AccessMethod):
 
     def _activations_from_best(self, candidate_df: pd.DataFrame, topk: int):
         rows = np.asarray(candidate_df.attrs["best_rows"][:topk], dtype=np.int64)
-        scores = candidate_df.max_score.values[:topk]
-        acts = []
-        for r, sc in zip(rows, scores):
-            acts.append(pd.DataFrame({"x1": [self._box[r, 0]], "y1": [self._box[r, 1]], "x2": [self._box[r, 2]],
-                                      "y2": [self._box[r, 3]], "dbidx": [self._row_dbidx[r]], "score": [sc]}))
-        return {"dbidxs": candidate_df.dbidx.values[:topk].astype("int"), "activations": acts}
+        scores = np.asarray(candidate_df.max_score)[:topk]
+        return {"dbidxs": np.asarray(candidate_df.dbidx)[:topk].astype("int"),
+                "activations": ActivationFrames(self._box[rows], self._row_dbidx[rows], scores)}
 
     def _candidate_rows(self, positions: np.ndarray) -> np.ndarray:
         positions = np.sort(np.asarray(positions, dtype=np.int64))
@@ -252,8 +273,8 @@ class MultiscaleIndex(AccessMethod):
         if shortlist_size < topk * 5:
             print(f"Warning: shortlist_size parameter {shortlist_size} is small compared to topk param {topk}, "
                   "you may consider increasing it")
-        candidate_df = self._query_prelim(vector=vector, topk_dbidx=shortlist_size, exclude_dbidx=exclude,
-                                          force_exact=force_exact)
+        candidate_df = self._prelim(vector=vector, topk_dbidx=shortlist_size, exclude_dbidx=exclude,
+                                    force_exact=force_exact)
         if isinstance(candidate_df, tuple):  # nothing left to return
             return {"dbidxs": np.zeros(0, dtype="int"), "activations": []}
         if vector2 is None and kwargs.get("agg_method") == "plain_score":
@@ -283,10 +304,8 @@ class MultiscaleIndex(AccessMethod):
             minus = self._dev.score_rows(vector2, self._candidate_rows(positions))
         scores, rows = self._dev.rescore_avg(positions, aug_larger, minus)
         top = np.argsort(-scores.astype(np.float64))[:topk]
-        acts = [pd.DataFrame({"x1": [self._box[r, 0]], "y1": [self._box[r, 1]], "x2": [self._box[r, 2]],
-                              "y2": [self._box[r, 3]], "dbidx": [self._row_dbidx[r]], "score": [sc]})
-                for r, sc in zip(rows[top], scores[top])]
-        return {"dbidxs": self._dbidx[positions[top]].astype("int"), "activations": acts}
+        return {"dbidxs": self._dbidx[positions[top]].astype("int"),
+                "activations": ActivationFrames(self._box[rows[top]], self._row_dbidx[rows[top]], scores[top])}
 
     def new_query(self):
         return BoxFeedbackQuery(self)
@@ -363,4 +382,4 @@ class BoxFeedbackQuery(InteractiveQuery):
         matched = self._matched_fast(target_description=target_description)
         if get_positions:
             return matched.index[matched.ys > 0].values, matched.index[matched.ys == 0].values
-        return matched[["dbidx", "ys", "max_iou"]]
+        return matched  # built with exactly the columns dbidx, ys, max_iou

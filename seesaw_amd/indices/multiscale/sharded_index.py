@@ -29,7 +29,8 @@ import pandas as pd
 
 from ...bitmap import BitMap
 from ...sharded import ShardedTopK, _DevArray, shard_bounds_by_image
-from .multiscale_index import MultiscaleIndex
+from ..interface import ActivationFrames
+from .multiscale_index import MultiscaleIndex, _Candidates
 
 
 def encode_keys(scores: np.ndarray, ids: np.ndarray) -> np.ndarray:
@@ -132,7 +133,7 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         self._dev = None  # there is no whole-matrix device index
 
     # ---- stage 1 ------------------------------------------------------------------------
-    def _query_prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
+    def _prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
         import torch
         excl_pos = self._excluded_positions(exclude_dbidx)
         n_included = self._dbidx.shape[0] - excl_pos.shape[0]
@@ -166,10 +167,7 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         pos, scores = decode_keys(merged)
         best_rows = x.best_rows_of(merged)
         self._resident_q = np.asarray(vector, dtype=np.float32).reshape(-1).copy()
-        df = pd.DataFrame({"dbidx": self._dbidx[pos], "max_score": scores})
-        df.attrs["positions"] = pos
-        df.attrs["best_rows"] = best_rows
-        return df
+        return _Candidates(self._dbidx[pos], scores, pos, best_rows)
 
     # ---- stage 2 ------------------------------------------------------------------------
     def _owned(self, positions: np.ndarray) -> np.ndarray:
@@ -221,16 +219,14 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         return self._activations(positions[top], rows[top], scores[top])
 
     def _activations(self, positions, rows, scores):
-        acts = [pd.DataFrame({"x1": [self._box[r, 0]], "y1": [self._box[r, 1]], "x2": [self._box[r, 2]],
-                              "y2": [self._box[r, 3]], "dbidx": [self._row_dbidx[r]], "score": [sc]})
-                for r, sc in zip(rows, scores)]
-        return {"dbidxs": self._dbidx[positions].astype("int"), "activations": acts}
+        return {"dbidxs": self._dbidx[positions].astype("int"),
+                "activations": ActivationFrames(self._box[rows], self._row_dbidx[rows], np.asarray(scores))}
 
     def query(self, *, vector, vector2=None, topk, shortlist_size, exclude=None, force_exact=False, **kwargs):
         if shortlist_size is None:
             shortlist_size = topk * 5
-        candidate_df = self._query_prelim(vector=vector, topk_dbidx=shortlist_size, exclude_dbidx=exclude,
-                                          force_exact=force_exact)
+        candidate_df = self._prelim(vector=vector, topk_dbidx=shortlist_size, exclude_dbidx=exclude,
+                                    force_exact=force_exact)
         if isinstance(candidate_df, tuple):
             return {"dbidxs": np.zeros(0, dtype="int"), "activations": []}
         agg_method = kwargs.get("agg_method")

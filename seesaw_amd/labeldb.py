@@ -37,7 +37,9 @@ class LabelDB:
         dbidx = int(dbidx)
         if dbidx not in self.ldata:
             return None  # never shown
-        boxes = self.ldata[dbidx] or []
+        boxes = self.ldata[dbidx]
+        if boxes is None:
+            boxes = []
         if format == "box":
             return boxes
         if format == "binary":

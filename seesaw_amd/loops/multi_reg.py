@@ -68,8 +68,9 @@ class RegModule:
         y [n] in {0,1}, matchdf with a `dbidx` column (sample weight = 1 / #vectors of the image)."""
         n = len(y)
         if n > 0:
-            counts = matchdf.groupby("dbidx").dbidx.transform("size").values.astype(np.float64)
-            vec_weight = 1.0 / counts
+            # 1 / (vectors of the same image): matchdf.groupby('dbidx').size() merged back (multi_reg.py:163-165)
+            _, inv, cnt = np.unique(matchdf.dbidx.values, return_inverse=True, return_counts=True)
+            vec_weight = 1.0 / cnt[inv].astype(np.float64)
             if X is not None:
                 self._engine.set_data(X, center=True)
             else:

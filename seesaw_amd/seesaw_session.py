@@ -125,12 +125,17 @@ class Session:
         if hit is None:
             urls = self.dataset.get_urls(idxbatch)
             acts = []
-            for i in range(len(idxbatch)):
-                if activation_batch is None or len(activation_batch) == 0:
-                    acts.append(None)
-                    continue
-                vals = activation_batch[i][["x1", "y1", "x2", "y2", "score"]].to_numpy(dtype=np.float64).tolist()
-                acts.append([ActivationData(box=Box(x1=v[0], y1=v[1], x2=v[2], y2=v[3]), score=v[4]) for v in vals])
+            if hasattr(activation_batch, "records") and len(activation_batch) == len(idxbatch):
+                # the index's own result object: numbers straight from its arrays, no DataFrame in between
+                acts = [[ActivationData(box=Box(x1=v[0], y1=v[1], x2=v[2], y2=v[3]), score=v[4])]
+                        for v in activation_batch.records()]
+            else:
+                for i in range(len(idxbatch)):
+                    if activation_batch is None or len(activation_batch) == 0:
+                        acts.append(None)
+                        continue
+                    vals = activation_batch[i][["x1", "y1", "x2", "y2", "score"]].to_numpy(dtype=np.float64).tolist()
+                    acts.append([ActivationData(box=Box(x1=v[0], y1=v[1], x2=v[2], y2=v[3]), score=v[4]) for v in vals])
             hit = cache[key] = (idxbatch, urls, acts)  # keeps idxbatch alive so its id stays unique
         return hit[1], hit[2]
 
@@ -138,10 +143,21 @@ class Session:
         urls, acts = self._static_panel(idxbatch, activation_batch)
         db = self.label_db if prefill else self.q.label_db
         out = []
+        cache = self.__dict__.setdefault("_imdata_cache", {})
         for url, dbidx, activations in zip(urls, idxbatch, acts):
             dbidx = int(dbidx)
-            out.append(Imdata.model_construct(url=url, dbidx=dbidx, boxes=db.get(dbidx, format="box"),
-                                              activations=activations, timing=self.image_timing.get(dbidx, [])))
+            boxes, timing = db.get(dbidx, format="box"), self.image_timing.get(dbidx, None)
+            # get_state() is called every round and walks every batch so far: the record of an image whose
+            # boxes / timing objects have not been replaced since the last call is reused as it is
+            hit = cache.get((dbidx, prefill))
+            if hit is not None and hit[0] is boxes and hit[1] is timing:
+                out.append(hit[2])
+                continue
+            im = Imdata.model_construct(url=url, dbidx=dbidx, boxes=boxes, activations=activations,
+                                        timing=[] if timing is None else timing)
+            if boxes is not None:  # (None = never shown: db.get builds nothing to key on)
+                cache[(dbidx, prefill)] = (boxes, timing, im)
+            out.append(im)
         return out
 
     def _update_labeldb(self, state: SessionState):
