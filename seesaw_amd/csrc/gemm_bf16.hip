@@ -384,6 +384,208 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves of 128 x 64 (2 x 4), phase-interleaved K loop  (variant 9)
+// ---------------------------------------------------------------------------------------
+// Why: in the 128 x 128 kernel above a wave owns 64 x 32 outputs and reads 12 fragments (ds_read_b128, 1 KiB each)
+// per 16 MFMAs; at 16 waves per CU that is 1536 LDS clocks per K-step against 1024 MFMA clocks per SIMD -- the loop
+// is bound by LDS read bandwidth (128 B/clk/CU), not by the matrix cores.  A wave that owns 128 x 64 reads 24
+// fragments per 64 MFMAs (0.375 per MFMA): 1536 LDS clocks against 2048 MFMA clocks.
+//
+// One workgroup per CU (128 KiB of LDS: two stages of {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255},
+// each a 128-row x 128-B image in the swizzled layout of the kernel above).  Wave (wr, wc) reads only A half wr and
+// W half wc >> 1.  A K-tile is four phases of 16 MFMAs (quadrants of the wave's 128 x 64: (lo,0) (lo,1) (hi,1)
+// (hi,0)); the W fragments of both column halves stay in registers, so a stage's W halves are free after phase 2
+// and its A halves after phase 3, and the next-but-one tile is restaged half by half while the current one
+// multiplies:
+//     phase 1: read A_lo, W_0          issue A1(kt+1)                                   MFMA (lo,0)
+//     phase 2: read W_1                                           lgkm(0), barrier      MFMA (lo,1)
+//     phase 3: read A_hi               issue W0(kt+2)             lgkm(0), barrier      MFMA (hi,1)
+//     phase 4:                         issue W1(kt+2), A0(kt+2)   vmcnt(6), barrier     MFMA (hi,0)
+// vmcnt(6) at phase 4 retires everything up to A1(kt+1) -- the three half-tiles issued after it stay in flight --
+// and the barrier behind it makes tile kt+1 readable in the next phase 1 (read one phase AFTER the wait that
+// retires the data).  WAR: a half is restaged only after a barrier that follows its last fragment reads
+// (W: phases 1-2 -> barrier of phase 2; A: phases 1 and 3 -> barrier of phase 3).
+constexpr int T256_HALF = 16384;            // one half-tile image: 128 rows x 128 B
+constexpr int T256_STAGE = 4 * T256_HALF;   // A0 A1 W0 W1
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
+                                                const float *__restrict__ bias, const float *__restrict__ residual,
+                                                void *__restrict__ Cout, int M, int N, int K, int m_tiles, int n_tiles) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
+    if (mt >= m_tiles) return;
+    const int m0 = mt * 256, n0 = nt * 256;
+
+    // staging: half-tile = 16 pieces of 8 rows x 128 B; wave w issues pieces 2w and 2w+1 of every half
+    const bf16 *a_src[2], *w_src[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = (wave * 2 + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[p] = A + (int64_t)min(m0 + row, M - 1) * K + chunk * 8;
+        w_src[p] = W + (int64_t)(n0 + row) * K + chunk * 8;
+    }
+    // the second half's rows are 128 further down; clamp the A rows of the last row tile
+    const bf16 *a_src1[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = 128 + (wave * 2 + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src1[p] = A + (int64_t)min(m0 + row, M - 1) * K + chunk * 8;
+    }
+    const int64_t w_half = (int64_t)128 * K;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
+    const unsigned piece_dst = lds0 + wave * 2048;
+#define T256_ISSUE_A0(kt, st) { const int k0 = (kt) * BK; glds16(a_src[0] + k0, piece_dst + (st) * T256_STAGE); \
+                                 glds16(a_src[1] + k0, piece_dst + (st) * T256_STAGE + 1024); }
+#define T256_ISSUE_A1(kt, st) { const int k0 = (kt) * BK; glds16(a_src1[0] + k0, piece_dst + (st) * T256_STAGE + T256_HALF); \
+                                 glds16(a_src1[1] + k0, piece_dst + (st) * T256_STAGE + T256_HALF + 1024); }
+#define T256_ISSUE_W0(kt, st) { const int k0 = (kt) * BK; glds16(w_src[0] + k0, piece_dst + (st) * T256_STAGE + 2 * T256_HALF); \
+                                 glds16(w_src[1] + k0, piece_dst + (st) * T256_STAGE + 2 * T256_HALF + 1024); }
+#define T256_ISSUE_W1(kt, st) { const int k0 = (kt) * BK; glds16(w_src[0] + w_half + k0, piece_dst + (st) * T256_STAGE + 3 * T256_HALF); \
+                                 glds16(w_src[1] + w_half + k0, piece_dst + (st) * T256_STAGE + 3 * T256_HALF + 1024); }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wc * 64 + j * 16 + fq * 4;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_F32) bv = *reinterpret_cast<const f32x4 *>(bias + col);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i][j] = bv;
+    }
+    const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+    const int a_frag = wr * T256_HALF + frag0;                                        // + i * 2048, i = 0..7
+    const int w_frag = (2 + (wc >> 1)) * T256_HALF + (wc & 1) * 4 * 2048 + frag0;     // + j * 2048, j = 0..3
+#define T256_READ_A(st, half, dst)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+            dst[i][ks] = *reinterpret_cast<const bf16x8 *>(smem + (st) * T256_STAGE + ((a_frag + ((half) * 4 + i) * 2048) ^ (ks * 64)));
+#define T256_READ_W(st, half, dst)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+            dst[j][ks] = *reinterpret_cast<const bf16x8 *>(smem + (st) * T256_STAGE + ((w_frag + ((half) * 2 + j) * 2048) ^ (ks * 64)));
+#define T256_MFMA(ahalf, a, whalf, b)                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                acc[(ahalf) * 4 + i][(whalf) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(         \
+                    b[j][ks], a[i][ks], acc[(ahalf) * 4 + i][(whalf) * 2 + j], 0, 0, 0);                  \
+    __builtin_amdgcn_s_setprio(0);
+#define T256_LGKM0_BARRIER()                                                                             \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                 \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");
+
+    asm volatile("" ::"s"(bias), "s"(residual), "s"(Cout), "s"(N));
+    const int nk = K / BK;
+    // prologue: tile 0 complete, then W0 W1 A0 of tile 1 (what phases 3-4 of a tile "-1" would have issued)
+    T256_ISSUE_A0(0, 0) T256_ISSUE_A1(0, 0) T256_ISSUE_W0(0, 0) T256_ISSUE_W1(0, 0)
+    if (nk > 1) {
+        T256_ISSUE_W0(1, 1) T256_ISSUE_W1(1, 1) T256_ISSUE_A0(1, 1)
+        wait_vmcnt<6>();
+    } else {
+        wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1, ot = st ^ 1;
+        // phase 1
+        T256_READ_A(st, 0, a)
+        T256_READ_W(st, 0, b0)
+        if (kt + 1 < nk) T256_ISSUE_A1(kt + 1, ot)
+        __builtin_amdgcn_sched_barrier(0);
+        T256_MFMA(0, a, 0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2
+        T256_READ_W(st, 1, b1)
+        T256_LGKM0_BARRIER()      // every wave's W reads of this stage are done
+        T256_MFMA(0, a, 1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3
+        T256_READ_A(st, 1, a)
+        if (kt + 2 < nk) T256_ISSUE_W0(kt + 2, st)
+        T256_LGKM0_BARRIER()      // every wave's A reads of this stage are done
+        T256_MFMA(1, a, 1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 4
+        if (kt + 2 < nk) {
+            T256_ISSUE_W1(kt + 2, st) T256_ISSUE_A0(kt + 2, st)
+            wait_vmcnt<6>();      // tile kt+1 has landed (its A1 was the oldest load still wanted)
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        T256_MFMA(1, a, 0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef T256_ISSUE_A0
+#undef T256_ISSUE_A1
+#undef T256_ISSUE_W0
+#undef T256_ISSUE_W1
+#undef T256_READ_A
+#undef T256_READ_W
+#undef T256_MFMA
+#undef T256_LGKM0_BARRIER
+
+    // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wr * 128 + i * 16 + fr;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wc * 64 + j * 16 + fq * 4;
+            const int64_t o = (int64_t)row * N + col;
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_BF16_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
+            }
+            if (EPI == EPI_F32_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4 *>(residual + o);
+            if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
+                bf16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
+                *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + o) = h;
+            } else {
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
+            }
+        }
+    }
+}
+
+template <int EPI>
+ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
+                      int N, int K) {
+    static bool attr_set = false;
+    constexpr int lds = 2 * T256_STAGE;
+    if (!attr_set) {
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_256<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
+    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    hipLaunchKernelGGL((gemm_256<EPI>), dim3(grid), dim3(512), lds, s, A, W, bias, res, C, M, N, K, m_tiles, n_tiles);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
 int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
@@ -414,8 +616,21 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
             SSW_HIP_TRY(hipGetLastError());
             return SSW_OK;
         case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
+        case 9:
+            if (N % 256 == 0) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K);
+            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
         case 2: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
-        default: return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
+        default: {
+            // the 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills the chip
+            // about twice or more: measured at M = 10 000 (profiles/r02_gemm_ab.txt) it wins on fc1 (480 tiles,
+            // 777 vs 674 TFLOP/s) and loses on QKV (360 tiles: 1.4 rounds) and on every N = 768 shape (120 tiles)
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
+            if (g_gemm_variant == 14 && N % 256 == 0 && 10 * tiles256 >= 18 * (int64_t)num_cus(dev))
+                return launch_256<EPI>(s, A, W, bias, res, C, M, N, K);
+            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
+        }
     }
 }
 
@@ -474,7 +689,7 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant != 0 && variant != 2 && variant != 7 && variant != 14) {
+    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15) {
         ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
         return SSW_ERR_INVALID;
     }
