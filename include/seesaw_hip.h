@@ -289,6 +289,11 @@ ssw_status ssw_fb_scores(ssw_fb *fb, const float *w_host, int32_t has_bias, floa
  * (the reference raises ValueError, logistic_regression.py:398-401). */
 ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, int32_t max_iter,
                       float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss);
+/* *out = 1 when the last ssw_fb_fit ran as ONE kernel launch (direction updates, line search and all closure
+ * evaluations inside one workgroup: labelled sets of up to 1024 rows, every objective except SSW_FB_RANKREG),
+ * 0 when the host drove one evaluation at a time (larger sets; or env SSW_FB_HOST_DRIVER).  Both walk the same
+ * path bit for bit. */
+ssw_status ssw_fb_last_fit_on_device(const ssw_fb *fb, int32_t *out);
 
 /* The pairwise rank losses on given scores (no data matrix): per-item column sums and d(sum)/d scores.
  * replaces ref_pairwise_rank_loss / ref_pairwise_logistic_loss(aggregate='sum') and

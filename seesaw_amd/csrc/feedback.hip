@@ -15,15 +15,19 @@
 // The reference evaluates the closure through Python autograd (with anomaly detection on)
 // up to 1.25 x max_iter times per refine; the math per evaluation is two skinny GEMVs
 // (n x 512, n = labelled tile vectors, up to ~10^4 with pseudo-labels) plus O(n^2) pairwise
-// terms.  Here one evaluation = 3-4 small kernels on rows that already sit in HBM:
-//   fb_logits   z = Xc w (+ b)                        wave per row, coalesced 16-B loads
-//   fb_pairwise per-item pairwise loss + dL/dz        one workgroup, z and targets in LDS
-//   fb_elem     per-item BCE loss + dL/dz             elementwise
-//   fb_grad     partial g = Xc' r per 32-row slab     thread per column, coalesced
-//   fb_final    fixed-order reduction of the partials + regulariser terms -> [loss, grad]
-// and the L-BFGS two-loop recursion / cubic-interpolation line search run on the host over
-// 513-float vectors (pure latency, no bandwidth).  Bound: launch/sync latency, not HBM --
-// nothing here is GEMM-shaped enough for MFMA.
+// terms.  Two drivers over the same arithmetic (bit-identical fits, tests/test_feedback_gpu.py):
+//   * n <= 1024 rows (every feedback session): k_fb_fit_wg -- the whole optimizer.step(closure), i.e. L-BFGS
+//     direction updates, strong-Wolfe line search and all closure evaluations, in ONE launch of one workgroup;
+//   * larger sets (PseudoLR's 10 000 pseudo-labelled rows) and the rank objective: the host walks the same
+//     state machine and launches one evaluation at a time = 3-4 small kernels on rows that already sit in HBM:
+//       fb_logits   z = Xc w (+ b)                        wave per row, coalesced 16-B loads
+//       fb_pairwise per-item pairwise loss + dL/dz        one workgroup, z and targets in LDS
+//       fb_elem     per-item BCE loss + dL/dz             elementwise
+//       fb_grad     partial g = Xc' r per 32-row slab     thread per column, coalesced
+//       fb_final    fixed-order reduction of the partials + regulariser terms -> [loss, grad]
+// Bound: issue / launch latency, not HBM -- nothing here is GEMM-shaped enough for MFMA.  Compiled with
+// -ffp-contract=off (Makefile): the host driver and the device driver must round alike, and the expressions that
+// are meant to be fused say fmaf.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -163,12 +167,10 @@ __global__ __launch_bounds__(256) void k_fb_logits_arg(const float *__restrict__
 // item_j = coef_j / max_inv_j * sum_i loss_ij, max_inv_j = #{i : t_ij != 0};
 // r_k = d(sum_j item_j)/dz_k.  One workgroup; z, y, c = coef/max_inv in LDS.
 template <int LOGISTIC>
-__global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ z,
-                                                      const float *__restrict__ y,
-                                                      const float *__restrict__ coef, float margin,
-                                                      int n, double *__restrict__ item_loss,
-                                                      float *__restrict__ r) {
-    extern __shared__ float sh[];
+__device__ __forceinline__ void fb_pairwise_body(const float *__restrict__ z, const float *__restrict__ y,
+                                                 const float *__restrict__ coef, float margin, int n,
+                                                 double *__restrict__ item_loss, float *__restrict__ r,
+                                                 float *sh /* LDS, 3 n floats */) {
     float *sz = sh, *sy = sh + n, *sc = sh + 2 * n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         sz[i] = z[i];
@@ -211,6 +213,16 @@ __global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ 
         item_loss[k] = (double)ck * loss_k;
         r[k] = (float)rk;
     }
+}
+
+template <int LOGISTIC>
+__global__ __launch_bounds__(1024) void k_fb_pairwise(const float *__restrict__ z,
+                                                      const float *__restrict__ y,
+                                                      const float *__restrict__ coef, float margin,
+                                                      int n, double *__restrict__ item_loss,
+                                                      float *__restrict__ r) {
+    extern __shared__ float sh[];
+    fb_pairwise_body<LOGISTIC>(z, y, coef, margin, n, item_loss, r, sh);
 }
 
 // RankingRegModule (logistic_regression.py:16-65): per-item "loss" |g_i| / total_pairs and the pseudo-gradient
@@ -258,50 +270,65 @@ struct FbObjDev {
     int exact;         // diagnostic (env SSW_FB_EXACT_LOSS): exact f64 loss values instead of torch's mixed f32/f64 rounding
 };
 
-// one workgroup of `dim` (<= 1024) threads: reduce partials in slab order, add the
-// regulariser terms, emit out[0] = loss, out[1 .. 1+P) = gradient, out[1+P ..] = parts
-__global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ partial, int nslabs,
-                                                   const double *__restrict__ item_loss,
-                                                   const float *__restrict__ r, int64_t n, int dim,
-                                                   const float *__restrict__ w_or_null, FbW wv,
-                                                   const float *__restrict__ qhat,
-                                                   const float *__restrict__ xlx, FbObjDev obj,
-                                                   float *__restrict__ out, double *__restrict__ out_loss,
-                                                   unsigned *__restrict__ done_flag, unsigned seqno) {
-    __shared__ double red[1024], red2[1024], red3[1024], red4[1024];
-    __shared__ float sw_[1024];
-    __shared__ double scal[8];
+// ---- reductions inside one full wave: row_shr 1, 2, 4, 8 (lane l takes lane l - s of its 16-lane row, rows'
+// first s lanes take 0), the four row totals (lanes 15, 31, 47, 63) added in ascending order
+template <int CTRL>
+__device__ __forceinline__ double dpp_take_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_take_d<0x111>(v);
+    v += dpp_take_d<0x112>(v);
+    v += dpp_take_d<0x114>(v);
+    v += dpp_take_d<0x118>(v);
+    return ((readlane_d(v, 15) + readlane_d(v, 31)) + readlane_d(v, 47)) + readlane_d(v, 63);
+}
+__device__ __forceinline__ double wave_max_d(double v) {  // v >= 0
+    v = fmax(v, dpp_take_d<0x111>(v));
+    v = fmax(v, dpp_take_d<0x112>(v));
+    v = fmax(v, dpp_take_d<0x114>(v));
+    v = fmax(v, dpp_take_d<0x118>(v));
+    return fmax(fmax(readlane_d(v, 15), readlane_d(v, 31)), fmax(readlane_d(v, 47), readlane_d(v, 63)));
+}
+
+struct FbFinalLds {
+    double *red;   // [64]  wave partials of the four-way sum
+    double *red2;  // [16]  wave partials of the single sums
+    float *sw_;    // [1024] parameters
+};
+
+// the body of the last evaluation step, shared by k_fb_final (one launch per evaluation, host-driven fit) and
+// k_fb_fit_wg (whole fit in one launch): `g` = this column's data gradient summed over the slabs in slab order,
+// `wc` = this column's parameter.  `out` / `out_loss` may point to LDS.
+__device__ __forceinline__ void fb_final_body(float g, const float wc, const double *__restrict__ item_loss,
+                                              const float *__restrict__ r, int64_t n, int dim,
+                                              const float *__restrict__ qhat, const float *__restrict__ xlx,
+                                              const FbObjDev &obj, float *out, double *out_loss, const FbFinalLds &L) {
+    double *red = L.red, *red2 = L.red2;
+    float *sw_ = L.sw_;
     const int c = threadIdx.x;
     const bool act = c < dim;
-    const float wc = act ? (w_or_null ? w_or_null[c] : wv.v[c < FB_ARG_FLOATS ? c : 0]) : 0.f;
     if (act) sw_[c] = wc;
-    // data gradient
-    float g = 0.f;
-    if (act)
-        for (int s = 0; s < nslabs; ++s) g += partial[(int64_t)s * dim + c];
     g *= obj.scale;
-    // block reductions: |w|^2, w.qhat, data loss, sum r.  Same association as the plain LDS tree
-    // (x[c] += x[c + s] for s = 512 ... 1): strides 512 ... 64 through LDS, strides 32 ... 1 inside wave 0
-    // by shuffles (lane c takes lane c + s), result broadcast through LDS; four sums share one pass.
-    auto tree = [&](double v, double *buf) -> double {
-        buf[c] = v;
-        __syncthreads();
-        for (int s = 512; s >= 64; s >>= 1) {
-            if (c < s) buf[c] += buf[c + s];
-            __syncthreads();
-        }
-        double x = c < 64 ? buf[c] : 0.0;
-        if (c < 64) {
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) x += __shfl_down(x, s, 64);
-        }
-        return x;  // valid in thread 0
-    };
+    // block reductions: |w|^2, w.qhat, data loss, sum r.  Inside each wave the DPP network of wave_sum_d (no LDS
+    // traffic), then the 16 wave totals added in ascending order by every thread; four sums share one barrier.
+    // (The first version walked an LDS tree with six barriers and 48 ds_bpermute per sum: 5 of the 6 us this
+    // step took.)
+    const int lane = c & 63, wave = c >> 6;
     auto block_sum = [&](double v) -> double {
-        const double x = tree(v, red);
-        if (c == 0) scal[0] = x;
+        const double wsum = wave_sum_d(v);
+        if (lane == 0) red2[wave] = wsum;
         __syncthreads();
-        const double o = scal[0];
+        double o = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) o += red2[w];
         __syncthreads();
         return o;
     };
@@ -312,55 +339,46 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
     }
     double ww, wq, data_loss, rsum;
     {
-        // four independent sums: one barrier schedule (the trees do not interact: separate buffers)
         const double v0 = act ? (double)wc * wc : 0.0, v1 = act && qhat ? (double)wc * qhat[c] : 0.0;
-        red[c] = v0;
-        red2[c] = v1;
-        red3[c] = ls;
-        red4[c] = rs;
-        __syncthreads();
-        for (int s = 512; s >= 64; s >>= 1) {
-            if (c < s) {
-                red[c] += red[c + s];
-                red2[c] += red2[c + s];
-                red3[c] += red3[c + s];
-                red4[c] += red4[c + s];
-            }
-            __syncthreads();
+        const double s0 = wave_sum_d(v0), s1 = wave_sum_d(v1), s2 = wave_sum_d(ls), s3 = wave_sum_d(rs);
+        if (lane == 0) {
+            red[4 * wave + 0] = s0;
+            red[4 * wave + 1] = s1;
+            red[4 * wave + 2] = s2;
+            red[4 * wave + 3] = s3;
         }
-        if (c < 64) {
-            double x0 = red[c], x1 = red2[c], x2 = red3[c], x3 = red4[c];
+        __syncthreads();
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) {
-                x0 += __shfl_down(x0, s, 64);
-                x1 += __shfl_down(x1, s, 64);
-                x2 += __shfl_down(x2, s, 64);
-                x3 += __shfl_down(x3, s, 64);
-            }
-            if (c == 0) {
-                scal[0] = x0;
-                scal[1] = x1;
-                scal[2] = x2;
-                scal[3] = x3;
-            }
+        for (int w = 0; w < 16; ++w) {
+            t0 += red[4 * w + 0];
+            t1 += red[4 * w + 1];
+            t2 += red[4 * w + 2];
+            t3 += red[4 * w + 3];
         }
-        __syncthreads();
-        ww = scal[0];
-        wq = scal[1];
-        data_loss = scal[2] * obj.scale;
-        rsum = scal[3] * obj.scale;
-        __syncthreads();
+        ww = t0;
+        wq = t1;
+        data_loss = t2 * obj.scale;
+        rsum = t3 * obj.scale;
     }
     const double norm = sqrt(ww);
     const double nclamp = norm > 1e-12 ? norm : 1e-12;  // F.normalize eps
-    double reg_loss = 0.0, p_norm = 0.0, p_data = 0.0, p_query = 0.0;
+    // From here on the scalar terms of the loss are formed by thread 0 only and waves that own no column leave
+    // once the last barrier is behind them: with all 16 waves walking the whole body its ~800 instructions, four
+    // waves deep on every SIMD, were most of this step's time.
     float greg = 0.f;
     if (obj.kind == 0) {
+        double d2 = 0.0;
         if (obj.reg_kind == 1) {
             // (|w| - 1)^2 + |w^ - q^|^2 ; |w^ - q^|^2 = w^.w^ - 2 w^.q^ + q^.q^  (q^ unit)
             const double what_c = wc / nclamp;
+            d2 = block_sum(act ? (what_c - qhat[c]) * (what_c - qhat[c]) : 0.0);
+        }
+        if (wave != 0 && wave * 64 >= dim) return;
+        double reg_loss = 0.0;
+        if (obj.reg_kind == 1) {
+            const double what_c = wc / nclamp;
             const double whq = wq / nclamp;
-            const double d2 = block_sum(act ? (what_c - qhat[c]) * (what_c - qhat[c]) : 0.0);
             reg_loss = (norm - 1.0) * (norm - 1.0) + d2;
             if (act) {
                 const double diff = what_c - qhat[c];
@@ -375,48 +393,86 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
         }
         reg_loss *= obj.reg_weight;
         greg *= obj.reg_weight;
-    } else {
-        // The three regulariser VALUES are rounded the way the reference's f32 tensors round them
-        // (multi_reg.py:125-129): the label loss is f64 there (float64 targets promote) but these terms are
-        // f32, and cosh(log s) - 1 near s = 1 moves in steps of 2^-23 -- times l_norm = 100 that is a 1.2e-5
-        // staircase in the total loss.  torch's L-BFGS stops / accepts line-search points on that staircase
-        // (|loss - prev_loss| < 1e-9, Armijo), so an exact f64 value here walks a different path and ends up to
-        // 7e-4 (rank scores) away from the reference's fit -- measured on tests/golden/multireg.npz c4.
-        // Gradients stay analytic (autograd's f32 sinh(log s)/s * 2w equals l (1 - 1/s^2) w to rounding).
-        // norm: l (cosh(log s) - 1), s = w.w ; d/dw = l (1 - 1/s^2) w
-        p_norm = obj.exact ? obj.l_norm * (0.5 * (ww + 1.0 / ww) - 1.0)
-                           : (double)(obj.l_norm * (coshf(logf((float)ww)) - 1.f));
-        // data: l w'Mw ; d/dw = l (M + M') w
-        double mw = 0.0, mtw = 0.0;
-        if (act && obj.l_data != 0.f && xlx) {
-            for (int k = 0; k < dim; ++k) {
-                mw += (double)xlx[(int64_t)c * dim + k] * sw_[k];
-                mtw += (double)xlx[(int64_t)k * dim + c] * sw_[k];
-            }
+        if (act) out[1 + c] = g + greg;
+        if (c == 0) {
+            out[0] = (float)(data_loss + reg_loss);
+            *out_loss = data_loss + reg_loss;
+            out[1 + dim] = obj.has_bias ? (float)rsum : 0.f;
+            float *parts = out + 1 + dim + 1;
+            parts[0] = 0.f;
+            parts[1] = 0.f;
+            parts[2] = 0.f;
+            parts[3] = (float)data_loss;
         }
-        p_data = obj.l_data * block_sum(act ? (double)wc * mw : 0.0);
-        if (!obj.exact) p_data = (double)(float)p_data;
+    } else {
+        // data: l w'Mw ; d/dw = l (M + M') w
+        double mw = 0.0, mtw = 0.0, p_data = 0.0;
+        if (obj.l_data != 0.f) {
+            if (act && xlx) {
+                for (int k = 0; k < dim; ++k) {
+                    mw += (double)xlx[(int64_t)c * dim + k] * sw_[k];
+                    mtw += (double)xlx[(int64_t)k * dim + c] * sw_[k];
+                }
+            }
+            p_data = obj.l_data * block_sum(act ? (double)wc * mw : 0.0);
+        }
+        if (wave != 0 && wave * 64 >= dim) return;
         // query: l (1 - w^.q^)/2 ; d/dw = -l/2 (q^ - (w^.q^) w^)/|w|
         const double whq = wq / nclamp;
-        p_query = obj.exact ? obj.l_query * (1.0 - whq) * 0.5 : (double)(obj.l_query * ((1.f - (float)whq) / 2.f));
         if (act) {
             const double what_c = wc / nclamp;
+            // norm: l (cosh(log s) - 1), s = w.w ; d/dw = l (1 - 1/s^2) w
             greg = (float)(obj.l_norm * (1.0 - 1.0 / (ww * ww)) * wc + obj.l_data * (mw + mtw) -
                            obj.l_query * 0.5 * ((qhat ? qhat[c] : 0.f) - whq * what_c) / nclamp);
+            out[1 + c] = g + greg;
         }
-        reg_loss = p_norm + p_data + p_query;
+        if (c == 0) {
+            // The three regulariser VALUES are rounded the way the reference's f32 tensors round them
+            // (multi_reg.py:125-129): the label loss is f64 there (float64 targets promote) but these terms are
+            // f32, and cosh(log s) - 1 near s = 1 moves in steps of 2^-23 -- times l_norm = 100 that is a 1.2e-5
+            // staircase in the total loss.  torch's L-BFGS stops / accepts line-search points on that staircase
+            // (|loss - prev_loss| < 1e-9, Armijo), so an exact f64 value here walks a different path and ends up to
+            // 7e-4 (rank scores) away from the reference's fit -- measured on tests/golden/multireg.npz c4.
+            // Gradients stay analytic (autograd's f32 sinh(log s)/s * 2w equals l (1 - 1/s^2) w to rounding).
+            const double p_norm = obj.exact ? obj.l_norm * (0.5 * (ww + 1.0 / ww) - 1.0)
+                                            : (double)(obj.l_norm * (coshf(logf((float)ww)) - 1.f));
+            if (!obj.exact) p_data = (double)(float)p_data;
+            const double p_query =
+                obj.exact ? obj.l_query * (1.0 - whq) * 0.5 : (double)(obj.l_query * ((1.f - (float)whq) / 2.f));
+            const double reg_loss = p_norm + p_data + p_query;
+            out[0] = (float)(data_loss + reg_loss);
+            *out_loss = data_loss + reg_loss;
+            out[1 + dim] = obj.has_bias ? (float)rsum : 0.f;
+            float *parts = out + 1 + dim + 1;
+            parts[0] = (float)p_norm;
+            parts[1] = (float)p_data;
+            parts[2] = (float)p_query;
+            parts[3] = (float)data_loss;
+        }
     }
-    if (act) out[1 + c] = g + greg;
-    if (c == 0) {
-        out[0] = (float)(data_loss + reg_loss);
-        *out_loss = data_loss + reg_loss;
-        out[1 + dim] = obj.has_bias ? (float)rsum : 0.f;
-        float *parts = out + 1 + dim + 1;
-        parts[0] = (float)p_norm;
-        parts[1] = (float)p_data;
-        parts[2] = (float)p_query;
-        parts[3] = (float)data_loss;
-    }
+}
+
+// one workgroup of 1024 threads (column c = thread c, dim <= 1024): reduce partials in slab order, add the
+// regulariser terms, emit out[0] = loss, out[1 .. 1+P) = gradient, out[1+P ..] = parts
+__global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ partial, int nslabs,
+                                                   const double *__restrict__ item_loss,
+                                                   const float *__restrict__ r, int64_t n, int dim,
+                                                   const float *__restrict__ w_or_null, FbW wv,
+                                                   const float *__restrict__ qhat,
+                                                   const float *__restrict__ xlx, FbObjDev obj,
+                                                   float *__restrict__ out, double *__restrict__ out_loss,
+                                                   unsigned *__restrict__ done_flag, unsigned seqno) {
+    __shared__ double red[64], red2[16];
+    __shared__ float sw_[1024];
+    const int c = threadIdx.x;
+    const bool act = c < dim;
+    const float wc = act ? (w_or_null ? w_or_null[c] : wv.v[c < FB_ARG_FLOATS ? c : 0]) : 0.f;
+    // data gradient
+    float g = 0.f;
+    if (act)
+        for (int s = 0; s < nslabs; ++s) g += partial[(int64_t)s * dim + c];
+    FbFinalLds L{red, red2, sw_};
+    fb_final_body(g, wc, item_loss, r, n, dim, qhat, xlx, obj, out, out_loss, L);
     // completion signal for the host's spin-wait (cheaper than waking up from hipStreamSynchronize, which costs
     // ~10 us per closure evaluation): every thread's result stores are released to the system, then one flag word
     if (done_flag) {
@@ -425,6 +481,674 @@ __global__ __launch_bounds__(1024) void k_fb_final(const float *__restrict__ par
         if (c == 0) {
             __hip_atomic_store(done_flag, seqno, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+    }
+}
+
+
+// minFunc's polyinterp restricted to two points with derivatives (torch.optim.lbfgs._cubic_interpolate)
+__host__ __device__ inline double cubic_interpolate_dev(double x1, double f1, double g1, double x2, double f2, double g2,
+                                                        bool has_bounds, double lo, double hi) {
+    double xmin = lo, xmax = hi;
+    if (!has_bounds) {
+        xmin = x1 <= x2 ? x1 : x2;
+        xmax = x1 <= x2 ? x2 : x1;
+    }
+    const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
+    const double d2sq = d1 * d1 - g1 * g2;
+    if (d2sq >= 0) {
+        const double d2 = sqrt(d2sq);
+        double mp;
+        if (x1 <= x2)
+            mp = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2));
+        else
+            mp = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2));
+        return fmin(fmax(mp, xmin), xmax);
+    }
+    return (xmin + xmax) / 2.0;
+}
+
+// ---- the whole fit in one launch --------------------------------------------------------------
+// k_fb_fit_wg: torch.optim.LBFGS(strong_wolfe).step(closure) -- direction update, line search and every closure
+// evaluation -- inside ONE workgroup, for labelled sets of up to FIT_WG_MAX_ROWS rows (a feedback session has
+// tens to hundreds).  The host-driven form (ssw_fb_fit's loop further down) pays three launches and a
+// host <-> device round trip per closure evaluation, ~27 us each and 80 % of a fit.  Here:
+//   * all 16 waves evaluate the closure: logits (a wave per row, eight rows in flight), label loss, gradient
+//     (column per thread, the two thread halves take alternate 32-row slabs), regulariser terms -- the bodies of
+//     the per-evaluation kernels, with z / r / item losses / targets / the query in LDS so that no phase waits
+//     for a global store to become visible; the only global traffic is two passes over the rows, which sit in L2;
+//   * wave 0 alone drives: the L-BFGS vectors live in LDS (element k in lane k % 64), reductions are DPP networks
+//     inside the wave -- no barrier and no memory round trip in the two-loop recursion; the history is the one
+//     structure too large for LDS (100 x 2 x 513 floats) and is prefetched from global one entry ahead.
+// The driver is the host loop of ssw_fb_fit (torch.optim.LBFGS.step + _strong_wolfe) unrolled into a state machine
+// around ONE evaluation site: ST_INIT (first closure call), ST_BRACKET (an evaluation of the bracketing phase),
+// ST_ZOOM (an evaluation of the zoom phase); ST_NEW_ITER, ST_ZOOM_HEAD, ST_LS_END need no evaluation.
+// The arithmetic is the host driver's, operation for operation (wave_sum_host restates the reduction network),
+// so both drivers return bit-identical fits, which tests/test_feedback_gpu.py asserts.
+constexpr int FIT_WG_MAX_ROWS = 1024;
+constexpr int FIT_HISTORY = 100;
+constexpr int FIT_ROUND_SLABS = 8;  // slabs whose partial gradients are staged in LDS at a time
+
+struct FitWgArgs {
+    const float *X, *y, *coef;   // [n, dim] centred rows, targets, per-item coefficients
+    const float *qhat, *xlx;     // or null
+    const float *w0_or_null;     // initial parameters when they do not fit the argument segment
+    float *hist_dirs, *hist_stps;  // [FIT_HISTORY, 1024] (rows padded: the driving wave loads without bounds checks)
+    float *out_w;                // mapped host memory: [dim + 1]
+    double *out_loss;            // mapped host
+    int *out_counts;             // mapped host: iterations, evaluations, status (0 ok, 1 loss diverged), diagnostics
+    unsigned *done_flag;
+    unsigned seqno;
+    int n, dim, P;               // P = trainable parameters (dim or dim + 1)
+    int label_mode;              // 0 elementwise BCE, 1 pairwise hinge, 2 pairwise logistic, 3 identically zero
+    float pw, margin;
+    int max_iter;
+    float lr;
+    FbObjDev obj;
+};
+
+struct FitDriver {  // the L-BFGS / line-search scalars of k_fb_fit_wg's driving wave
+    double loss, prev_loss, t, H_diag, gtd;
+    double f0, d_norm, t_prev, f_prev, gtd_prev, gtd_new;
+    double br0, br1, brf0, brf1, brg0, brg1;
+    int st, status, n_iter, current_evals, evals, m, head;
+    int nbr, low, ls_iter, ls_evals, done, insuf, first_ls_eval;
+};
+
+// ---- LDS map of k_fb_fit_wg (the launch sizes the allocation with fit_wg_lds_bytes)
+__host__ __device__ inline size_t fit_wg_vec_stride(int dim) { return dim + 1 <= 9 * 64 ? 9 * 64 : 16 * 64; }  // FIT_EPL * 64
+__host__ __device__ inline size_t fit_wg_stage_floats(int dim) {
+    const size_t a = (size_t)FIT_ROUND_SLABS * dim, b = (size_t)3 * FIT_WG_MAX_ROWS;
+    return a > b ? a : b;
+}
+constexpr size_t FIT_LDS_DOUBLES = 64 + 16 + 2 * FIT_HISTORY + 2 + 2 + 32 + 8 + FIT_WG_MAX_ROWS + 32 /* FitWgArgs */;
+__host__ __device__ inline size_t fit_wg_lds_bytes(int dim) {
+    const size_t floats = 1024 /*sw*/ + 1040 /*gout*/ + 4 * FIT_WG_MAX_ROWS /*z r y coef*/ + 1024 /*qhat*/ +
+                          7 * fit_wg_vec_stride(dim) + fit_wg_stage_floats(dim);
+    return FIT_LDS_DOUBLES * sizeof(double) + floats * sizeof(float);
+}
+// pointers read back from the LDS copy of the arguments are generic to the compiler (flat loads, 64-bit address
+// arithmetic per access); the phases cast them back to what they are
+typedef const float __attribute__((address_space(1))) *fit_gcptr;
+typedef float __attribute__((address_space(1))) *fit_gptr;
+typedef float fit_v4f __attribute__((ext_vector_type(4)));
+typedef const fit_v4f __attribute__((address_space(1))) *fit_g4ptr;
+
+struct FitLds {
+    double *red;        // [64]  wave partials of the four-way block sum (fb_final_body)
+    double *red2;       // [16]
+    double *ro, *al;    // [FIT_HISTORY] 1 / y.s of the history entries; the two-loop recursion's alphas
+    double *loss_slot;  // [2]  loss of the last evaluation (f64)
+    double *ctl;        // [2]  ctl[0] != 0: the driver has finished
+    FitDriver *drv;     // [32 doubles]
+    unsigned long long *tk;  // [8] diagnostic timers (100 MHz ticks)
+    double *item;       // [FIT_WG_MAX_ROWS] per-item label losses
+    FitWgArgs *args;    // [32 doubles] the kernel arguments, for the phases compiled as functions
+    float *sw_;         // [1024] parameters of the evaluation
+    float *gout;        // [1 + dim + 1 + 4] loss, gradient, parts (the layout k_fb_final emits)
+    float *zl, *rl, *yl, *cl;  // [FIT_WG_MAX_ROWS] logits, d loss / d logit, targets, per-item coefficients
+    float *qh;          // [dim] unit query
+    float *vx, *vd, *vg, *vpg, *vgp, *vb0, *vb1;  // L-BFGS vectors, [FIT_EPL * 64] each, zero beyond element dim
+    float *stage;       // pairwise staging [3 n] / partial gradients [FIT_ROUND_SLABS, dim]
+};
+__device__ __forceinline__ FitLds fit_lds_map(double *base, int dim) {
+    static_assert(sizeof(FitDriver) <= 32 * sizeof(double), "FitDriver outgrew its LDS slot");
+    static_assert(sizeof(FitWgArgs) <= 32 * sizeof(double), "FitWgArgs outgrew its LDS slot");
+    FitLds S;
+    S.red = base;
+    S.red2 = S.red + 64;
+    S.ro = S.red2 + 16;
+    S.al = S.ro + FIT_HISTORY;
+    S.loss_slot = S.al + FIT_HISTORY;
+    S.ctl = S.loss_slot + 2;
+    S.drv = reinterpret_cast<FitDriver *>(S.ctl + 2);
+    S.tk = reinterpret_cast<unsigned long long *>(S.ctl + 2 + 32);
+    S.item = S.ctl + 2 + 32 + 8;
+    S.args = reinterpret_cast<FitWgArgs *>(S.item + FIT_WG_MAX_ROWS);
+    S.sw_ = reinterpret_cast<float *>(base + FIT_LDS_DOUBLES);
+    S.gout = S.sw_ + 1024;
+    S.zl = S.gout + 1040;
+    S.rl = S.zl + FIT_WG_MAX_ROWS;
+    S.yl = S.rl + FIT_WG_MAX_ROWS;
+    S.cl = S.yl + FIT_WG_MAX_ROWS;
+    S.qh = S.cl + FIT_WG_MAX_ROWS;
+    const int VS = (int)fit_wg_vec_stride(dim);
+    S.vx = S.qh + 1024;
+    S.vd = S.vx + VS;
+    S.vg = S.vd + VS;
+    S.vpg = S.vg + VS;
+    S.vgp = S.vpg + VS;
+    S.vb0 = S.vgp + VS;
+    S.vb1 = S.vb0 + VS;
+    S.stage = S.vb1 + VS;
+    return S;
+}
+
+// The phases of one closure evaluation and the driver step are separate (not inlined) functions: each gets the
+// whole 128-register budget of a 1024-thread workgroup.  Inlined into one body the kernel spilled 130+ registers
+// into scratch inside its hot loops, and every phase ran 3-5x slower than its memory traffic allows.
+
+// z = X w (+ b): a wave per row, eight rows in flight
+__device__ __noinline__ void fit_eval_logits(double *base, int dim_) {
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int n = a.n, dim = a.dim;
+    float *sw_ = S.sw_, *zl = S.zl;
+    for (int row0 = wave; row0 < n; row0 += 128) {
+        float acc[8];
+        fit_g4ptr x4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = row0 + 16 * u;
+            x4[u] = (fit_g4ptr)(a.X + (int64_t)(row < n ? row : row0) * dim);
+            acc[u] = 0.f;
+        }
+        const float4 *w4 = reinterpret_cast<const float4 *>(sw_);
+        for (int k = lane; k < dim / 4; k += 64) {  // the eight rows' loads are issued together
+            fit_v4f xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x4[u][k];
+            const float4 wq = w4[k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float s_ = acc[u];
+                s_ = fmaf(xv[u].x, wq.x, s_);
+                s_ = fmaf(xv[u].y, wq.y, s_);
+                s_ = fmaf(xv[u].z, wq.z, s_);
+                s_ = fmaf(xv[u].w, wq.w, s_);
+                acc[u] = s_;
+            }
+        }
+        // the xor butterfly of k_fb_logits (a += shfl_xor(a, off), off = 32 ... 1) for eight rows at once: at
+        // off = 32, 16, 8 each lane keeps half of its rows and hands the other half to its partner, so a step
+        // moves 4, 2, 1 values instead of 8, 8, 8 -- the sums formed are the butterfly's (a + b = b + a), bit for bit
+        float b4[4], b2[2], b1;
+        {
+            const bool hi = (lane & 32) != 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = hi ? acc[j + 4] : acc[j], send = hi ? acc[j] : acc[j + 4];
+                b4[j] = keep + __shfl_xor(send, 32, 64);
+            }
+        }
+        {
+            const bool hi = (lane & 16) != 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float keep = hi ? b4[j + 2] : b4[j], send = hi ? b4[j] : b4[j + 2];
+                b2[j] = keep + __shfl_xor(send, 16, 64);
+            }
+        }
+        {
+            const bool hi = (lane & 8) != 0;
+            const float keep = hi ? b2[1] : b2[0], send = hi ? b2[0] : b2[1];
+            b1 = keep + __shfl_xor(send, 8, 64);
+        }
+        b1 += __shfl_xor(b1, 4, 64);
+        b1 += __shfl_xor(b1, 2, 64);
+        b1 += __shfl_xor(b1, 1, 64);
+        {
+            const int u = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            const int row = row0 + 16 * u;
+            if ((lane & 7) == 0 && row < n) zl[row] = b1 + (a.obj.has_bias ? sw_[dim] : 0.f);
+        }
+    }
+}
+
+// per-item label losses and d loss / d logit
+__device__ __noinline__ void fit_eval_labels(double *base, int dim_) {
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int c = threadIdx.x;
+    const int n = a.n;
+    float *zl = S.zl, *yl = S.yl, *cl = S.cl, *rl = S.rl, *stage = S.stage;
+    double *item = S.item;
+    if (a.label_mode == 0) {
+        for (int i = c; i < n; i += 1024) {
+            const double zi = zl[i], yi = yl[i], ci = cl[i];
+            const double lw = 1.0 + ((double)a.pw - 1.0) * yi;
+            item[i] = ci * bce_item(zi, yi, lw, a.obj.exact != 0);
+            rl[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+        }
+    } else if (a.label_mode == 1) {
+        fb_pairwise_body<0>(zl, yl, cl, a.margin, n, item, rl, stage);
+    } else if (a.label_mode == 2) {
+        fb_pairwise_body<1>(zl, yl, cl, a.margin, n, item, rl, stage);
+    } else {
+        for (int i = c; i < n; i += 1024) {
+            item[i] = 0.0;
+            rl[i] = 0.f;
+        }
+    }
+}
+
+// g = X' r: slabs of FB_SLAB rows, an ordered fma chain inside each (k_fb_grad), the slab sums added in slab
+// order (k_fb_final); returns column threadIdx.x's sum
+__device__ __noinline__ float fit_eval_grad(double *base, int dim_) {
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int c = threadIdx.x;
+    const int n = a.n, dim = a.dim;
+    float *rl = S.rl, *stage = S.stage;
+    float gcol = 0.f;
+    {
+        // a thread takes four adjacent columns (16-byte loads); thread group grp = c / (dim / 4) takes slab s0 + grp
+        // of every round of FIT_ROUND_SLABS slabs; a slab's chain runs in two halves of 16 rows in flight
+        const int dq = dim / 4;
+        const int groups = min(FIT_ROUND_SLABS, 1024 / dq);
+        const int grp = c / dq, cq = c - grp * dq;
+        const int nslabs = (n + FB_SLAB - 1) / FB_SLAB;
+        for (int s0 = 0; s0 < nslabs; s0 += groups) {
+            const int sl = s0 + grp;
+            if (grp < groups && sl < nslabs) {
+                const int r0 = sl * FB_SLAB;
+                const int cnt = min(r0 + FB_SLAB, n) - r0;
+                float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int h = 0; h < FB_SLAB; h += 16) {
+                    fit_v4f xv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        xv[i] = *(fit_g4ptr)(a.X + (int64_t)(r0 + (h + i < cnt ? h + i : 0)) * dim + 4 * cq);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (h + i < cnt) {
+                            const float ri = rl[r0 + h + i];
+                            p.x = fmaf(ri, xv[i].x, p.x);
+                            p.y = fmaf(ri, xv[i].y, p.y);
+                            p.z = fmaf(ri, xv[i].z, p.z);
+                            p.w = fmaf(ri, xv[i].w, p.w);
+                        }
+                }
+                *reinterpret_cast<float4 *>(stage + (size_t)grp * dim + 4 * cq) = p;
+            }
+            __syncthreads();
+            if (c < dim)
+                for (int j = 0; j < groups && s0 + j < nslabs; ++j) gcol += stage[(size_t)j * dim + c];
+            __syncthreads();
+        }
+    }
+    return gcol;
+}
+
+__device__ __noinline__ void fit_eval_final(double *base, int dim_, float gcol) {
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int c = threadIdx.x;
+    const FbFinalLds L{S.red, S.red2, S.sw_};
+    fb_final_body(gcol, c < a.dim ? S.sw_[c] : 0.f, S.item, S.rl, a.n, a.dim, a.qhat ? S.qh : (const float *)nullptr, a.xlx,
+                  a.obj, S.gout, S.loss_slot, L);
+}
+
+// One step of the driver (wave 0): consumes the evaluation in gout / loss_slot, advances the L-BFGS / line-search
+// state machine up to the next point that needs an evaluation, and publishes that point in sw_ (or ctl[0] = 1).
+// FIT_EPL: vector elements per lane (9 covers dim + 1 <= 576, 16 covers 1024).
+template <int FIT_EPL>
+__device__ __noinline__ void fit_driver_step(double *base, int dim_) {
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int lane = threadIdx.x & 63;
+    const int dim = a.dim, Pd = dim + 1;
+    double *ro = S.ro, *al = S.al, *loss_slot = S.loss_slot, *ctl = S.ctl;
+    float *sw_ = S.sw_, *gout = S.gout;
+    float *vx = S.vx, *vd = S.vd, *vg = S.vg, *vpg = S.vpg, *vgp = S.vgp, *vb0 = S.vb0, *vb1 = S.vb1;
+    enum { ST_INIT, ST_BRACKET, ST_ZOOM, ST_NEW_ITER, ST_ZOOM_HEAD, ST_LS_END };
+    FitDriver &D = *S.drv;
+    int &st = D.st, &status = D.status, &n_iter = D.n_iter, &current_evals = D.current_evals, &evals = D.evals;
+    int &m = D.m, &head = D.head;  // history ring: logical entry i sits in slot (head + i) % FIT_HISTORY
+    int &nbr = D.nbr, &low = D.low, &ls_iter = D.ls_iter, &ls_evals = D.ls_evals;
+    int &done = D.done, &insuf = D.insuf, &first_ls_eval = D.first_ls_eval;
+    double &loss = D.loss, &prev_loss = D.prev_loss, &t = D.t, &H_diag = D.H_diag, &gtd = D.gtd;
+    double &f0 = D.f0, &d_norm = D.d_norm, &t_prev = D.t_prev, &f_prev = D.f_prev, &gtd_prev = D.gtd_prev;
+    double &gtd_new = D.gtd_new;
+    double &br0 = D.br0, &br1 = D.br1, &brf0 = D.brf0, &brf1 = D.brf1, &brg0 = D.brg0, &brg1 = D.brg1;  // bracket ends: t, f, g.d
+    const double tol_grad = 1e-7, tol_change = 1e-9, c1 = 1e-4, c2 = 0.9;
+    const int max_ls = 25;
+    const int max_eval = a.max_iter * 5 / 4;
+    // vector helpers: element k of a vector lives in lane k % 64.  The L-BFGS vectors are FIT_EPL * 64 long and zero
+    // beyond element dim, so the loops are unrolled without bounds checks (the LDS reads overlap); `g_new` is the one
+    // operand with live data behind element dim (the loss parts): it is masked when copied and only ever multiplied
+    // with a padded vector otherwise.
+    auto vdot = [&](const float *u, const float *v) -> double {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < FIT_EPL; ++j) s += (double)u[lane + 64 * j] * (double)v[lane + 64 * j];
+        return (double)(float)wave_sum_d(s);
+    };
+    auto vabsmax = [&](const float *u) -> double {
+        double mx = 0.0;
+#pragma unroll
+        for (int j = 0; j < FIT_EPL; ++j) mx = fmax(mx, (double)fabsf(u[lane + 64 * j]));
+        return wave_max_d(mx);
+    };
+    auto vcopy = [&](float *dst, const float *src) {
+        float v[FIT_EPL];
+#pragma unroll
+        for (int j = 0; j < FIT_EPL; ++j) v[j] = src[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < FIT_EPL; ++j) dst[lane + 64 * j] = lane + 64 * j < Pd ? v[j] : 0.f;
+    };
+    const float *g_new = gout + 1;  // the gradient of the last evaluation (element dim is forced to 0 without intercept)
+
+    evals++;
+    if (a.P == dim && lane == 0) gout[1 + dim] = 0.f;  // no intercept: that slot is not a parameter
+    const double f_new = loss_slot[0];
+    bool finished = false;
+    if (!isfinite(f_new)) {
+        status = 1;
+        finished = true;
+    } else if (st == ST_INIT) {
+        loss = f_new;
+        vcopy(vg, g_new);
+        current_evals = 1;
+        prev_loss = loss;
+        if (vabsmax(vg) <= tol_grad) finished = true;
+        st = ST_NEW_ITER;
+    } else if (st == ST_BRACKET) {
+        if (first_ls_eval) {
+            ls_evals = 1;
+            first_ls_eval = 0;
+        } else {
+            ls_evals++;
+            ls_iter++;
+        }
+        gtd_new = vdot(g_new, vd);
+        bool next_eval = false;
+        if (ls_iter < max_ls) {
+            if (f_new > (f0 + c1 * t * gtd) || (ls_iter > 1 && f_new >= f_prev)) {
+                br0 = t_prev; br1 = t; brf0 = f_prev; brf1 = f_new;
+                vcopy(vb0, vgp); vcopy(vb1, g_new); brg0 = gtd_prev; brg1 = gtd_new; nbr = 2;
+            } else if (fabs(gtd_new) <= -c2 * gtd) {
+                br0 = t; brf0 = f_new; vcopy(vb0, g_new); nbr = 1;
+                done = 1;
+            } else if (gtd_new >= 0) {
+                br0 = t_prev; br1 = t; brf0 = f_prev; brf1 = f_new;
+                vcopy(vb0, vgp); vcopy(vb1, g_new); brg0 = gtd_prev; brg1 = gtd_new; nbr = 2;
+            } else {
+                const double min_step = t + 0.01 * (t - t_prev), max_step = t * 10;
+                const double tmp = t;
+                t = cubic_interpolate_dev(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, min_step, max_step);
+                t_prev = tmp; f_prev = f_new; vcopy(vgp, g_new); gtd_prev = gtd_new;
+                next_eval = true;
+            }
+        } else {  // max_ls interpolations without a bracket: [0, t]
+            br0 = 0; br1 = t; brf0 = f0; brf1 = f_new; vcopy(vb0, vg); vcopy(vb1, g_new); nbr = 2;
+            brg0 = gtd; brg1 = gtd_new;
+        }
+        if (!next_eval) {
+            insuf = 0;
+            low = 0;
+            if (nbr == 2) low = brf0 <= brf1 ? 0 : 1;
+            st = ST_ZOOM_HEAD;
+        }
+    } else {  // ST_ZOOM
+        ls_evals++;
+        gtd_new = vdot(g_new, vd);
+        ls_iter++;
+        const double brf_low = low == 0 ? brf0 : brf1;
+        if (f_new > (f0 + c1 * t * gtd) || f_new >= brf_low) {
+            if (low == 0) { br1 = t; brf1 = f_new; vcopy(vb1, g_new); brg1 = gtd_new; }
+            else          { br0 = t; brf0 = f_new; vcopy(vb0, g_new); brg0 = gtd_new; }
+            low = brf0 <= brf1 ? 0 : 1;
+        } else {
+            if (fabs(gtd_new) <= -c2 * gtd) {
+                done = 1;
+            } else {
+                const double br_high = low == 0 ? br1 : br0, br_low = low == 0 ? br0 : br1;
+                if (gtd_new * (br_high - br_low) >= 0) {
+                    if (low == 0) { br1 = br0; brf1 = brf0; vcopy(vb1, vb0); brg1 = brg0; }
+                    else          { br0 = br1; brf0 = brf1; vcopy(vb0, vb1); brg0 = brg1; }
+                }
+            }
+            if (low == 0) { br0 = t; brf0 = f_new; vcopy(vb0, g_new); brg0 = gtd_new; }
+            else          { br1 = t; brf1 = f_new; vcopy(vb1, g_new); brg1 = gtd_new; }
+        }
+        st = ST_ZOOM_HEAD;
+    }
+
+    while (!finished && st != ST_BRACKET && st != ST_ZOOM) {
+        if (st == ST_ZOOM_HEAD) {
+            if (done || ls_iter >= max_ls || fabs(br1 - br0) * d_norm < tol_change) {
+                st = ST_LS_END;
+                continue;
+            }
+            t = cubic_interpolate_dev(br0, brf0, brg0, br1, brf1, brg1, false, 0, 0);
+            const double bmax = fmax(br0, br1), bmin = fmin(br0, br1);
+            const double eps = 0.1 * (bmax - bmin);
+            if (fmin(bmax - t, t - bmin) < eps) {
+                if (insuf || t >= bmax || t <= bmin) {
+                    t = (fabs(t - bmax) < fabs(t - bmin)) ? bmax - eps : bmin + eps;
+                    insuf = 0;
+                } else {
+                    insuf = 1;
+                }
+            } else {
+                insuf = 0;
+            }
+            st = ST_ZOOM;
+        } else if (st == ST_LS_END) {
+            // accepted point: the bracket's low end
+            loss = low == 0 ? brf0 : brf1;
+            vcopy(vg, low == 0 ? vb0 : vb1);
+            t = low == 0 ? br0 : br1;
+            double dm = 0.0;  // max_i |d_i t| in f64, as the host forms it
+            for (int k = lane; k < Pd; k += 64) {
+                vx[k] += (float)t * vd[k];
+                dm = fmax(dm, fabs((double)vd[k] * t));
+            }
+            dm = wave_max_d(dm);
+            const bool opt_cond = vabsmax(vg) <= tol_grad;
+            current_evals += ls_evals;
+            if (n_iter == a.max_iter || current_evals >= max_eval || opt_cond || dm <= tol_change ||
+                fabs(loss - prev_loss) < tol_change) {
+                finished = true;
+                break;
+            }
+            st = ST_NEW_ITER;
+        } else {  // ST_NEW_ITER: the optimality test of the initial point / previous iteration has passed
+            if (n_iter >= a.max_iter) {
+                finished = true;
+                break;
+            }
+            n_iter++;
+            if (n_iter == 1) {
+                for (int k = lane; k < Pd; k += 64) vd[k] = -vg[k];
+                H_diag = 1.0;
+            } else {
+                const unsigned long long t2l = wall_clock64();
+                // y = g - prev_g, s = d t
+                float yv[FIT_EPL], sv[FIT_EPL];
+                double pys = 0.0, pyy = 0.0;
+#pragma unroll
+                for (int j = 0; j < FIT_EPL; ++j) {
+                    const int k = lane + 64 * j;
+                    yv[j] = vg[k] - vpg[k];  // the vectors are zero beyond element dim
+                    sv[j] = vd[k] * (float)t;
+                    pys += (double)yv[j] * (double)sv[j];
+                    pyy += (double)yv[j] * (double)yv[j];
+                }
+                const double ys = (double)(float)wave_sum_d(pys);
+                if (ys > 1e-10) {
+                    if (m == FIT_HISTORY) {
+                        head = (head + 1) % FIT_HISTORY;
+                        m--;
+                    }
+                    const int slot = (head + m) % FIT_HISTORY;
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) {
+                        ((fit_gptr)a.hist_dirs + (size_t)slot * 1024 + lane)[64 * j] = yv[j];
+                        ((fit_gptr)a.hist_stps + (size_t)slot * 1024 + lane)[64 * j] = sv[j];
+                    }
+                    if (lane == 0) ro[slot] = 1.0 / ys;
+                    m++;
+                    H_diag = ys / (double)(float)wave_sum_d(pyy);
+                }
+                // two-loop recursion, q in registers; the next history entry is loaded while this one reduces
+                // (two entries per trip, so the two register sets swap roles without copies)
+                const fit_gcptr hst = (fit_gcptr)a.hist_stps + lane, hdr = (fit_gcptr)a.hist_dirs + lane;
+                float q[FIT_EPL], sA[FIT_EPL], dA[FIT_EPL], sB[FIT_EPL], dB[FIT_EPL];
+#pragma unroll
+                for (int j = 0; j < FIT_EPL; ++j) {
+                    q[j] = -vg[lane + 64 * j];
+                    sA[j] = dA[j] = sB[j] = dB[j] = 0.f;
+                }
+                auto load_entry = [&](int i, float *s_out, float *d_out) {
+                    const int slot = (head + i) % FIT_HISTORY;
+                    const fit_gcptr ps = hst + (size_t)slot * 1024, pd = hdr + (size_t)slot * 1024;
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) {
+                        s_out[j] = ps[64 * j];
+                        d_out[j] = pd[64 * j];
+                    }
+                };
+                auto first_loop_step = [&](int i, const float *cs, const float *cd) {
+                    double p = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) p += (double)cs[j] * (double)q[j];
+                    const double ali = (double)(float)wave_sum_d(p) * ro[(head + i) % FIT_HISTORY];
+                    if (lane == 0) al[i] = ali;
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) q[j] -= (float)ali * cd[j];
+                };
+                if (m > 0) load_entry(m - 1, sA, dA);
+                for (int i = m - 1; i >= 0; i -= 2) {
+                    if (i > 0) load_entry(i - 1, sB, dB);
+                    first_loop_step(i, sA, dA);
+                    if (i > 0) {
+                        if (i > 1) load_entry(i - 2, sA, dA);
+                        first_loop_step(i - 1, sB, dB);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FIT_EPL; ++j) q[j] = q[j] * (float)H_diag;  // q is now d
+                auto second_loop_step = [&](int i, const float *cs, const float *cd) {
+                    double p = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) p += (double)cd[j] * (double)q[j];
+                    const double be = (double)(float)wave_sum_d(p) * ro[(head + i) % FIT_HISTORY];
+                    const float cf = (float)(al[i] - be);
+#pragma unroll
+                    for (int j = 0; j < FIT_EPL; ++j) q[j] += cf * cs[j];
+                };
+                if (m > 0) load_entry(0, sA, dA);
+                for (int i = 0; i < m; i += 2) {
+                    if (i + 1 < m) load_entry(i + 1, sB, dB);
+                    second_loop_step(i, sA, dA);
+                    if (i + 1 < m) {
+                        if (i + 2 < m) load_entry(i + 2, sA, dA);
+                        second_loop_step(i + 1, sB, dB);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FIT_EPL; ++j) {
+                    vd[lane + 64 * j] = q[j];
+                }
+                if (lane == 0) S.tk[5] += wall_clock64() - t2l;
+            }
+            vcopy(vpg, vg);
+            prev_loss = loss;
+            if (n_iter == 1) {
+                double pa = 0.0;
+                for (int k = lane; k < Pd; k += 64) pa += (double)fabsf(vg[k]);
+                const double gs = wave_sum_d(pa);
+                t = fmin(1.0, 1.0 / gs) * (double)a.lr;
+            } else {
+                t = (double)a.lr;
+            }
+            gtd = vdot(vg, vd);
+            if (gtd > -tol_change) {
+                finished = true;
+                break;
+            }
+            // line-search set-up
+            f0 = loss;
+            d_norm = vabsmax(vd);
+            t_prev = 0; f_prev = f0; gtd_prev = gtd;
+            vcopy(vgp, vg);
+            done = 0;
+            ls_iter = 0;
+            nbr = 0;
+            first_ls_eval = 1;
+            st = ST_BRACKET;
+        }
+    }
+    if (finished) {
+        if (lane == 0) ctl[0] = 1.0;
+    } else {
+        for (int k = lane; k < Pd; k += 64) sw_[k] = vx[k] + (float)t * vd[k];
+    }
+}
+
+template <int FIT_EPL>
+__global__ __launch_bounds__(1024) void k_fb_fit_wg(FitWgArgs a_in, FbW w0v) {
+    extern __shared__ double fit_lds[];
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int dim = a_in.dim, n = a_in.n, Pd = dim + 1;
+    const FitLds S = fit_lds_map(fit_lds, dim);
+    const int VS = (int)fit_wg_vec_stride(dim);
+    if (c == 0) {
+        *S.args = a_in;
+        FitDriver z0;
+        memset(&z0, 0, sizeof(z0));
+        z0.H_diag = 1.0;  // st = ST_INIT = 0
+        *S.drv = z0;
+        S.ctl[0] = 0.0;
+        for (int i = 0; i < 8; ++i) S.tk[i] = 0;
+    }
+    for (int i = c; i < n; i += 1024) {
+        S.yl[i] = a_in.y[i];
+        S.cl[i] = a_in.coef[i];
+    }
+    if (c < dim) S.qh[c] = a_in.qhat ? a_in.qhat[c] : 0.f;
+    for (int k = c; k < 1040; k += 1024) S.gout[k] = 0.f;  // the driver reads it FIT_EPL * 64 wide
+    for (int k = c; k < VS; k += 1024) {
+        float x0 = 0.f;
+        if (k < a_in.P) x0 = a_in.w0_or_null ? a_in.w0_or_null[k] : w0v.v[k < FB_ARG_FLOATS ? k : 0];
+        S.vx[k] = x0;
+        S.vd[k] = 0.f;
+        S.vg[k] = 0.f;
+        S.vpg[k] = 0.f;
+        S.vgp[k] = 0.f;
+        S.vb0[k] = 0.f;
+        S.vb1[k] = 0.f;
+        if (k < 1024) S.sw_[k] = x0 + (float)0.0 * 0.f;  // the first closure call: f(x + 0 d)
+    }
+    const unsigned long long t_kernel0 = wall_clock64();
+    const long long c_kernel0 = clock64();
+    for (;;) {
+        __syncthreads();  // sw_ and ctl are published
+        if (S.ctl[0] != 0.0) break;
+        unsigned long long tq0 = wall_clock64();
+        fit_eval_logits(fit_lds, dim);
+        __syncthreads();
+        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
+        fit_eval_labels(fit_lds, dim);
+        __syncthreads();
+        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[1] += q - tq0; tq0 = q; }
+        const float gcol = fit_eval_grad(fit_lds, dim);
+        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[2] += q - tq0; tq0 = q; }
+        fit_eval_final(fit_lds, dim, gcol);
+        __syncthreads();
+        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[3] += q - tq0; tq0 = q; }
+        if (wave == 0) fit_driver_step<FIT_EPL>(fit_lds, dim);
+    }
+    // every wave is here; wave 0 publishes the result
+    if (wave == 0) {
+        const FitDriver &D = *S.drv;
+        for (int k = lane; k < Pd; k += 64) a_in.out_w[k] = S.vx[k];
+        if (lane == 0) {
+            a_in.out_counts[0] = D.n_iter;
+            a_in.out_counts[1] = D.evals;
+            a_in.out_counts[2] = D.status;
+            for (int i = 0; i < 4; ++i) a_in.out_counts[3 + i] = (int)S.tk[i];
+            a_in.out_counts[7] = (int)(wall_clock64() - t_kernel0);
+            a_in.out_counts[8] = (int)((clock64() - c_kernel0) >> 4);
+            a_in.out_counts[9] = 0;
+            a_in.out_counts[10] = (int)S.tk[5];
+            *a_in.out_loss = D.loss;
+        }
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(a_in.done_flag, a_in.seqno, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -461,6 +1185,8 @@ struct ssw_fb {
     // diagnostics of the last fit
     int last_iters = 0, last_evals = 0;
     float rank_factor = 0.f;   // 1 / total_pairs of the installed targets (SSW_FB_RANKREG)
+    float *hist = nullptr;     // [2, FIT_HISTORY, 1024] L-BFGS history of the single-launch fit
+    bool last_fit_on_device = false;
 };
 
 static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
@@ -682,6 +1408,8 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     return SSW_OK;
 }
 
+static double g_fit_eval_s = 0;  // diagnostic (SSW_FB_TIMING): seconds of the last fit spent inside closure evaluations
+
 // ---- L-BFGS with strong-Wolfe line search ----------------------------------------------
 // Restatement of the algorithm torch.optim.LBFGS implements (minFunc's lbfgs / lswolfe with
 // cubic interpolation; defaults history 100, tolerance_grad 1e-7, tolerance_change 1e-9,
@@ -691,36 +1419,32 @@ namespace {
 
 typedef std::vector<float> Vec;
 
+// Sums in the association k_fb_fit_wg's driving wave uses (element i in lane i % 64, each lane adding its elements
+// in ascending order; then inside every 16-lane row lane l takes lane l - s for s = 1, 2, 4, 8; then the four row
+// totals in ascending order), so that the host-driven and the single-launch fit agree bit for bit.  (torch's own
+// dot is a BLAS call with an unspecified order.)
+double wave_sum_host(const double *p, size_t n) {
+    double b[64], nb[64];
+    for (size_t l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (size_t i = l; i < n; i += 64) s += p[i];
+        b[l] = s;
+    }
+    for (size_t s = 1; s <= 8; s <<= 1) {
+        for (size_t l = 0; l < 64; ++l) nb[l] = b[l] + ((l & 15) >= s ? b[l - s] : 0.0);
+        for (size_t l = 0; l < 64; ++l) b[l] = nb[l];
+    }
+    return ((b[15] + b[31]) + b[47]) + b[63];
+}
 double vdot(const Vec &a, const Vec &b) {
-    double s = 0.0;
-    for (size_t i = 0; i < a.size(); ++i) s += (double)a[i] * b[i];
-    return (double)(float)s;
+    double p[1032];
+    for (size_t i = 0; i < a.size(); ++i) p[i] = (double)a[i] * (double)b[i];
+    return (double)(float)wave_sum_host(p, a.size());
 }
 double vabsmax(const Vec &a) {
     float m = 0.f;
     for (float v : a) m = std::fmax(m, std::fabs(v));
     return m;
-}
-
-double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2, bool has_bounds,
-                         double lo, double hi) {
-    double xmin = lo, xmax = hi;
-    if (!has_bounds) {
-        xmin = x1 <= x2 ? x1 : x2;
-        xmax = x1 <= x2 ? x2 : x1;
-    }
-    const double d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2);
-    const double d2sq = d1 * d1 - g1 * g2;
-    if (d2sq >= 0) {
-        const double d2 = std::sqrt(d2sq);
-        double mp;
-        if (x1 <= x2)
-            mp = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2));
-        else
-            mp = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2));
-        return std::fmin(std::fmax(mp, xmin), xmax);
-    }
-    return (xmin + xmax) / 2.0;
 }
 
 struct Evaluator {
@@ -734,7 +1458,9 @@ struct Evaluator {
     // f(x + t d) and its gradient
     bool eval(const Vec &x, double t, const Vec &d, double *f, Vec *g) {
         for (int i = 0; i < P; ++i) fb->w_host[i] = x[i] + (float)t * d[i];
+        const auto t0 = std::chrono::steady_clock::now();
         status = fb_eval(fb, o, dev, pw, pairwise_active, P);
+        g_fit_eval_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (status != SSW_OK) return false;
         *f = fb->loss_host[0];
         g->assign(fb->out_host + 1, fb->out_host + 1 + P);
@@ -782,7 +1508,7 @@ bool strong_wolfe(Evaluator &E, const Vec &x, double t, const Vec &d, double f, 
         }
         const double min_step = t + 0.01 * (t - t_prev), max_step = t * 10;
         const double tmp = t;
-        t = cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, min_step, max_step);
+        t = cubic_interpolate_dev(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, min_step, max_step);
         t_prev = tmp; f_prev = f_new; g_prev = g_new; gtd_prev = gtd_new;
         if (!E.eval(x, t, d, &f_new, &g_new)) return false;
         ls_evals++;
@@ -801,7 +1527,7 @@ bool strong_wolfe(Evaluator &E, const Vec &x, double t, const Vec &d, double f, 
     }
     while (!done && ls_iter < max_ls) {
         if (std::fabs(br[1] - br[0]) * d_norm < tol_change) break;
-        t = cubic_interpolate(br[0], br_f[0], br_gtd[0], br[1], br_f[1], br_gtd[1], false, 0, 0);
+        t = cubic_interpolate_dev(br[0], br_f[0], br_gtd[0], br[1], br_f[1], br_gtd[1], false, 0, 0);
         const double bmax = std::fmax(br[0], br[1]), bmin = std::fmin(br[0], br[1]);
         const double eps = 0.1 * (bmax - bmin);
         if (std::fmin(bmax - t, t - bmin) < eps) {
@@ -860,6 +1586,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->xlx);
     (void)hipFree(fb->out);
     (void)hipFree(fb->loss_dev);
+    (void)hipFree(fb->hist);
     if (fb->loss_host) (void)hipHostFree(fb->loss_host);
     if (fb->out_host) (void)hipHostFree(fb->out_host);
     if (fb->w_host) (void)hipHostFree(fb->w_host);
@@ -893,6 +1620,7 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipMalloc((void **)&fb->xlx, (size_t)dim * dim * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->out, outn * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->loss_dev, sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&fb->hist, (size_t)2 * FIT_HISTORY * 1024 * sizeof(float)) != hipSuccess ||
         hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->flag_host, 64, hipHostMallocMapped) != hipSuccess ||
@@ -1032,8 +1760,94 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
     E.fb = fb;
     E.o = obj;
     E.P = fb->dim + 1;  // the device always sees dim+1 parameters; slot dim is the (maybe unused) bias
+    const auto t_fit0 = std::chrono::steady_clock::now();
     SSW_TRY(fb_prepare(fb, obj, &E.dev, &E.pw, &E.pairwise_active));
+    const double prep_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit0).count();
+    g_fit_eval_s = 0;
     fb->last_evals = 0;
+    fb->last_fit_on_device = false;
+    // ---- the whole step(closure) in one launch (k_fb_fit_wg) when the labelled set fits one workgroup's reach
+    if (fb->n <= FIT_WG_MAX_ROWS && fb->dim + 1 <= 1024 && obj->kind != SSW_FB_RANKREG && !getenv("SSW_FB_HOST_DRIVER")) {
+        for (int i = 0; i < P; ++i) SSW_REQUIRE(std::isfinite(w_inout[i]), "initial weight %d is not finite", i);
+        FitWgArgs a;
+        memset(&a, 0, sizeof(a));
+        a.X = fb->X; a.y = fb->y; a.coef = fb->coef;
+        a.qhat = fb->has_q ? fb->qhat : nullptr;
+        a.xlx = fb->has_xlx ? fb->xlx : nullptr;
+        a.hist_dirs = fb->hist;
+        a.hist_stps = fb->hist + (size_t)FIT_HISTORY * 1024;
+        a.out_w = fb->out_host_dev + 1;
+        a.out_loss = fb->loss_host_dev;
+        a.out_counts = reinterpret_cast<int *>(fb->flag_host_dev) + 4;
+        a.done_flag = fb->flag_host_dev;
+        a.seqno = ++fb->seqno;
+        a.n = (int)fb->n; a.dim = fb->dim; a.P = P;
+        const bool pairwise = obj->kind == SSW_FB_MULTIREG && obj->loss_type != SSW_FB_LOSS_CE;
+        a.label_mode = !pairwise ? 0 : !E.pairwise_active ? 3 : obj->loss_type == SSW_FB_LOSS_PAIRWISE_LOGISTIC ? 2 : 1;
+        a.pw = E.pw; a.margin = obj->margin; a.max_iter = max_iter; a.lr = lr; a.obj = E.dev;
+        FbW w0v;
+        memset(&w0v, 0, sizeof(w0v));
+        if (fb->dim + 1 <= FB_ARG_FLOATS) {
+            memcpy(w0v.v, w_inout, (size_t)P * sizeof(float));
+        } else {
+            memcpy(fb->w_host, w_inout, (size_t)P * sizeof(float));
+            if (P == fb->dim) fb->w_host[fb->dim] = 0.f;
+            SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)(fb->dim + 1) * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+            a.w0_or_null = fb->w;
+        }
+        const size_t lds = fit_wg_lds_bytes(fb->dim);
+        auto kern = fb->dim + 1 <= 9 * 64 ? k_fb_fit_wg<9> : k_fb_fit_wg<16>;
+        static bool lds_attr[2] = {false, false};
+        if (!lds_attr[fb->dim + 1 <= 9 * 64 ? 0 : 1]) {
+            SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            lds_attr[fb->dim + 1 <= 9 * 64 ? 0 : 1] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, fb->stream, a, w0v);
+        SSW_HIP_TRY(hipGetLastError());
+        {
+            const unsigned want = fb->seqno;
+            bool seen = false;
+            if (!getenv("SSW_FB_NO_SPIN")) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned it = 0;; ++it) {
+                    if (__atomic_load_n(fb->flag_host, __ATOMIC_ACQUIRE) == want) {
+                        seen = true;
+                        break;
+                    }
+                    if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                }
+            }
+            if (!seen) SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+        }
+        const int *counts = reinterpret_cast<const int *>(fb->flag_host) + 4;
+        fb->last_iters = counts[0];
+        fb->last_evals = counts[1];
+        fb->last_fit_on_device = true;
+        if (counts[2] != 0) {
+            set_error("feedback: loss diverged -- regression training failed with a nan");
+            return SSW_ERR_NUMERIC;  // logistic_regression.py:398-401
+        }
+        for (int i = 0; i < P; ++i) {
+            if (!std::isfinite(fb->out_host[1 + i])) {
+                set_error("feedback: weights diverged");
+                return SSW_ERR_NUMERIC;
+            }
+            w_inout[i] = fb->out_host[1 + i];
+        }
+        if (getenv("SSW_FB_TIMING"))
+            fprintf(stderr, "fit (one launch): n=%lld iters=%d evals=%d total %.1f us, prepare %.1f; kernel %.1f us = logits %.1f + "
+                    "labels %.1f + gradient %.1f + final %.1f + driver %.1f (%.0f MHz)\n", (long long)fb->n, counts[0], counts[1],
+                    1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit0).count(), 1e6 * prep_s,
+                    counts[7] * 0.01, counts[3] * 0.01, counts[4] * 0.01, counts[5] * 0.01, counts[6] * 0.01,
+                    (counts[7] - counts[3] - counts[4] - counts[5] - counts[6]) * 0.01,
+                    counts[7] > 0 ? 16.0 * counts[8] / (counts[7] * 0.01) : 0.0);
+        if (getenv("SSW_FB_TIMING"))
+            fprintf(stderr, "   of the driver: two-loop recursion %.1f us\n", counts[10] * 0.01);
+        if (out_iters) *out_iters = counts[0];
+        if (out_evals) *out_evals = counts[1];
+        if (out_final_loss) *out_final_loss = (float)fb->loss_host[0];
+        return SSW_OK;
+    }
     const int history = 100;
     const double tol_grad = 1e-7, tol_change = 1e-9;
     const int max_eval = max_iter * 5 / 4;
@@ -1090,8 +1904,9 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
         prev_g = g;
         prev_loss = loss;
         if (n_iter == 1) {
-            double gs = 0;
-            for (float v : g) gs += std::fabs(v);
+            double pa[1032];
+            for (size_t i = 0; i < g.size(); ++i) pa[i] = (double)std::fabs(g[i]);
+            const double gs = wave_sum_host(pa, g.size());
             t = std::fmin(1.0, 1.0 / gs) * lr;
         } else {
             t = lr;
@@ -1125,9 +1940,20 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
         w_inout[i] = x[i];
     }
     fb->last_iters = n_iter;
+    if (getenv("SSW_FB_TIMING"))
+        fprintf(stderr, "fit: n=%lld iters=%d evals=%d total %.1f us, prepare %.1f, evaluations %.1f\n", (long long)fb->n,
+                n_iter, fb->last_evals,
+                1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit0).count(), 1e6 * prep_s,
+                1e6 * g_fit_eval_s);
     if (out_iters) *out_iters = n_iter;
     if (out_evals) *out_evals = fb->last_evals;
     if (out_final_loss) *out_final_loss = (float)loss;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_last_fit_on_device(const ssw_fb *fb, int32_t *out) {
+    SSW_REQUIRE(fb && out, "NULL argument");
+    *out = fb->last_fit_on_device ? 1 : 0;
     return SSW_OK;
 }
 

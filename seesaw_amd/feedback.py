@@ -97,4 +97,7 @@ class FeedbackEngine:
         iters, evals, loss = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(0)
         _lib.call("ssw_fb_fit", self._h, ctypes.byref(obj), _p(w), int(max_iter), float(lr),
                   ctypes.byref(iters), ctypes.byref(evals), ctypes.byref(loss))
-        return w, {"n_iter": iters.value, "func_evals": evals.value, "loss": float(loss.value)}
+        on_dev = ctypes.c_int32(0)
+        _lib.call("ssw_fb_last_fit_on_device", self._h, ctypes.byref(on_dev))
+        return w, {"n_iter": iters.value, "func_evals": evals.value, "loss": float(loss.value),
+                   "on_device": bool(on_dev.value)}

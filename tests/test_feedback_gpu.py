@@ -225,3 +225,81 @@ def test_fit_from_resident_index_rows(oracle):
     b.fit(None, y, w0=w0, index=idx, rows=rows)
     assert np.array_equal(a.get_coeff(), b.get_coeff())
     idx.close()
+
+
+def _fit_both_drivers(eng, obj, w0, max_iter=200):
+    """(w, info) of the single-launch fit (k_fb_fit_wg) and of the host-driven loop (SSW_FB_HOST_DRIVER)"""
+    assert "SSW_FB_HOST_DRIVER" not in os.environ
+    w_dev, info_dev = eng.fit(obj, w0, max_iter)
+    os.environ["SSW_FB_HOST_DRIVER"] = "1"
+    try:
+        w_host, info_host = eng.fit(obj, w0, max_iter)
+    finally:
+        del os.environ["SSW_FB_HOST_DRIVER"]
+    assert info_dev.pop("on_device") is True and info_host.pop("on_device") is False
+    return (w_dev, info_dev), (w_host, info_host)
+
+
+def test_single_launch_fit_is_the_host_driven_fit_bit_for_bit():
+    """k_fb_fit_wg (whole L-BFGS step(closure) in one workgroup) walks the same path as the host loop that
+    launches three kernels per closure evaluation: same iteration / evaluation counts, same final loss, identical
+    coefficient bits -- on every multireg golden case (ce / pairwise hinge / pairwise logistic, data and query
+    regularisers) and on logistic fits with an intercept and soft labels"""
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    g = np.load(os.path.join(GOLDEN, "multireg.npz"))
+    eng = FeedbackEngine(512)
+    eng.set_xlx(g["xlx"])
+    total_evals = 0
+    for c in range(int(g["n_cases"])):
+        X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
+        _, inv, counts = np.unique(img, return_inverse=True, return_counts=True)
+        eng.set_data(X, center=True)
+        eng.set_targets(y, 1.0 / counts[inv])
+        eng.set_query(q)
+        obj = _multireg_obj(str(g[f"c{c}_loss_type"]), float(g[f"c{c}_data_lam"]), float(g[f"c{c}_query_lam"]))
+        w0 = (q / np.linalg.norm(q)).astype(np.float32)
+        (wd, idev), (wh, ihost) = _fit_both_drivers(eng, obj, w0)
+        assert idev == ihost, (c, idev, ihost)
+        assert np.array_equal(wd.view(np.uint32), wh.view(np.uint32)), (c, np.abs(wd - wh).max())
+        total_evals += idev["func_evals"]
+    assert total_evals > 100
+    rng = np.random.default_rng(3)
+    for n, intercept, reg_kind in ((40, 1, _lib.SSW_FB_REG_VECTOR), (700, 0, _lib.SSW_FB_REG_NORM), (1024, 1, _lib.SSW_FB_REG_NONE)):
+        X = rng.standard_normal((n, 512)).astype(np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        q = X[:4].mean(0)
+        y = rng.uniform(0, 1, n)
+        y[: n // 2] = rng.uniform(size=n // 2) > 0.6
+        eng.set_data(X, center=True)
+        eng.set_targets(y, rng.uniform(0.5, 2.0, n))
+        eng.set_query(q)
+        obj = _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=intercept, reg_kind=reg_kind,
+                               pos_weight=2.0, reg_weight=1.0 / n, margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                               reg_query_lambda=0)
+        w0 = (rng.standard_normal(512 + intercept) * 0.05).astype(np.float32)
+        (wd, idev), (wh, ihost) = _fit_both_drivers(eng, obj, w0, max_iter=60)
+        assert idev == ihost, (n, idev, ihost)
+        assert np.array_equal(wd.view(np.uint32), wh.view(np.uint32)), (n, np.abs(wd - wh).max())
+
+
+def test_larger_labelled_sets_take_the_host_driven_fit():
+    """above 1024 rows (pseudo_lr's 10 000 pseudo-labelled rows) the per-evaluation kernels run, driven from the host"""
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    rng = np.random.default_rng(5)
+    n = 1025
+    X = rng.standard_normal((n, 512)).astype(np.float32)
+    eng = FeedbackEngine(512)
+    eng.set_data(X, center=True)
+    eng.set_targets((rng.uniform(size=n) > 0.5).astype(np.float64), None)
+    obj = _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=0, reg_kind=_lib.SSW_FB_REG_NORM,
+                           pos_weight=1.0, reg_weight=1.0 / n, margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                           reg_query_lambda=0)
+    w0 = np.zeros(512, np.float32) + 0.01
+    w, info = eng.fit(obj, w0, 30)
+    assert info["on_device"] is False and info["func_evals"] > 2
+    eng.set_data(X[:1024], center=True)
+    eng.set_targets((rng.uniform(size=1024) > 0.5).astype(np.float64), None)
+    w, info = eng.fit(obj, w0, 30)
+    assert info["on_device"] is True
