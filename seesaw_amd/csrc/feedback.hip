@@ -290,6 +290,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_take_d<0x118>(v);
     return ((readlane_d(v, 15) + readlane_d(v, 31)) + readlane_d(v, 47)) + readlane_d(v, 63);
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_take_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {  // the same network in f32
+    v += dpp_take_f<0x111>(v);
+    v += dpp_take_f<0x112>(v);
+    v += dpp_take_f<0x114>(v);
+    v += dpp_take_f<0x118>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return ((r0 + r1) + r2) + r3;
+}
 __device__ __forceinline__ double wave_max_d(double v) {  // v >= 0
     v = fmax(v, dpp_take_d<0x111>(v));
     v = fmax(v, dpp_take_d<0x112>(v));
@@ -793,7 +808,8 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
     float *sw_ = S.sw_, *gout = S.gout;
     float *vx = S.vx, *vd = S.vd, *vg = S.vg, *vpg = S.vpg, *vgp = S.vgp, *vb0 = S.vb0, *vb1 = S.vb1;
     enum { ST_INIT, ST_BRACKET, ST_ZOOM, ST_NEW_ITER, ST_ZOOM_HEAD, ST_LS_END };
-    FitDriver &D = *S.drv;
+    FitDriver D = *S.drv;  // a register copy for the duration of the step (LDS round trips between dependent scalar
+                           // operations were most of a step's time); written back on the way out
     int &st = D.st, &status = D.status, &n_iter = D.n_iter, &current_evals = D.current_evals, &evals = D.evals;
     int &m = D.m, &head = D.head;  // history ring: logical entry i sits in slot (head + i) % FIT_HISTORY
     int &nbr = D.nbr, &low = D.low, &ls_iter = D.ls_iter, &ls_evals = D.ls_evals;
@@ -809,11 +825,13 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
     // beyond element dim, so the loops are unrolled without bounds checks (the LDS reads overlap); `g_new` is the one
     // operand with live data behind element dim (the loss parts): it is masked when copied and only ever multiplied
     // with a padded vector otherwise.
+    // dot products are f32 throughout, like torch's (a BLAS sdot there; here: per-lane products added in ascending
+    // order, then wave_sum_f's network) -- one wave owns the whole recursion, so every instruction saved is latency
     auto vdot = [&](const float *u, const float *v) -> double {
-        double s = 0.0;
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < FIT_EPL; ++j) s += (double)u[lane + 64 * j] * (double)v[lane + 64 * j];
-        return (double)(float)wave_sum_d(s);
+        for (int j = 0; j < FIT_EPL; ++j) s += u[lane + 64 * j] * v[lane + 64 * j];
+        return (double)wave_sum_f(s);
     };
     auto vabsmax = [&](const float *u) -> double {
         double mx = 0.0;
@@ -958,16 +976,16 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
                 const unsigned long long t2l = wall_clock64();
                 // y = g - prev_g, s = d t
                 float yv[FIT_EPL], sv[FIT_EPL];
-                double pys = 0.0, pyy = 0.0;
+                float pys = 0.f, pyy = 0.f;
 #pragma unroll
                 for (int j = 0; j < FIT_EPL; ++j) {
                     const int k = lane + 64 * j;
                     yv[j] = vg[k] - vpg[k];  // the vectors are zero beyond element dim
                     sv[j] = vd[k] * (float)t;
-                    pys += (double)yv[j] * (double)sv[j];
-                    pyy += (double)yv[j] * (double)yv[j];
+                    pys += yv[j] * sv[j];
+                    pyy += yv[j] * yv[j];
                 }
-                const double ys = (double)(float)wave_sum_d(pys);
+                const double ys = (double)wave_sum_f(pys);
                 if (ys > 1e-10) {
                     if (m == FIT_HISTORY) {
                         head = (head + 1) % FIT_HISTORY;
@@ -981,16 +999,18 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
                     }
                     if (lane == 0) ro[slot] = 1.0 / ys;
                     m++;
-                    H_diag = ys / (double)(float)wave_sum_d(pyy);
+                    H_diag = ys / (double)wave_sum_f(pyy);
                 }
-                // two-loop recursion, q in registers; the next history entry is loaded while this one reduces
-                // (two entries per trip, so the two register sets swap roles without copies)
+                // two-loop recursion, q in registers.  A step is ~60 instructions of one wave (~300 cycles) and needs
+                // one history entry (2 x 513 floats in L2, ~800 cycles away): four register sets, entries loaded three
+                // steps ahead, the trip unrolled by four so the sets rotate without copies.
                 const fit_gcptr hst = (fit_gcptr)a.hist_stps + lane, hdr = (fit_gcptr)a.hist_dirs + lane;
-                float q[FIT_EPL], sA[FIT_EPL], dA[FIT_EPL], sB[FIT_EPL], dB[FIT_EPL];
+                float q[FIT_EPL], sb[4][FIT_EPL], db[4][FIT_EPL];
 #pragma unroll
                 for (int j = 0; j < FIT_EPL; ++j) {
                     q[j] = -vg[lane + 64 * j];
-                    sA[j] = dA[j] = sB[j] = dB[j] = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sb[u][j] = db[u][j] = 0.f;
                 }
                 auto load_entry = [&](int i, float *s_out, float *d_out) {
                     const int slot = (head + i) % FIT_HISTORY;
@@ -1002,41 +1022,51 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
                     }
                 };
                 auto first_loop_step = [&](int i, const float *cs, const float *cd) {
-                    double p = 0.0;
+                    const double roi = ro[(head + i) % FIT_HISTORY];  // read before the reduction, not after it
+                    float p = 0.f;
 #pragma unroll
-                    for (int j = 0; j < FIT_EPL; ++j) p += (double)cs[j] * (double)q[j];
-                    const double ali = (double)(float)wave_sum_d(p) * ro[(head + i) % FIT_HISTORY];
+                    for (int j = 0; j < FIT_EPL; ++j) p += cs[j] * q[j];
+                    const double ali = (double)wave_sum_f(p) * roi;
                     if (lane == 0) al[i] = ali;
 #pragma unroll
                     for (int j = 0; j < FIT_EPL; ++j) q[j] -= (float)ali * cd[j];
                 };
-                if (m > 0) load_entry(m - 1, sA, dA);
-                for (int i = m - 1; i >= 0; i -= 2) {
-                    if (i > 0) load_entry(i - 1, sB, dB);
-                    first_loop_step(i, sA, dA);
-                    if (i > 0) {
-                        if (i > 1) load_entry(i - 2, sA, dA);
-                        first_loop_step(i - 1, sB, dB);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (u < m) load_entry(m - 1 - u, sb[u], db[u]);
+                for (int k0 = 0; k0 < m; k0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + u;  // step k works on entry m - 1 - k
+                        if (k < m) {
+                            if (k + 3 < m) load_entry(m - 1 - (k + 3), sb[(u + 3) & 3], db[(u + 3) & 3]);
+                            first_loop_step(m - 1 - k, sb[u], db[u]);
+                        }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < FIT_EPL; ++j) q[j] = q[j] * (float)H_diag;  // q is now d
                 auto second_loop_step = [&](int i, const float *cs, const float *cd) {
-                    double p = 0.0;
+                    const double roi = ro[(head + i) % FIT_HISTORY], ali = al[i];
+                    float p = 0.f;
 #pragma unroll
-                    for (int j = 0; j < FIT_EPL; ++j) p += (double)cd[j] * (double)q[j];
-                    const double be = (double)(float)wave_sum_d(p) * ro[(head + i) % FIT_HISTORY];
-                    const float cf = (float)(al[i] - be);
+                    for (int j = 0; j < FIT_EPL; ++j) p += cd[j] * q[j];
+                    const double be = (double)wave_sum_f(p) * roi;
+                    const float cf = (float)(ali - be);
 #pragma unroll
                     for (int j = 0; j < FIT_EPL; ++j) q[j] += cf * cs[j];
                 };
-                if (m > 0) load_entry(0, sA, dA);
-                for (int i = 0; i < m; i += 2) {
-                    if (i + 1 < m) load_entry(i + 1, sB, dB);
-                    second_loop_step(i, sA, dA);
-                    if (i + 1 < m) {
-                        if (i + 2 < m) load_entry(i + 2, sA, dA);
-                        second_loop_step(i + 1, sB, dB);
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (u < m) load_entry(u, sb[u], db[u]);
+                for (int k0 = 0; k0 < m; k0 += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = k0 + u;
+                        if (k < m) {
+                            if (k + 3 < m) load_entry(k + 3, sb[(u + 3) & 3], db[(u + 3) & 3]);
+                            second_loop_step(k, sb[u], db[u]);
+                        }
                     }
                 }
 #pragma unroll
@@ -1075,8 +1105,10 @@ __device__ __noinline__ void fit_driver_step(double *base, int dim_) {
     if (finished) {
         if (lane == 0) ctl[0] = 1.0;
     } else {
-        for (int k = lane; k < Pd; k += 64) sw_[k] = vx[k] + (float)t * vd[k];
+#pragma unroll
+        for (int j = 0; j < FIT_EPL; ++j) sw_[lane + 64 * j] = vx[lane + 64 * j] + (float)t * vd[lane + 64 * j];
     }
+    if (lane == 0) *S.drv = D;
 }
 
 template <int FIT_EPL>
@@ -1436,10 +1468,23 @@ double wave_sum_host(const double *p, size_t n) {
     }
     return ((b[15] + b[31]) + b[47]) + b[63];
 }
+float wave_sum_host_f(const float *p, size_t n) {  // wave_sum_f's network over per-lane sums in ascending order
+    float b[64], nb[64];
+    for (size_t l = 0; l < 64; ++l) {
+        float s = 0.f;
+        for (size_t i = l; i < n; i += 64) s += p[i];
+        b[l] = s;
+    }
+    for (size_t s = 1; s <= 8; s <<= 1) {
+        for (size_t l = 0; l < 64; ++l) nb[l] = b[l] + ((l & 15) >= s ? b[l - s] : 0.f);
+        for (size_t l = 0; l < 64; ++l) b[l] = nb[l];
+    }
+    return ((b[15] + b[31]) + b[47]) + b[63];
+}
 double vdot(const Vec &a, const Vec &b) {
-    double p[1032];
-    for (size_t i = 0; i < a.size(); ++i) p[i] = (double)a[i] * (double)b[i];
-    return (double)(float)wave_sum_host(p, a.size());
+    float p[1032];
+    for (size_t i = 0; i < a.size(); ++i) p[i] = a[i] * b[i];
+    return (double)wave_sum_host_f(p, a.size());
 }
 double vabsmax(const Vec &a) {
     float m = 0.f;
