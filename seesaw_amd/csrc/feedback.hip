@@ -52,15 +52,31 @@ __global__ void k_fb_gather_rows(const float *__restrict__ X, const int64_t *__r
 }
 
 // column means in f64 (fixed order), then subtract: StandardScaler(with_std=False) /
-// `X - X.mean(axis=0)` (logistic_regression.py:353-355, multi_reg.py:168-169)
-__global__ void k_fb_center(float *__restrict__ X, int64_t n, int dim, float *__restrict__ mu) {
+// `X - X.mean(axis=0)` (logistic_regression.py:353-355, multi_reg.py:168-169).  Three small launches: per-column sums
+// of 256-row blocks, the block sums added in block order, the subtraction over all elements.  (One thread walking a
+// whole column took 3.7 ms on PseudoLR's 10 000 rows.)
+constexpr int FB_CENTER_ROWS = 256;
+__global__ void k_fb_colsum_blocks(const float *__restrict__ X, int64_t n, int dim, double *__restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    const int64_t r0 = (int64_t)blockIdx.y * FB_CENTER_ROWS, r1 = min(r0 + FB_CENTER_ROWS, n);
+    double s = 0.0;
+    for (int64_t i = r0; i < r1; ++i) s += (double)X[i * dim + c];
+    partial[(int64_t)blockIdx.y * dim + c] = s;
+}
+__global__ void k_fb_colmean(const double *__restrict__ partial, int nblk, int64_t n, int dim, float *__restrict__ mu) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= dim) return;
     double s = 0.0;
-    for (int64_t i = 0; i < n; ++i) s += (double)X[i * dim + c];
-    const float m = (float)(s / (double)n);
-    mu[c] = m;
-    for (int64_t i = 0; i < n; ++i) X[i * dim + c] -= m;
+    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * dim + c];
+    mu[c] = (float)(s / (double)n);
+}
+__global__ void k_fb_subtract_mean(float *__restrict__ X, int64_t n, int dim, const float *__restrict__ mu) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    const float m = mu[c];
+    const int64_t r0 = (int64_t)blockIdx.y * FB_CENTER_ROWS, r1 = min(r0 + FB_CENTER_ROWS, n);
+    for (int64_t i = r0; i < r1; ++i) X[i * dim + c] -= m;
 }
 
 // ---- per-evaluation kernels -----------------------------------------------------------
@@ -1200,6 +1216,7 @@ struct ssw_fb {
     double *loss_dev = nullptr, *loss_host = nullptr;  // total loss in f64
     int64_t *rows = nullptr;   // gather staging
     float *partial = nullptr;  // [nslabs(cap), dim]
+    double *colsum = nullptr;  // [cap / FB_CENTER_ROWS, dim] block sums of the centring step
     float *w = nullptr;        // [dim + 1]
     float *qhat = nullptr;     // [dim]
     float *xlx = nullptr;      // [dim, dim]
@@ -1232,6 +1249,8 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
+    (void)hipFree(fb->colsum);
+    fb->colsum = nullptr;
     fb->X = fb->y = fb->coef = fb->z = fb->r = fb->partial = nullptr;
     fb->item = nullptr;
     fb->rows = nullptr;
@@ -1247,14 +1266,19 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     SSW_HIP_TRY(hipMalloc((void **)&fb->r, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->rows, (size_t)cap * sizeof(int64_t)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->partial, (size_t)nslabs * fb->dim * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->colsum, (size_t)((cap + FB_CENTER_ROWS - 1) / FB_CENTER_ROWS) * fb->dim * sizeof(double)));
     fb->cap = cap;
     return SSW_OK;
 }
 
 static ssw_status fb_center(ssw_fb *fb, int center) {
     if (center && fb->n > 0) {
-        hipLaunchKernelGGL(k_fb_center, dim3((fb->dim + 63) / 64), dim3(64), 0, fb->stream, fb->X, fb->n,
+        const int nblk = (int)((fb->n + FB_CENTER_ROWS - 1) / FB_CENTER_ROWS);
+        const dim3 grid((fb->dim + 63) / 64, nblk);
+        hipLaunchKernelGGL(k_fb_colsum_blocks, grid, dim3(64), 0, fb->stream, fb->X, fb->n, fb->dim, fb->colsum);
+        hipLaunchKernelGGL(k_fb_colmean, dim3((fb->dim + 63) / 64), dim3(64), 0, fb->stream, fb->colsum, nblk, fb->n,
                            fb->dim, fb->mu);
+        hipLaunchKernelGGL(k_fb_subtract_mean, grid, dim3(64), 0, fb->stream, fb->X, fb->n, fb->dim, fb->mu);
         SSW_HIP_TRY(hipGetLastError());
     } else {
         SSW_HIP_TRY(hipMemsetAsync(fb->mu, 0, (size_t)fb->dim * sizeof(float), fb->stream));
@@ -1626,6 +1650,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
+    (void)hipFree(fb->colsum);
     (void)hipFree(fb->w);
     (void)hipFree(fb->qhat);
     (void)hipFree(fb->xlx);
@@ -1993,6 +2018,19 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
     if (out_iters) *out_iters = n_iter;
     if (out_evals) *out_evals = fb->last_evals;
     if (out_final_loss) *out_final_loss = (float)loss;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_reset(ssw_fb *fb) {
+    SSW_REQUIRE(fb != nullptr, "NULL argument");
+    DeviceGuard guard(fb->device);
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    fb->n = 0;
+    fb->has_q = fb->has_xlx = false;
+    fb->y_host.clear();
+    fb->sw_host.clear();
+    fb->last_iters = fb->last_evals = 0;
+    fb->last_fit_on_device = false;
     return SSW_OK;
 }
 

@@ -64,9 +64,19 @@ class LogisticRegressionPT:
                            reg_weight=float(self.reg_lambda) / n_examples, margin=0.0,
                            reg_norm_lambda=0.0, reg_data_lambda=0.0, reg_query_lambda=0.0)
 
+    def __del__(self):
+        eng, self._engine = getattr(self, "_engine", None), None
+        if eng is not None:
+            try:
+                eng.release()
+            except Exception:
+                pass
+
     def _ensure_engine(self, dim: int):
         if self._engine is None or self._dim != dim:
-            self._engine = FeedbackEngine(dim, device=self._device)
+            if self._engine is not None:
+                self._engine.release()
+            self._engine = FeedbackEngine.acquire(dim, device=self._device)
             self._dim = dim
             if self.regularizer_vector is not None:
                 self._engine.set_query(self.regularizer_vector)

@@ -3,6 +3,8 @@ import os
 
 import numpy as np
 
+from ..nprand import permutation_prefix
+
 
 def makeXy(idx, lr, sample_size, pseudoLabel=True):
     """real labels + a random sample of pseudo-labelled vectors (their propagated scores)."""
@@ -12,7 +14,7 @@ def makeXy(idx, lr, sample_size, pseudoLabel=True):
     is_real = np.ones_like(y)
     if pseudoLabel:
         unl = np.nonzero(~is_labeled)[0]
-        pick = unl[np.random.permutation(unl.shape[0])[:sample_size]]
+        pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
         rows = np.concatenate((rows, pick))
         y = np.concatenate((y, lr.current_scores()[pick]))
         is_real = np.concatenate((is_real, np.zeros(pick.shape[0])))
@@ -26,7 +28,7 @@ def makeXy_rows(lr, sample_size):
     y = lr.labels[is_labeled]
     is_real = np.ones_like(y)
     unl = np.nonzero(~is_labeled)[0]
-    pick = unl[np.random.permutation(unl.shape[0])[:sample_size]]
+    pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
     return (np.concatenate((rows, pick)), np.concatenate((y, lr.current_scores()[pick])),
             np.concatenate((is_real, np.zeros(pick.shape[0]))))
 

@@ -1,0 +1,25 @@
+"""`np.random.permutation(n)[:k]` on numpy's own global MT19937 stream, computed by the library
+(`ssw_np_permutation_prefix`, csrc/nprand.hip): same values, same stream position afterwards, a third of the time.
+Used where the reference draws PseudoLR's pseudo-labelled sample (seesaw/loops/util.py:13)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def permutation_prefix(n: int, k: int) -> np.ndarray:
+    """== np.random.permutation(n)[:k] (int64), consuming the global RandomState exactly as that call does"""
+    n, k = int(n), int(k)
+    if n < 0:
+        raise ValueError("negative dimensions are not allowed")  # np.arange(n) inside numpy's permutation raises too
+    state = np.random.get_state()
+    if state[0] != "MT19937":  # not the legacy global generator: leave it to numpy
+        return np.random.permutation(n)[:k]
+    key = np.array(state[1], dtype=np.uint32, copy=True)
+    pos = ctypes.c_int32(int(state[2]))
+    out = np.empty(max(0, min(n, k)), dtype=np.int64)
+    _lib.call("ssw_np_permutation_prefix", ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
+              ctypes.c_void_p(out.ctypes.data))
+    np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
+    return out

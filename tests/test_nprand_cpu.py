@@ -1,0 +1,61 @@
+"""ssw_np_permutation_prefix (host-only C, csrc/nprand.hip) against numpy itself: the same first k entries of
+np.random.permutation(n) and the same stream afterwards, for sizes on both sides of every power of two the rejection
+sampler's masks step at, with the generator at arbitrary positions inside its 624-word block."""
+import numpy as np
+import pytest
+
+from seesaw_amd.nprand import permutation_prefix
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 31, 32, 33, 624, 625, 1000, 65535, 65536, 65537, 300001])
+def test_prefix_and_stream_equal_numpy(n):
+    for seed, burn in ((0, 0), (1, 7), (12345, 623), (99, 624), (7, 1250)):
+        np.random.seed(seed)
+        np.random.randint(0, 10, size=burn)  # move the position inside / across the 624-word block
+        state = np.random.get_state()
+        ref = np.random.permutation(n)
+        ref_next = np.random.random(5)
+        for k in (0, 1, 10, n, n + 3):
+            np.random.set_state(state)
+            got = permutation_prefix(n, k)
+            assert got.dtype == np.int64
+            assert np.array_equal(got, ref[:k]), (n, seed, burn, k)
+            assert np.array_equal(np.random.random(5), ref_next), "the stream must continue where numpy's call leaves it"
+
+
+def test_makexy_rows_draw_is_the_reference_expression():
+    from seesaw_amd.loops.util import makeXy_rows
+
+    class _Ranker:
+        def __init__(self, n):
+            self.is_labeled = np.zeros(n)
+            self.is_labeled[[3, 17, 40]] = 1
+            self.labels = np.zeros(n)
+            self.labels[17] = 1
+            self._s = np.linspace(0, 1, n)
+
+        def current_scores(self):
+            return self._s
+
+    lr = _Ranker(5000)
+    np.random.seed(4)
+    rows, y, is_real = makeXy_rows(lr, sample_size=100)
+    np.random.seed(4)
+    unl = np.nonzero(~(lr.is_labeled > 0))[0]
+    pick = unl[np.random.permutation(unl.shape[0])[:100]]
+    assert np.array_equal(rows, np.concatenate(([3, 17, 40], pick)))
+    assert np.array_equal(y, np.concatenate(([0, 1, 0], lr._s[pick])))
+    assert is_real.sum() == 3
+
+
+def test_generator_gaussian_cache_survives():
+    """has_gauss / cached_gaussian of the legacy state tuple are passed through untouched"""
+    np.random.seed(3)
+    np.random.standard_normal(1)  # leaves one cached gaussian
+    st = np.random.get_state()
+    assert st[3] == 1
+    ref = np.random.permutation(50)
+    ref_n = np.random.standard_normal(2)
+    np.random.set_state(st)
+    assert np.array_equal(permutation_prefix(50, 50), ref)
+    assert np.array_equal(np.random.standard_normal(2), ref_n)
