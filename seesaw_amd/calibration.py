@@ -9,8 +9,13 @@ class FixedCalibrator:
     def __init__(self, a: float, b: float, sigmoid: bool):
         self.a, self.b, self.sigmoid = a, b, sigmoid
 
-    def get_probabilities(self, vector_scorer, vectors):
-        rescaled = self.a * (vectors @ vector_scorer.reshape(-1) + self.b)
+    def get_probabilities(self, vector_scorer, vectors, scores=None):
+        """`scores`: the index's own scan of `vector_scorer` (AccessMethod.score, on the device) when the caller
+        already has it -- the reference's `vectors @ vector_scorer` (calibration.py:51) over the whole index is the
+        scan this package exists to replace; without it the expression runs as the reference writes it."""
+        if scores is None:
+            scores = vectors @ vector_scorer.reshape(-1)
+        rescaled = self.a * (np.asarray(scores) + self.b)
         return scipy.special.expit(rescaled) if self.sigmoid else rescaled
 
 
@@ -25,8 +30,8 @@ class GroundTruthCalibrator:
     def get_mean(self):
         return self._mean
 
-    def get_probabilities(self, vector_scorer, vectors):
+    def get_probabilities(self, vector_scorer, vectors, scores=None):
         from sklearn.calibration import _SigmoidCalibration
         sc = _SigmoidCalibration()
         sc.fit((self.X @ vector_scorer.reshape(-1)).reshape(-1, 1), self.y)
-        return sc.predict(vectors @ vector_scorer.reshape(-1))
+        return sc.predict(vectors @ vector_scorer.reshape(-1) if scores is None else np.asarray(scores))

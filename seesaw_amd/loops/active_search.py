@@ -56,7 +56,7 @@ class ActiveSearch(LoopBase):
         super().set_text_vec(tvec)
         self.scores = self.q.index.score(tvec)
         if self.gamma["mode"] == "clip":
-            probs = self._calibrator.get_probabilities(tvec, self.q.index.vectors)
+            probs = self._calibrator.get_probabilities(tvec, self.q.index.vectors, scores=self.scores)
             self.prob_model = self.prob_model.with_gamma(np.asarray(probs, dtype=np.float64))
 
     def get_stats(self):
@@ -113,7 +113,7 @@ class LKNNSearch(LoopBase):
         super().set_text_vec(tvec)
         self.scores = self.q.index.score(tvec)
         if self.use_clip_as_gamma:
-            probs = self.scores if self._calibrator is None else self._calibrator.get_probabilities(tvec, self.q.index.vectors)
+            probs = self.scores if self._calibrator is None else self._calibrator.get_probabilities(tvec, self.q.index.vectors, scores=self.scores)
             self.prob_model = self.prob_model.with_gamma(np.asarray(probs, dtype=np.float64))
 
     def next_batch(self):

@@ -303,3 +303,35 @@ def test_larger_labelled_sets_take_the_host_driven_fit():
     eng.set_targets((rng.uniform(size=1024) > 0.5).astype(np.float64), None)
     w, info = eng.fit(obj, w0, 30)
     assert info["on_device"] is True
+
+
+@pytest.mark.parametrize("dim,n", [(512, 0), (512, 1), (512, 33), (256, 70), (768, 90), (1020, 512), (64, 1024)])
+def test_single_launch_fit_other_shapes(dim, n):
+    """the one-launch fit on the shapes around its limits: no rows at all (regulariser only), one row, a ragged last
+    slab, dims that use the 9- and the 16-elements-per-lane driver (dim + 1 <= 576 / <= 1024), the row limit --
+    each equal to the host-driven fit bit for bit"""
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    rng = np.random.default_rng(dim * 7 + n)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    if n:
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+    q = rng.standard_normal(dim).astype(np.float32)
+    y = (rng.uniform(size=n) > 0.6).astype(np.float64)
+    eng = FeedbackEngine(dim)
+    eng.set_query(q)
+    eng.set_data(X, center=n > 0)
+    eng.set_targets(y, rng.uniform(0.5, 1.5, n) if n else None)
+    w0 = (q / np.linalg.norm(q)).astype(np.float32)
+    objs = [_multireg_obj("ce_loss", 0.0, 10.0),
+            _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=1, reg_kind=_lib.SSW_FB_REG_VECTOR,
+                             pos_weight=1.5, reg_weight=1.0 / max(n, 1), margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                             reg_query_lambda=0)]
+    if 2 <= n <= 200 and y.min() != y.max():
+        objs.append(_multireg_obj("pairwise_logistic_loss", 0.0, 1.0))
+    for obj in objs:
+        start = w0 if obj.fit_intercept == 0 else np.concatenate([w0, [0.1]]).astype(np.float32)
+        (wd, idev), (wh, ihost) = _fit_both_drivers(eng, obj, start, max_iter=40)
+        assert idev == ihost, (dim, n, idev, ihost)
+        assert np.array_equal(wd.view(np.uint32), wh.view(np.uint32)), (dim, n, np.abs(wd - wh).max())
+        assert np.isfinite(wd).all()
