@@ -9,7 +9,8 @@ import time
 
 import numpy as np
 
-from .basic_types import ActivationData, BenchParams, Box, Imdata, SessionParams, SessionState, is_image_accepted
+from .basic_types import (ActivationData, BenchParams, Box, Imdata, LogEntry, SessionParams, SessionState,
+                          is_image_accepted)
 from .bitmap import BitMap
 from .indices.interface import AccessMethod
 from .labeldb import LabelDB
@@ -53,8 +54,8 @@ class Session:
         return self.loop.get_stats()
 
     def _log(self, message: str):
-        self.action_log.append({"logger": "server", "time": time.time(), "message": message,
-                                "seen": len(self.seen), "accepted": len(self.accepted)})
+        self.action_log.append(LogEntry.model_construct(logger="server", time=time.time(), message=message,
+                                                        seen=len(self.seen), accepted=len(self.accepted)))
 
     def next(self):
         """next batch of image ids from the loop; the batch and its activations are remembered for get_state"""
