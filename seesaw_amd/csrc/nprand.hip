@@ -38,21 +38,45 @@ inline void mt_reload(uint32_t *key) {
 struct Mt {
     uint32_t *key;
     int pos;
+    uint32_t out[MT_N];  // tempered words of the current block (filled from `pos` on)
+    inline void temper_from(int from) {
+        for (int i = from; i < MT_N; ++i) {
+            uint32_t y = key[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            out[i] = y;
+        }
+    }
     inline uint32_t next32() {
         if (pos == MT_N) {
             mt_reload(key);
             pos = 0;
+            temper_from(0);
         }
-        uint32_t y = key[pos++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
+        return out[pos++];
     }
     inline uint64_t next64() {  // mt19937_next64: high word first
         const uint64_t hi = next32();
         return (hi << 32) | next32();
+    }
+    // numpy's random_interval for max <= 0xffffffff: words are drawn until (word & mask) <= max.  Two candidates are
+    // looked at per trip and the choice made without a branch (the first one is rejected 0-50 % of the time, which a
+    // predictor cannot learn); the stream position advances by exactly the number of words numpy would have drawn.
+    inline uint32_t interval32(uint32_t max, uint32_t mask) {
+        for (;;) {
+            if (pos + 2 <= MT_N) {
+                const uint32_t v1 = out[pos] & mask, v2 = out[pos + 1] & mask;
+                const bool ok1 = v1 <= max;
+                const uint32_t v = ok1 ? v1 : v2;
+                pos += ok1 ? 1 : 2;
+                if (ok1 || v2 <= max) return v;
+            } else {
+                const uint32_t v = next32() & mask;
+                if (v <= max) return v;
+            }
+        }
     }
     inline uint64_t interval(uint64_t max) {
         if (max == 0) return 0;
@@ -63,13 +87,9 @@ struct Mt {
         mask |= mask >> 8;
         mask |= mask >> 16;
         mask |= mask >> 32;
+        if (max <= 0xffffffffull) return interval32((uint32_t)max, (uint32_t)mask);
         uint64_t v;
-        if (max <= 0xffffffffull) {
-            while ((v = (next32() & mask)) > max) {
-            }
-        } else {
-            while ((v = (next64() & mask)) > max) {
-            }
+        while ((v = (next64() & mask)) > max) {
         }
         return v;
     }
@@ -84,7 +104,10 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
     SSW_REQUIRE(n >= 0 && k >= 0, "negative size");
     if (k > n) k = n;
     SSW_REQUIRE(k == 0 || out_prefix, "NULL output");
-    Mt mt{mt_key624, *mt_pos};
+    Mt mt;
+    mt.key = mt_key624;
+    mt.pos = *mt_pos;
+    mt.temper_from(mt.pos);
     // The draws do not depend on the array, only on i: they are made a batch ahead and their targets prefetched, so
     // the swaps (random accesses into a 6-MB array) do not wait for memory one at a time.
     constexpr int BATCH = 64;
