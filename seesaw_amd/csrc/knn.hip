@@ -290,6 +290,233 @@ __global__ __launch_bounds__(512) void k_knn_gemm_filter(const f16 *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// the symmetric last level on 256 x 256 tiles (round 2)
+// ---------------------------------------------------------------------------------------
+// The loop of gemm_bf16.hip's gemm_256 (its comment has the schedule and the hazards): 8 waves of 128 x 64, two LDS
+// stages of four 128-row halves {A0, A1, W0, W1}, a K-tile in four phases of 16 MFMAs, halves restaged as soon as their
+// last fragment read is behind a barrier.  A wave that owns 128 x 64 reads 0.375 fragments per MFMA against 0.75 in
+// the 128 x 128 kernel above, whose K-loop is bound by LDS read bandwidth.  Here the K-tile sequence runs on across the
+// workgroup's column tiles (step s = tile * nk + kt): the first K-tiles of the next column tile are requested while
+// the current tile's last phases multiply and its accumulators are filtered, so the ring never drains.
+// Tiles, super-tiles (8 x 8 tiles per XCD group), the upper-triangle enumeration and `mirror_from` mean what they mean
+// above with an edge of 256; c0 (the columns done by earlier levels) must be a multiple of 256.
+constexpr int KT2 = 256;
+constexpr int K2_HALF = 16384;           // 128 rows x 128 B
+constexpr int K2_STAGE = 4 * K2_HALF;    // A0 A1 W0 W1
+
+__global__ __launch_bounds__(512) void k_knn_gemm_filter256(const f16 *__restrict__ Xh, int D, int n,
+                                                            const float *__restrict__ thr, unsigned *__restrict__ cnt,
+                                                            uint64_t *__restrict__ buf, int i_tiles, int sj_count,
+                                                            int n_super, int mirror_from) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int64_t bid = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const int64_t local = bid >> 3;
+    if ((local >> 3) * 8 + xcd >= n_super) return;
+    const int g = (int)(local >> 3) * 8 + xcd;
+    const int within = (int)(local & 7);
+    int SI, SJ;
+    {  // g enumerates the super-tile pairs SI <= SJ row by row: row SI starts at SI*ns - SI(SI-1)/2
+        const int ns = sj_count;
+        const double b = 2.0 * ns + 1.0;
+        SI = (int)((b - sqrt(b * b - 8.0 * (double)g)) * 0.5);
+        SI = max(0, min(SI, ns - 1));
+        while (SI > 0 && SI * ns - SI * (SI - 1) / 2 > g) --SI;
+        while (SI + 1 < ns && (SI + 1) * ns - (SI + 1) * SI / 2 <= g) ++SI;
+        SJ = SI + (g - (SI * ns - SI * (SI - 1) / 2));
+    }
+    const int I = SI * 8 + within;
+    if (I >= i_tiles) return;
+    const int j_lo = max(SJ * 8, max(I, mirror_from)), j_hi = min(SJ * 8 + 8, i_tiles);
+    if (j_lo >= j_hi) return;
+    const int m0 = I * KT2;
+
+    // staging: a half = 16 pieces of 8 rows x 128 B; wave w issues pieces 2w and 2w + 1 of every half
+    const f16 *a_src[2], *a_src1[2];
+    int p_row[2], p_chunk[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = (wave * 2 + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // the same for row and row + 128
+        p_row[p] = row;
+        p_chunk[p] = chunk * 8;
+        a_src[p] = Xh + (int64_t)min(m0 + row, n - 1) * D + chunk * 8;
+        a_src1[p] = Xh + (int64_t)min(m0 + 128 + row, n - 1) * D + chunk * 8;
+    }
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
+    const unsigned piece_dst = lds0 + wave * 2048;
+#define K2_ISSUE_A0(k0, st) { glds16(a_src[0] + (k0), piece_dst + (st) * K2_STAGE); \
+                              glds16(a_src[1] + (k0), piece_dst + (st) * K2_STAGE + 1024); }
+#define K2_ISSUE_A1(k0, st) { glds16(a_src1[0] + (k0), piece_dst + (st) * K2_STAGE + K2_HALF); \
+                              glds16(a_src1[1] + (k0), piece_dst + (st) * K2_STAGE + K2_HALF + 1024); }
+#define K2_ISSUE_W(J, half, k0, st)                                                                              \
+    {                                                                                                            \
+        const int nb = (J) * KT2 + (half) * 128;                                                                 \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                            \
+            glds16(Xh + (int64_t)min(nb + p_row[p], n - 1) * D + p_chunk[p] + (k0),                              \
+                   piece_dst + (st) * K2_STAGE + (2 + (half)) * K2_HALF + p * 1024);                             \
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+    const int a_frag = wr * K2_HALF + frag0;                                       // + i * 2048, i = 0..7
+    const int w_frag = (2 + (wc >> 1)) * K2_HALF + (wc & 1) * 4 * 2048 + frag0;    // + j * 2048, j = 0..3
+#define K2_READ_A(st, half, dst)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+            dst[i][ks] = *reinterpret_cast<const f16x8 *>(smem + (st) * K2_STAGE + ((a_frag + ((half) * 4 + i) * 2048) ^ (ks * 64)));
+#define K2_READ_W(st, half, dst)                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+            dst[j][ks] = *reinterpret_cast<const f16x8 *>(smem + (st) * K2_STAGE + ((w_frag + ((half) * 2 + j) * 2048) ^ (ks * 64)));
+#define K2_MFMA(ahalf, a, whalf, b)                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                acc[(ahalf) * 4 + i][(whalf) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(          \
+                    b[j][ks], a[i][ks], acc[(ahalf) * 4 + i][(whalf) * 2 + j], 0, 0, 0);                  \
+    __builtin_amdgcn_s_setprio(0);
+#define K2_LGKM0_BARRIER()                                                                               \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                 \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("" ::: "memory");
+
+    // thresholds of this lane's eight rows (accumulator row = m0 + wr*128 + i*16 + fr)
+    float trow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = m0 + wr * 128 + i * 16 + fr;
+        trow[i] = row < n ? thr[row] : INFINITY;
+    }
+    asm volatile("" ::"s"(cnt), "s"(buf), "s"(thr));  // scalar loads done before the loop (gemm_bf16.hip)
+    const int nk = D / KBK;
+    const int S = (j_hi - j_lo) * nk;  // K-tile steps of this workgroup
+    // cursors of the steps s + 1 and s + 2 (column tile, k offset in elements)
+    int J1 = j_lo, k1 = KBK, J2 = j_lo, k2 = 2 * KBK;
+    if (nk == 1) { J1 = j_lo + 1; k1 = 0; }
+    if (nk <= 2) { J2 = j_lo + (nk == 1 ? 2 : 1); k2 = 0; }
+    // prologue: step 0 complete, then W0 W1 A0 of step 1
+    K2_ISSUE_A0(0, 0) K2_ISSUE_A1(0, 0) K2_ISSUE_W(j_lo, 0, 0, 0) K2_ISSUE_W(j_lo, 1, 0, 0)
+    if (S > 1) {
+        K2_ISSUE_W(J1, 0, k1, 1) K2_ISSUE_W(J1, 1, k1, 1) K2_ISSUE_A0(k1, 1)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 a[4][2], b0[2][2], b1[2][2];
+    int J = j_lo, kt = 0;
+    for (int s_ = 0; s_ < S; ++s_) {
+        const int st = s_ & 1, ot = st ^ 1;
+        // phase 1
+        K2_READ_A(st, 0, a)
+        K2_READ_W(st, 0, b0)
+        if (s_ + 1 < S) K2_ISSUE_A1(k1, ot)
+        __builtin_amdgcn_sched_barrier(0);
+        K2_MFMA(0, a, 0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2
+        K2_READ_W(st, 1, b1)
+        K2_LGKM0_BARRIER()      // every wave's W reads of this stage are done
+        K2_MFMA(0, a, 1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3
+        K2_READ_A(st, 1, a)
+        if (s_ + 2 < S) K2_ISSUE_W(J2, 0, k2, st)
+        K2_LGKM0_BARRIER()      // every wave's A reads of this stage are done
+        K2_MFMA(1, a, 1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 4
+        if (s_ + 2 < S) {
+            K2_ISSUE_W(J2, 1, k2, st) K2_ISSUE_A0(k2, st)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // step s + 1 has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        K2_MFMA(1, a, 0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        // advance the cursors
+        k1 = k2; J1 = J2;
+        k2 += KBK;
+        if (k2 == nk * KBK) { k2 = 0; ++J2; }
+        if (++kt < nk) continue;
+        kt = 0;
+        // ---- this column tile is complete: acc[i][j][r] = S~[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
+        const int n0 = J * KT2;
+        const bool mirror = I != J && I >= mirror_from;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float tr = trow[i];
+            const int row = m0 + wr * 128 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = acc[i][j];
+                if (fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > tr) {
+                    const int col = n0 + wc * 64 + j * 16 + fq * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (v[r] > tr && col + r < n) {
+                            const unsigned pos = atomicAdd(&cnt[row], 1u);
+                            if (pos < (unsigned)KNN_CAP)
+                                buf[(int64_t)row * KNN_CAP + pos] =
+                                    ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)(col + r));
+                        }
+                    }
+                }
+            }
+        }
+        if (mirror) {  // entry (j, i) of the symmetric matrix: this tile's columns as rows, its rows as columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wc * 64 + j * 16 + fq * 4;  // thr is padded to a tile multiple with +inf
+                const f32x4 tc = *reinterpret_cast<const f32x4 *>(thr + col);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 v = acc[i][j];
+                    const int row = m0 + wr * 128 + i * 16 + fr;
+                    if (row < n && (v[0] > tc[0] || v[1] > tc[1] || v[2] > tc[2] || v[3] > tc[3])) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (v[r] > tc[r]) {
+                                const unsigned pos = atomicAdd(&cnt[col + r], 1u);
+                                if (pos < (unsigned)KNN_CAP)
+                                    buf[(int64_t)(col + r) * KNN_CAP + pos] =
+                                        ((uint64_t)f32_to_ord(v[r]) << 32) | (uint64_t)(0xFFFFFFFFu - (unsigned)row);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ++J;
+    }
+#undef K2_ISSUE_A0
+#undef K2_ISSUE_A1
+#undef K2_ISSUE_W
+#undef K2_READ_A
+#undef K2_READ_W
+#undef K2_MFMA
+#undef K2_LGKM0_BARRIER
+}
+
+// ---------------------------------------------------------------------------------------
 // per row: keep the best M entries (score desc, column asc), raise the threshold
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_knn_compact(uint64_t *__restrict__ buf, unsigned *__restrict__ cnt,
@@ -408,7 +635,7 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     const bool sym = n > 512 && n <= 8000000 && !(force && force[0] == '1') &&  // (one workgroup per row in k_knn_compact)
                      (double)n * (KNN_CAP * 8.0 + D * 2.0 + 64.0) < 0.6 * (double)free_b;
     const int64_t RB = sym ? n : std::min<int64_t>(n, 131072);
-    const int64_t RBP = (RB + KT - 1) / KT * KT;
+    const int64_t RBP = (RB + KT2 - 1) / KT2 * KT2;  // thresholds padded (+inf) to the larger tile edge
     KNN_HIP(hipMalloc((void **)&sc.perm, (size_t)n * 4));
     KNN_HIP(hipMalloc((void **)&sc.norms, (size_t)n * 4));
     KNN_HIP(hipMalloc((void **)&sc.maxima, 8));
@@ -452,6 +679,17 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
     KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K_STAGE));
+    KNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn_gemm_filter256),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * K2_STAGE));
+    // The symmetric last level can run on 256 x 256 tiles (SSW_KNN_TILE256_FROM = smallest n that takes them; the
+    // tests set 0).  It is NOT the default: measured at 1.56 M rows it takes 1.396 s against 1.369 s for the 128 x 128
+    // kernel (both ~0.9 PFLOP/s of real MFMA work).  Counters for the 256 kernel: MFMA pipes busy 35 %, waves in
+    // s_waitcnt / barriers 51 % of their cycles, L2 hit 91 % at 7.5 TB/s, HBM 0.5 TB/s; with the MFMAs removed the
+    // same loop streams its operands 4.7x faster -- neither operand delivery nor the fragment reads bound it, the
+    // barrier-synchronised phases do (both waves of a SIMD belong to one workgroup and wait together).
+    const char *tile_env = getenv("SSW_KNN_TILE256_FROM");
+    const int64_t big_from = tile_env ? atoll(tile_env) : (int64_t)1 << 62;
+    const bool big_tiles = sym && n >= big_from;
 
     // level boundaries over the permuted columns (multiples of the tile edge): 512, then a constant
     // ratio <= 512 / M up to n: a level appends ~ M x ratio <= 512 entries per row (+- 90), the buffers hold 1024
@@ -465,7 +703,7 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
             const double ratio = std::pow(span, 1.0 / levels);
             for (int l = 1; l < levels; ++l) {
                 const int64_t b = (int64_t)std::llround((double)b0 * std::pow(ratio, l));
-                bounds.push_back(std::min<int64_t>(n, (b + KT - 1) / KT * KT));
+                bounds.push_back(std::min<int64_t>(n, (b + KT2 - 1) / KT2 * KT2));
             }
             bounds.push_back(n);
         }
@@ -473,7 +711,7 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     for (int64_t r0 = 0; r0 < n && rc == SSW_OK; r0 += RB) {
         const int64_t r1 = std::min(n, r0 + RB);
         const int rows = (int)(r1 - r0);
-        const int rows_padded = (rows + KT - 1) / KT * KT;
+        const int rows_padded = (rows + KT2 - 1) / KT2 * KT2;
         hipLaunchKernelGGL(k_knn_reset, dim3((rows_padded + 255) / 256), dim3(256), 0, s, sc.thr, sc.cnt, sc.overflow, rows,
                            rows_padded);
         int64_t c0 = 0;
@@ -481,6 +719,37 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
             const int64_t c1 = bounds[li];
             if (c1 <= c0) continue;
             const bool last_sym = sym && li + 1 == bounds.size() && li > 0;
+            if (last_sym && big_tiles && c0 % KT2 == 0) {
+                const int i_tiles2 = (int)((n + KT2 - 1) / KT2);
+                const int sj2 = (i_tiles2 + 7) / 8;
+                const int64_t n_super2 = (int64_t)sj2 * (sj2 + 1) / 2;
+                const int64_t blocks2 = ((n_super2 + 7) / 8) * 8 * 8;
+                const int64_t gx2 = std::min<int64_t>(blocks2, 1 << 22), gy2 = (blocks2 + gx2 - 1) / gx2;
+                auto kern256 = k_knn_gemm_filter256;
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                const bool timing = getenv("SSW_KNN_TIMING") != nullptr;
+                if (timing) {
+                    (void)hipEventCreate(&ev0);
+                    (void)hipEventCreate(&ev1);
+                    (void)hipEventRecord(ev0, s);
+                }
+                hipLaunchKernelGGL(kern256, dim3((unsigned)gx2, (unsigned)gy2), dim3(512), 2 * K2_STAGE, s, sc.Xh,
+                                   (int)D, (int)n, sc.thr, sc.cnt, sc.buf, i_tiles2, sj2, (int)n_super2, (int)(c0 / KT2));
+                if (timing) {
+                    (void)hipEventRecord(ev1, s);
+                    (void)hipEventSynchronize(ev1);
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, ev0, ev1);
+                    const double tiles = 0.5 * (double)i_tiles2 * i_tiles2 - 0.5 * (double)(c0 / KT2) * (c0 / KT2);
+                    fprintf(stderr, "knn: symmetric level on 256-tiles: %.3f ms, %.0f tiles, %.0f TFLOP/s of MFMA work\n", ms,
+                            tiles, tiles * 2.0 * KT2 * KT2 * D / (ms * 1e-3) / 1e12);
+                    (void)hipEventDestroy(ev0);
+                    (void)hipEventDestroy(ev1);
+                }
+                hipLaunchKernelGGL(k_knn_compact, dim3(rows), dim3(256), 0, s, sc.buf, sc.cnt, sc.thr, sc.overflow, rows, M);
+                c0 = c1;
+                continue;
+            }
             const int i_tiles = (rows + KT - 1) / KT;
             int j_tiles, sj;
             int64_t n_super;

@@ -120,3 +120,25 @@ def test_knn_one_past_the_row_batch(oracle, monkeypatch, batched):
     X = oracle.synth_rows(31, 0, n, 512)
     rows = [0, 1, 127, 128, 131_071, 131_072] + np.random.default_rng(8).integers(0, n, size=20).tolist()
     assert _check_vs_oracle(oracle, X, 10, rows=rows) <= n // 100
+
+
+@pytest.mark.parametrize("n,k,dim", [(600, 10, 512), (1025, 10, 512), (3000, 10, 512), (2500, 3, 768), (2000, 31, 512),
+                                     (4097, 10, 256), (5000, 15, 1024)])
+def test_knn_256_tiles_every_row_vs_oracle(oracle, monkeypatch, n, k, dim):
+    """the symmetric last level on 256 x 256 tiles (k_knn_gemm_filter256; taken from 32 768 rows on by default),
+    forced here at sizes where every row can be held against the oracle: ragged last tiles in both directions, one
+    and several super-tiles, every supported dim (4 ... 16 K-tiles per output tile)"""
+    monkeypatch.setenv("SSW_KNN_TILE256_FROM", "0")
+    X = oracle.synth_rows(300 + n, 0, n, dim)
+    redone = _check_vs_oracle(oracle, X, k)
+    assert redone <= max(2, n // 50)
+
+
+def test_knn_256_tiles_clustered_duplicates(oracle, monkeypatch):
+    monkeypatch.setenv("SSW_KNN_TILE256_FROM", "0")
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    X = np.concatenate([g["X"], g["X"][::-1] * np.float32(1.0)])  # every row twice: ties across tiles
+    if X.shape[0] <= 512:
+        X = np.concatenate([X, X, X])
+    redone = _check_vs_oracle(oracle, X, 10)
+    assert redone <= X.shape[0] // 5
