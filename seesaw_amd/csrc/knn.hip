@@ -686,7 +686,9 @@ extern "C" ssw_status ssw_knn_build(ssw_index *index, int32_t k, uint64_t seed, 
     // kernel (both ~0.9 PFLOP/s of real MFMA work).  Counters for the 256 kernel: MFMA pipes busy 35 %, waves in
     // s_waitcnt / barriers 51 % of their cycles, L2 hit 91 % at 7.5 TB/s, HBM 0.5 TB/s; with the MFMAs removed the
     // same loop streams its operands 4.7x faster -- neither operand delivery nor the fragment reads bound it, the
-    // barrier-synchronised phases do (both waves of a SIMD belong to one workgroup and wait together).
+    // barrier-synchronised phases do.  A third structure was measured and dropped: 128 x 256 x 32 tiles, four waves per
+    // workgroup, two workgroups per CU (so that a SIMD's two waves drift apart), three 24-KB stages, one barrier per
+    // K-step -- bit-exact as well, 1.553 s.
     const char *tile_env = getenv("SSW_KNN_TILE256_FROM");
     const int64_t big_from = tile_env ? atoll(tile_env) : (int64_t)1 << 62;
     const bool big_tiles = sym && n >= big_from;
