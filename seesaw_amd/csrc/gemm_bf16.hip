@@ -586,6 +586,12 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
     return SSW_OK;
 }
 
+// (Round 2 also measured an anti-phase form of this kernel -- waves 0-3 multiply a whole K-tile from registers while
+//  waves 4-7 read their fragments of the next one and issue the LDS-DMA, roles swapping at every barrier, halves issued
+//  two intervals ahead of their first read: same results bit for bit, 511 TFLOP/s on fc1 against 800 for gemm_256 and
+//  320 against 930 (128 x 128 kernel) on fc2 -- an interval took ~3 700 cycles against 1 024 of MFMA work, i.e. every
+//  interval ended waiting for the DMA issued in the interval before.  Removed again)
+
 int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
