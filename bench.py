@@ -329,6 +329,47 @@ def c2_extras(device: int):
     return out
 
 
+def fit_extras(device: int):
+    """the feedback update alone (MultiReg ce_loss objective, 200 L-BFGS iterations allowed) on labelled sets the size
+    a session reaches: the whole step(closure) as one kernel launch against the same fit driven from the host one
+    closure evaluation at a time (bit-identical results: tests/test_feedback_gpu.py), ms per fit over 20 fits"""
+    import numpy as np
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FbObjective, FeedbackEngine
+    rng = np.random.default_rng(0)
+    out = {}
+    for n in (52, 208, 390):
+        X = rng.standard_normal((n, 512)).astype(np.float32)
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        q = X[:5].mean(0)
+        y = (X @ q > np.quantile(X @ q, 0.8)).astype(np.float64)
+        eng = FeedbackEngine(512, device=device)
+        eng.set_query(q / np.linalg.norm(q))
+        eng.set_data(X, center=True)
+        eng.set_targets(y, np.ones(n))
+        obj = FbObjective(kind=_lib.SSW_FB_MULTIREG, loss_type=_lib.SSW_FB_LOSS_CE, fit_intercept=0, reg_kind=0,
+                          pos_weight=-1.0, reg_weight=0.0, margin=0.0, reg_norm_lambda=100.0, reg_data_lambda=0.0,
+                          reg_query_lambda=0.0)
+        w0 = (q / np.linalg.norm(q)).astype(np.float32)
+        row = {}
+        for tag, host in (("one_launch", False), ("host_driven", True)):
+            if host:
+                os.environ["SSW_FB_HOST_DRIVER"] = "1"
+            try:
+                eng.fit(obj, w0, 200)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    _, info = eng.fit(obj, w0, 200)
+                row[tag + "_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+            finally:
+                os.environ.pop("SSW_FB_HOST_DRIVER", None)
+            assert info["on_device"] is (not host)
+        row.update(closure_evaluations=info["func_evals"], lbfgs_iterations=info["n_iter"])
+        out[f"rows_{n}"] = row
+        eng.close()
+    return out
+
+
 SCAN_KERNEL = "scan_scores_kernel<2,2,nt>"          # what launch_scan runs by default (scan.hip)
 SCAN_SOURCES = ("seesaw_amd/csrc/scan.hip",)
 
@@ -514,6 +555,7 @@ def main():
         if world == 1 and not args.no_extras:
             extras = {}
             for key, fn in (("c2_one_million_rows", lambda: c2_extras(local_rank)),
+                            ("feedback_fit", lambda: fit_extras(local_rank)),
                             ("feedback_loop", lambda: feedback_loop_extras(local_rank, args.loop_images)),
                             ("clip", lambda: clip_extras(local_rank))):
                 try:
