@@ -592,6 +592,10 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 //  320 against 930 (128 x 128 kernel) on fc2 -- an interval took ~3 700 cycles against 1 024 of MFMA work, i.e. every
 //  interval ended waiting for the DMA issued in the interval before.  Removed again)
 
+// (And a 256 x 256 x 32 tile with a four-stage ring -- operands requested three K-steps ahead, 96 KB in flight per CU,
+//  one barrier per step, 188 VGPRs: same results, 693 TFLOP/s on fc1 and 507 on fc2.  So the waits of the two-stage
+//  kernels are not a shortage of operands in flight either.  Removed again.)
+
 int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
