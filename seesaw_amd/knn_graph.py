@@ -102,15 +102,31 @@ def post_process_graph_df(df: pd.DataFrame, nvec: int) -> pd.DataFrame:
     dist = np.clip(df.distance.values.astype("float32"), a_min=0.0, a_max=None)
     keep = src != dst
     src, dst, dist = src[keep], dst[keep], dist[keep]
-    order = np.lexsort((np.arange(src.shape[0]), dist, src))
-    src, dst, dist = src[order], dst[order], dist[order]
+    # rank within a vertex = position after a stable sort by (src_vertex, distance).  The graph builders hand the edges
+    # over in exactly that order already (rows in vertex order, neighbours by descending score): checking costs one
+    # pass, the three-key sort of 17 M edges it avoids cost 3.2 s of the 5.7-s build at 1.56 M vectors
+    if src.shape[0] > 1:
+        same = src[1:] == src[:-1]
+        in_order = bool(np.all(src[1:] >= src[:-1]) and np.all(dist[1:][same] >= dist[:-1][same]))
+    else:
+        in_order = True
+    if not in_order:
+        order = np.lexsort((np.arange(src.shape[0]), dist, src))
+        src, dst, dist = src[order], dst[order], dist[order]
+    n_edges = src.shape[0]
     starts = np.concatenate(([0], np.cumsum(np.bincount(src, minlength=nvec))))[:-1]
-    rank = (np.arange(src.shape[0]) - starts[src] + 1).astype("int32")
+    rank = (np.arange(n_edges) - starts[src] + 1).astype("int32")
+    # merged with the rank-0 self edges in (src_vertex, dst_rank) order without another sort: vertex v's block starts
+    # after the edges of the vertices before it and their v self edges
+    pos_edges = np.arange(n_edges, dtype=np.int64) + src.astype(np.int64) + 1
+    pos_self = starts.astype(np.int64) + np.arange(nvec, dtype=np.int64)
+    total = n_edges + nvec
+    o_src, o_dst = np.empty(total, dtype="int32"), np.empty(total, dtype="int32")
+    o_dist, o_rank = np.empty(total, dtype="float32"), np.empty(total, dtype="int32")
     ids = np.arange(nvec, dtype="int32")
-    out = pd.DataFrame({"src_vertex": np.concatenate([src, ids]), "dst_vertex": np.concatenate([dst, ids]),
-                        "distance": np.concatenate([dist, np.zeros(nvec, dtype="float32")]),
-                        "dst_rank": np.concatenate([rank, np.zeros(nvec, dtype="int32")])})
-    return out.sort_values(["src_vertex", "dst_rank"]).reset_index(drop=True)
+    o_src[pos_edges], o_dst[pos_edges], o_dist[pos_edges], o_rank[pos_edges] = src, dst, dist, rank
+    o_src[pos_self], o_dst[pos_self], o_dist[pos_self], o_rank[pos_self] = ids, ids, np.float32(0.0), 0
+    return pd.DataFrame({"src_vertex": o_src, "dst_vertex": o_dst, "distance": o_dist, "dst_rank": o_rank})
 
 
 def compute_exact_knn(vectors: np.ndarray, n_neighbors: int, device_index=None, device: int = 0) -> pd.DataFrame:

@@ -116,10 +116,10 @@ class SyntheticDataset:
                 from .indices.multiscale.multiscale_index import MultiscaleIndex
                 idx = MultiscaleIndex(embedding=self.embedding, vectors=self.vectors, vector_meta=self.vector_meta,
                                       vec_index=None, path=self.path, device=self.device)
+            self._index = idx  # before the graph is built: knn_graph() then uses the matrix the index already holds in HBM
             if self.knn_k > 0:
                 graph = self.knn_graph()
                 idx.knng = {name: graph for name in ("exact", "nndescent60", "")}
-            self._index = idx
         return self._index
 
 
