@@ -160,6 +160,12 @@ ssw_status ssw_index_set_tile_meta(ssw_index *idx, const float *boxes_host, cons
  * pandas' float32 group mean (Kahan sum): bit-identical to the reference on identical tile scores. */
 ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions, int32_t m, int32_t aug_larger,
                                  const float *minus_scores_or_null, float *out_scores, int64_t *out_best_rows);
+/* the same aggregation over float64 tile scores that live on the device, one per index row (the output of
+ * ssw_labelprop_run_resident: ssw_labelprop_device_scores) -- what the graph loops' own rescoring does with the
+ * propagated scores (`fullmeta.assign(score=scores[rows])` then rescore_candidates, seesaw/loops/graph_based.py:100-108):
+ * mean = pandas' float64 group mean (Kahan sum in f64), IoU in f32 as above. */
+ssw_status ssw_index_rescore_avg_f64(ssw_index *idx, const double *dev_scores, const int64_t *image_positions, int32_t m,
+                                     int32_t aug_larger, double *out_scores, int64_t *out_best_rows);
 
 /* merge several sorted key lists (e.g. the all-gathered per-shard top-k of a
  * row-sharded index; keys as in ssw_index_result_ptrs but with GLOBAL image ids
@@ -215,6 +221,8 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
                                       int32_t *out_sweeps, int32_t *out_converged);
 ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host);
 ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled);
+/* device address of the [n] f64 result of the last propagation (valid until the next run on this handle). */
+ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores);
 
 /* Exact k-NN graph over the resident matrix (rows as vertices, cosine / dot similarity):
  * replaces compute_exact_knn, seesaw/knn_graph.py:170-191 (`1 - X @ X.T`, argsort, first k+1).

@@ -641,12 +641,20 @@ def gen_bench_loop():
         "knn_prop2_b": ("B", "knn_prop2", lp_opts),
         "pseudo_lr_b": ("B", "pseudo_lr", dict(switch_over=True, real_sample_weight=1.0, sample_size=2000,
                                                log_reg_params=logreg_opts, label_prop_params=lp_opts)),
+        # the aggregation of the reference's standard bench config (scripts/configs/std_bench.yaml:23-24) inside
+        # whole sessions (batch size 1: the reference's reversal check takes `batch in accepted`, which only a
+        # one-element batch survives, seesaw_session.py:118-130) and the graph loop's own rescoring branch
+        "plain_avg": ("A", "plain", None),
+        "knn_prop2_b_avg": ("B", "knn_prop2", lp_opts),
     }
+    session_overrides = {"plain_avg": dict(agg_method="avg_score", aug_larger="all", batch_size=1),
+                         "knn_prop2_b_avg": dict(agg_method="avg_score", aug_larger="greater", batch_size=1)}
     out = {"names": np.array(list(variants)), "datasets": np.asarray(json.dumps(BENCH_LOOP_DATASETS)),
            "seeds": np.asarray(BENCH_LOOP_SEEDS),
            "knn_pool": np.asarray(BENCH_LOOP_KNN_POOL),
            "variant_dataset": np.array([v[0] for v in variants.values()]),
-           "variant_interactive": np.array([v[1] for v in variants.values()])}
+           "variant_interactive": np.array([v[1] for v in variants.values()]),
+           "session_overrides": np.asarray(json.dumps(session_overrides))}
     built = {}
     for key, spec in BENCH_LOOP_DATASETS.items():
         ds = make_dataset("lvis", knn_k=0, **spec["make"])
@@ -677,9 +685,10 @@ def gen_bench_loop():
             index = coarse.CoarseIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta)
         else:
             index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+        over = dict(agg_method="plain_score", aug_larger="greater", batch_size=1)
+        over.update(session_overrides.get(name, {}))
         p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="coarse" if is_coarse else "multiscale", c_name=None),
-                             interactive=interactive, interactive_options=opts, batch_size=1, shortlist_size=50,
-                             agg_method="plain_score", aug_larger="greater",
+                             interactive=interactive, interactive_options=opts, shortlist_size=50, **over,
                              # the reference's KnnProp2 never sets curr_qvec, and its start-policy check reads
                              # the multiscale form of getXy (loop_base.py:82-83): both only run from_start
                              start_policy="from_start" if (interactive == "knn_prop2" or is_coarse) else "after_first_batch",
@@ -719,7 +728,7 @@ def gen_bench_loop():
                     out[f"{name}_fit{r}_traj_w"], out[f"{name}_fit{r}_traj_loss"], out[f"{name}_fit{r}_traj_grad"] = cap["traj"]
             if captured:
                 out[f"{name}_n_fits"] = np.asarray(min(len(captured), 8))
-            shown = np.array([int(a[0]) for a in session.acc_indices], dtype=np.int64)
+            shown = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in session.acc_indices])
             suffix = "" if seed == BENCH_LOOP_SEEDS[0] else f"_seed{seed}"
             out[f"{name}_shown{suffix}"] = shown
             out[f"{name}_nfound{suffix}"] = np.asarray(res["nfound"])

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ssw_index_topk_dev": (c_i32, [c_void_p, c_void_p, c_i32]),
     "ssw_index_set_tile_meta": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_index_rescore_avg": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "ssw_index_rescore_avg_f64": (c_i32, [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p]),
     "ssw_index_select_deep_dev": (c_i32, [c_void_p, c_i32]),
     "ssw_index_result_ptrs": (c_i32, [c_void_p, c_void_pp, c_void_pp, c_void_pp]),
     "ssw_index_topk_fetch": (c_i32, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32_p]),
@@ -81,6 +82,7 @@ _SIGNATURES = {
     "ssw_labelprop_run_resident": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, c_i32, c_void_p, c_void_p]),
     "ssw_labelprop_fetch": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_scores_to_index": (c_i32, [c_void_p, c_void_p, c_i32]),
+    "ssw_labelprop_device_scores": (c_i32, [c_void_p, ctypes.POINTER(c_void_p)]),
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_knn_build": (c_i32, [c_void_p, c_i32, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),

@@ -444,6 +444,60 @@ ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions,
     return SSW_OK;
 }
 
+ssw_status ssw_index_rescore_avg_f64(ssw_index *idx, const double *dev_scores, const int64_t *image_positions, int32_t m,
+                                     int32_t aug_larger, double *out_scores, int64_t *out_best_rows) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (m <= 0) return SSW_OK;
+    SSW_REQUIRE(dev_scores && image_positions && out_scores && out_best_rows, "NULL argument");
+    SSW_REQUIRE(aug_larger >= 0 && aug_larger <= 2, "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent)", aug_larger);
+    SSW_REQUIRE(idx->has_map && idx->tile_boxes && idx->tile_zoom,
+                "rescore_avg needs ssw_index_set_row2image and ssw_index_set_tile_meta first");
+    DeviceGuard guard(idx->device);
+    std::vector<int64_t> off((size_t)m);
+    int64_t total = 0, max_tiles = 0;
+    for (int32_t c = 0; c < m; ++c) {
+        const int64_t p = image_positions[c];
+        SSW_REQUIRE(p >= 0 && p < idx->n_images, "image position %lld outside [0, %lld)", (long long)p,
+                    (long long)idx->n_images);
+        const int64_t t = idx->row_start_host[(size_t)p + 1] - idx->row_start_host[(size_t)p];
+        off[(size_t)c] = total;
+        total += t;
+        max_tiles = std::max(max_tiles, t);
+    }
+    hipStream_t s = idx->stream;
+    int64_t *d_pos = nullptr, *d_off = nullptr, *d_row = nullptr;
+    double *d_score = nullptr;
+    auto release = [&]() {
+        for (void *q : {(void *)d_pos, (void *)d_off, (void *)d_row, (void *)d_score}) (void)hipFree(q);
+    };
+    // (a few hundred bytes per call and one call per round of a graph loop: plain allocations keep this entry
+    //  independent of the f32 path's cached buffers)
+    if (hipMalloc((void **)&d_pos, (size_t)m * 8) != hipSuccess || hipMalloc((void **)&d_off, (size_t)m * 8) != hipSuccess ||
+        hipMalloc((void **)&d_row, (size_t)m * 8) != hipSuccess || hipMalloc((void **)&d_score, (size_t)m * 8) != hipSuccess) {
+        release();
+        set_error("rescore_avg_f64: allocation failed");
+        return SSW_ERR_NOMEM;
+    }
+    ssw_status rc = SSW_OK;
+    hipError_t e = hipMemcpyAsync(d_pos, image_positions, (size_t)m * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (size_t)m * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        rc = launch_avg_score_f64(idx->tile_boxes, idx->tile_zoom, dev_scores, idx->row_start, d_pos, d_off, m,
+                                  (int32_t)max_tiles, aug_larger, d_score, d_row, s);
+    if (e == hipSuccess && rc == SSW_OK) e = hipMemcpyAsync(out_scores, d_score, (size_t)m * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == SSW_OK) e = hipMemcpyAsync(out_best_rows, d_row, (size_t)m * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    else (void)hipStreamSynchronize(s);
+    release();
+    if (rc != SSW_OK) return rc;
+    if (e != hipSuccess) {
+        set_error("rescore_avg_f64: %s", hipGetErrorString(e));
+        return SSW_ERR_HIP;
+    }
+    return SSW_OK;
+}
+
 ssw_status ssw_index_scan_dev(ssw_index *idx, const float *q_dev) {
     SSW_REQUIRE(idx != nullptr && q_dev != nullptr, "NULL argument");
     DeviceGuard guard(idx->device);

@@ -702,6 +702,13 @@ ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host) {
     return SSW_OK;
 }
 
+ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores) {
+    SSW_REQUIRE(lp != nullptr && out_dev_scores != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_device_scores: nothing has been propagated yet");
+    *out_dev_scores = lp->f[lp->last_result];
+    return SSW_OK;
+}
+
 ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled) {
     SSW_REQUIRE(lp != nullptr && index != nullptr, "NULL argument");
     SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_scores_to_index: nothing has been propagated yet");

@@ -40,14 +40,18 @@ __device__ __forceinline__ float iou_f32(const float4 a, float area_a, const flo
 // boxes: x1, y1, x2, y2 per row.  cand_pos[c] = image position; its rows are [row_start[p], row_start[p+1]).
 // minus (optional) holds one value per candidate row, in candidate order (cand_off[c] = first), subtracted from
 // the resident score (the vector2 form of MultiscaleIndex.query).
+// ST = the dtype of the score column: float for the scan's scores (pandas' float32 group mean), double for the graph
+// loops, which hand rescore_candidates the label-propagation output as float64 (graph_based.py:100-108; pandas' float64
+// group mean is the same Kahan sum in f64).  IoUs are f32 either way (the boxes are).
+template <typename ST>
 __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restrict__ boxes,
                                                           const int32_t *__restrict__ zoom,
-                                                          const float *__restrict__ scores,
-                                                          const float *__restrict__ minus_or_null,
+                                                          const ST *__restrict__ scores,
+                                                          const ST *__restrict__ minus_or_null,
                                                           const int64_t *__restrict__ row_start,
                                                           const int64_t *__restrict__ cand_pos,
                                                           const int64_t *__restrict__ cand_off, int aug,
-                                                          float *__restrict__ out_score,
+                                                          ST *__restrict__ out_score,
                                                           int64_t *__restrict__ out_row) {
     extern __shared__ float4 sh4[];
     const int c = blockIdx.x;
@@ -55,10 +59,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restri
     const int64_t r0 = row_start[p];
     const int T = (int)(row_start[p + 1] - r0);
     float4 *sbox = sh4;                                   // [T]
-    float *sarea = reinterpret_cast<float *>(sbox + T);  // [T]
-    float *sscore = sarea + T;                            // [T]
-    float *sagg = sscore + T;                             // [T]
-    int *szoom = reinterpret_cast<int *>(sagg + T);       // [T]
+    ST *sscore = reinterpret_cast<ST *>(sbox + T);        // [T]  (8-byte types first: the base is 16-byte aligned)
+    ST *sagg = sscore + T;                                // [T]
+    float *sarea = reinterpret_cast<float *>(sagg + T);   // [T]
+    int *szoom = reinterpret_cast<int *>(sarea + T);      // [T]
     __shared__ unsigned level_mask;
     if (threadIdx.x == 0) level_mask = 0u;
     __syncthreads();
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restri
         const float4 b = boxes[r0 + i];
         sbox[i] = b;
         sarea[i] = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
-        float s = scores[r0 + i];
-        if (minus_or_null) s = __fsub_rn(s, minus_or_null[cand_off[c] + i]);
+        ST s = scores[r0 + i];
+        if (minus_or_null) s = s - minus_or_null[cand_off[c] + i];
         sscore[i] = s;
         const int z = zoom[r0 + i];
         szoom[i] = z;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restri
         const float4 bi = sbox[i];
         const float ai = sarea[i];
         const int zi = szoom[i];
-        float sum = 0.f, comp = 0.f;  // Kahan pair
+        ST sum = 0, comp = 0;  // Kahan pair
         int groups = 0;
         for (unsigned m = levels; m != 0u; m &= m - 1u) {
             const int z = __ffs(m) - 1;  // ascending zoom level
@@ -96,52 +100,76 @@ __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restri
                 }
             }
             if (bj >= 0) {
-                const float y = __fsub_rn(sscore[bj], comp);
-                const float t = __fadd_rn(sum, y);
-                comp = __fsub_rn(__fsub_rn(t, sum), y);
+                const ST y = sscore[bj] - comp;  // (this file is compiled without fma contraction)
+                const ST t = sum + y;
+                comp = (t - sum) - y;
                 sum = t;
                 ++groups;
             }
         }
-        sagg[i] = groups > 0 ? __fdiv_rn(sum, (float)groups) : __builtin_nanf("");
+        sagg[i] = groups > 0 ? sum / (ST)groups : (ST)__builtin_nanf("");
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // first tile with the highest aggregated score (NaN skipped, as pandas' max does)
         int bi = -1;
-        float bv = 0.f;
+        ST bv = 0;
         for (int i = 0; i < T; ++i) {
-            const float v = sagg[i];
+            const ST v = sagg[i];
             if (v != v) continue;
             if (bi < 0 || v > bv) {
                 bv = v;
                 bi = i;
             }
         }
-        out_score[c] = bi >= 0 ? bv : __builtin_nanf("");
+        out_score[c] = bi >= 0 ? bv : (ST)__builtin_nanf("");
         out_row[c] = r0 + (bi >= 0 ? bi : 0);
     }
 }
 
 }  // namespace
 
-size_t avg_score_lds_bytes(int max_tiles) {
-    return (size_t)max_tiles * (sizeof(float4) + 3 * sizeof(float) + sizeof(int));
+size_t avg_score_lds_bytes(int max_tiles, size_t score_bytes) {
+    return (size_t)max_tiles * (sizeof(float4) + 2 * score_bytes + sizeof(float) + sizeof(int));
 }
 
-ssw_status launch_avg_score(const float *boxes, const int32_t *zoom, const float *scores, const float *minus_or_null,
-                            const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
-                            int32_t max_tiles, int32_t aug, float *out_score, int64_t *out_row, hipStream_t stream) {
+template <typename ST>
+static ssw_status launch_avg_score_t(const float *boxes, const int32_t *zoom, const ST *scores, const ST *minus_or_null,
+                                     const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
+                                     int32_t max_tiles, int32_t aug, ST *out_score, int64_t *out_row, hipStream_t stream) {
     if (m <= 0) return SSW_OK;
     if (max_tiles > SSW_RESCORE_MAX_TILES) {
         set_error("avg_score: an image with %d tiles exceeds the %d the kernel keeps in LDS", max_tiles,
                   SSW_RESCORE_MAX_TILES);
         return SSW_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_avg_score, dim3((unsigned)m), dim3(RS_THREADS), avg_score_lds_bytes(max_tiles), stream,
+    const size_t lds = avg_score_lds_bytes(max_tiles, sizeof(ST));
+    if (lds > (size_t)64 * 1024) {  // 2048 tiles of f64 scores: 80 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_avg_score<ST>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(k_avg_score<ST>, dim3((unsigned)m), dim3(RS_THREADS), lds, stream,
                        reinterpret_cast<const float4 *>(boxes), zoom, scores, minus_or_null, row_start, cand_pos,
                        cand_off, (int)aug, out_score, out_row);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
+}
+
+ssw_status launch_avg_score(const float *boxes, const int32_t *zoom, const float *scores, const float *minus_or_null,
+                            const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
+                            int32_t max_tiles, int32_t aug, float *out_score, int64_t *out_row, hipStream_t stream) {
+    return launch_avg_score_t<float>(boxes, zoom, scores, minus_or_null, row_start, cand_pos, cand_off, m, max_tiles, aug,
+                                     out_score, out_row, stream);
+}
+
+ssw_status launch_avg_score_f64(const float *boxes, const int32_t *zoom, const double *scores,
+                                const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
+                                int32_t max_tiles, int32_t aug, double *out_score, int64_t *out_row, hipStream_t stream) {
+    return launch_avg_score_t<double>(boxes, zoom, scores, (const double *)nullptr, row_start, cand_pos, cand_off, m,
+                                      max_tiles, aug, out_score, out_row, stream);
 }
 
 }  // namespace ssw

@@ -176,5 +176,9 @@ constexpr int SSW_RESCORE_MAX_ZOOM = 31;     // zoom levels index a 32-bit prese
 ssw_status launch_avg_score(const float *boxes, const int32_t *zoom, const float *scores, const float *minus_or_null,
                             const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
                             int32_t max_tiles, int32_t aug, float *out_score, int64_t *out_row, hipStream_t stream);
+// the same aggregation over float64 scores that live on the device (label-propagation output)
+ssw_status launch_avg_score_f64(const float *boxes, const int32_t *zoom, const double *scores,
+                                const int64_t *row_start, const int64_t *cand_pos, const int64_t *cand_off, int32_t m,
+                                int32_t max_tiles, int32_t aug, double *out_score, int64_t *out_row, hipStream_t stream);
 
 }  // namespace ssw

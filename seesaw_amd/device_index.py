@@ -181,6 +181,17 @@ class DeviceIndex:
                   _ptr(scores), _ptr(rows))
         return scores, rows
 
+    def rescore_avg_f64(self, dev_scores_ptr: int, image_positions: np.ndarray, aug_larger: str):
+        """rescore_avg over float64 tile scores resident on the device (one per index row, e.g. the label-propagation
+        output): -> (aggregated score f64 [m], best tile's row int64 [m])"""
+        pos = np.ascontiguousarray(image_positions, dtype=np.int64)
+        m = pos.shape[0]
+        scores = np.empty(m, dtype=np.float64)
+        rows = np.empty(m, dtype=np.int64)
+        _lib.call("ssw_index_rescore_avg_f64", self._h, ctypes.c_void_p(int(dev_scores_ptr)), _ptr(pos), m,
+                  self.AUG_LARGER[aug_larger], _ptr(scores), _ptr(rows))
+        return scores, rows
+
     # -- device-resident forms (bench / sharded index) --------------------------------
     def set_excluded(self, excluded: Optional[Iterable[int]]):
         ex = None

@@ -307,6 +307,15 @@ class MultiscaleIndex(AccessMethod):
         return {"dbidxs": self._dbidx[positions[top]].astype("int"),
                 "activations": ActivationFrames(self._box[rows[top]], self._row_dbidx[rows[top]], scores[top])}
 
+    def rescore_avg_from_device_scores(self, candidate_df, topk, aug_larger, dev_scores_ptr: int):
+        """rescore_candidates(fullmeta with score = the caller's float64 per-row scores, agg 'avg_score') for scores that
+        are on the device already -- the graph loops' second stage (graph_based.py:100-108) in one kernel launch"""
+        positions = np.sort(np.asarray(candidate_df.attrs["positions"], dtype=np.int64))
+        scores, rows = self._dev.rescore_avg_f64(dev_scores_ptr, positions, aug_larger)
+        top = np.argsort(-scores, kind="stable")[:topk]
+        return {"dbidxs": self._dbidx[positions[top]].astype("int"),
+                "activations": ActivationFrames(self._box[rows[top]], self._row_dbidx[rows[top]], scores[top])}
+
     def new_query(self):
         return BoxFeedbackQuery(self)
 

@@ -81,6 +81,12 @@ class LabelPropagation:
         _lib.call("ssw_labelprop_fetch", self._h, _p(out))
         return out
 
+    def device_scores_ptr(self) -> int:
+        """device address of the f64 result of the last propagation"""
+        out = ctypes.c_void_p()
+        _lib.call("ssw_labelprop_device_scores", self._h, ctypes.byref(out))
+        return int(out.value)
+
     def scores_to_index(self, device_index, mask_labeled: bool = True):
         """last result -> the index's f32 score buffer (labelled nodes at -inf), ready for topk(None, ...)"""
         _lib.call("ssw_labelprop_scores_to_index", self._h, device_index._h, int(bool(mask_labeled)))

@@ -106,8 +106,10 @@ class KnnProp2(LoopBase):
         """next images by propagated score: unlabelled vectors only, distinct non-returned
         images, then the usual per-image aggregation (graph_based.py:88-109)."""
         model, p, q = self.state.knn_model, self.params, self.q
-        on_device = getattr(model, "scores_on_device", lambda: False)() and p.agg_method == "plain_score" \
-            and hasattr(q.index, "topk_from_device_scores")
+        resident = getattr(model, "scores_on_device", lambda: False)() and hasattr(q.index, "topk_from_device_scores")
+        avg_on_device = resident and p.agg_method != "plain_score" and getattr(q.index, "_has_tile_meta", False) \
+            and getattr(p, "aug_weight", None) in (None, "level_max") and hasattr(q.index, "rescore_avg_from_device_scores")
+        on_device = resident and (p.agg_method == "plain_score" or avg_on_device)
         if on_device:  # propagated scores go from the graph handle to the index's score buffer on the GPU
             cand = q.index.topk_from_device_scores(lambda dev: model.lp.scores_to_index(dev, mask_labeled=True),
                                                    topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned)
@@ -118,6 +120,8 @@ class KnnProp2(LoopBase):
                                             skip_rows=model.is_labeled > 0)
         if p.agg_method == "plain_score":  # best tile per image came back with the selection
             ans = q.index._activations_from_best(cand, p.batch_size)
+        elif avg_on_device:  # the averaging aggregation over the UNMASKED f64 scores, where they are
+            ans = q.index.rescore_avg_from_device_scores(cand, p.batch_size, p.aug_larger, model.lp.device_scores_ptr())
         else:
             rows = q.index._candidate_rows(cand.attrs["positions"])
             fullmeta = q.index.vector_meta.iloc[rows].assign(score=np.asarray(scores)[rows])

@@ -123,7 +123,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 SEQUENCE_VARIANTS = ["plain", "rocchio_update", "multi_reg", "multi_reg_data", "knn_prop2", "plain_c", "log_reg2_c",
-                     "plain_b", "knn_prop2_b", "pseudo_lr_b"]
+                     "plain_b", "knn_prop2_b", "pseudo_lr_b", "plain_avg", "knn_prop2_b_avg"]
 
 
 @pytest.fixture(scope="module")
@@ -161,9 +161,10 @@ def test_benchmark_loop_sequence_matches_reference(sequence_datasets, name):
     key, interactive = str(g["variant_dataset"][i]), str(g["variant_interactive"][i])
     gdm, ds, coarse = datasets[key]
     opts_name = {"multi_reg_data": "multi_reg_data"}.get(name, interactive)
+    over = dict(agg_method="plain_score", aug_larger="greater", batch_size=1)
+    over.update(json.loads(str(g["session_overrides"])).get(name, {}))  # plain_avg / knn_prop2_b_avg: avg_score sessions
     p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="coarse" if coarse else "multiscale", c_name=None),
-                      interactive=interactive, interactive_options=LOOPS[opts_name], batch_size=1, shortlist_size=50,
-                      agg_method="plain_score", aug_larger="greater",
+                      interactive=interactive, interactive_options=LOOPS[opts_name], shortlist_size=50, **over,
                       start_policy="from_start" if (interactive == "knn_prop2" or coarse) else "after_first_batch",
                       index_options={"use_vec_index": False})
     b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
@@ -172,7 +173,7 @@ def test_benchmark_loop_sequence_matches_reference(sequence_datasets, name):
     ret = make_session(gdm, p, b=b)
     boxes, _ = ds.load_ground_truth()
     out = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
-    shown = np.array([int(a[0]) for a in ret["session"].acc_indices])
+    shown = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in ret["session"].acc_indices])
     ref = g[f"{name}_shown"]
     stable = _stable_rounds(g, name)
     print(f"{name}: reference reproduces itself over {stable} of {len(ref)} rounds; ours equals it over "

@@ -235,3 +235,37 @@ def test_multiscale_getxy_and_subset(oracle):
     sub = index.subset(BitMap([3, 4, 5]))
     assert len(sub) == 3 and sub.vectors.shape[0] == 12
     assert index.subset(BitMap(range(n_images))) is index
+
+
+def test_avg_score_over_device_f64_scores_equals_the_host_loop():
+    """ssw_index_rescore_avg_f64 (float64 scores on the device: what the graph loops re-score with) against the host
+    restatement of the reference's rescore_candidates over the same float64 column: same images, same activation
+    boxes, bit-identical scores -- for the three aug_larger modes"""
+    import ctypes
+    from seesaw_amd import _lib
+    from seesaw_amd.indices.multiscale.multiscale_index import MultiscaleIndex, rescore_candidates
+    from seesaw_amd.synthetic import make_dataset
+    ds = make_dataset("lvis", n_images=120, tiles_per_image=13, n_categories=2, positive_frac=0.1, seed=3, knn_k=0)
+    idx = MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+    assert idx._has_tile_meta
+    rng = np.random.default_rng(9)
+    scores64 = rng.uniform(0, 1, ds.vectors.shape[0])  # float64, like a label-propagation result
+    scores64[rng.integers(0, scores64.shape[0], 200)] = 0.5  # exact ties
+    lib = _lib.load()
+    torch = pytest.importorskip("torch")
+    dev_scores = torch.from_numpy(scores64).cuda()
+    positions = np.sort(rng.choice(120, size=50, replace=False)).astype(np.int64)
+    cand = pd.DataFrame({"dbidx": idx._dbidx[positions], "max_score": np.zeros(50)})
+    cand.attrs["positions"] = positions
+    for aug in ("all", "greater", "adjacent"):
+        got = idx.rescore_avg_from_device_scores(cand, 10, aug, dev_scores.data_ptr())
+        rows = idx._candidate_rows(positions)
+        want = rescore_candidates(idx.vector_meta.iloc[rows].assign(score=scores64[rows]), 10, agg_method="avg_score",
+                                  aug_larger=aug)
+        assert np.array_equal(got["dbidxs"], want["dbidxs"]), aug
+        recs = got["activations"].records()
+        for i, frame in enumerate(want["activations"]):
+            ref = frame[["x1", "y1", "x2", "y2", "score"]].to_numpy(dtype=np.float64)[0]
+            assert np.array_equal(np.asarray(recs[i], dtype=np.float64)[:4], ref[:4]), (aug, i)
+            assert recs[i][4] == ref[4], (aug, i, recs[i][4], ref[4])
+    idx._dev.close()
