@@ -219,6 +219,11 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host);
 ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, const double *label_vals,
                                       int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
                                       int32_t *out_sweeps, int32_t *out_converged);
+/* "nothing to propagate yet": the installed prior itself becomes the resident result (unchanged values) and the given
+ * nodes are marked labelled, so that the first rounds of a graph loop -- BaseLabelPropagationRanker.update skips the
+ * propagation until a negative label exists and serves the prior (research/knn_methods.py:62-75) -- go through the
+ * same device path as the later ones. */
+ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels);
 ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host);
 ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled);
 /* device address of the [n] f64 result of the last propagation (valid until the next run on this handle). */

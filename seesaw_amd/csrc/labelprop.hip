@@ -258,6 +258,10 @@ __global__ void k_lp_clear_labels(unsigned char *is_label, const int64_t *ids, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_labels) is_label[ids[i]] = 0;
 }
+__global__ void k_lp_mark_labels(unsigned char *is_label, const int64_t *ids, int64_t n_labels) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_labels) is_label[ids[i]] = 1;
+}
 
 
 // ---------------------------------------------------------------------------------------
@@ -689,6 +693,44 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
     SSW_TRY(lp_run_core(lp, nullptr, true, nullptr, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, &st));
     if (out_sweeps) *out_sweeps = st.sweeps;
     if (out_converged) *out_converged = st.done;
+    return SSW_OK;
+}
+
+ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels) {
+    SSW_REQUIRE(lp != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->prior_installed, "ssw_labelprop_prior_as_result: no prior installed (ssw_labelprop_set_prior)");
+    SSW_REQUIRE(n_labels == 0 || label_ids, "NULL labels");
+    for (int64_t i = 0; i < n_labels; ++i)
+        SSW_REQUIRE(label_ids[i] >= 0 && label_ids[i] < lp->n, "label id %lld out of range", (long long)label_ids[i]);
+    DeviceGuard guard(lp->device);
+    hipStream_t s = lp->stream;
+    SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)lp->n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (lp->n_labels_installed > 0) {
+        const int64_t m = lp->n_labels_installed;
+        hipLaunchKernelGGL(k_lp_clear_labels, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, lp->is_label, lp->ids, m);
+        lp->n_labels_installed = 0;
+    }
+    if (n_labels > 0) {
+        if (n_labels > lp->ids_cap) {
+            SSW_HIP_TRY(hipStreamSynchronize(s));
+            (void)hipFree(lp->ids);
+            (void)hipFree(lp->vals);
+            lp->ids = nullptr;
+            lp->vals = nullptr;
+            int64_t cap = 1024;
+            while (cap < n_labels) cap <<= 1;
+            SSW_HIP_TRY(hipMalloc((void **)&lp->ids, (size_t)cap * sizeof(int64_t)));
+            SSW_HIP_TRY(hipMalloc((void **)&lp->vals, (size_t)cap * sizeof(double)));
+            lp->ids_cap = cap;
+        }
+        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, label_ids, (size_t)n_labels * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lp_mark_labels, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, lp->is_label,
+                           lp->ids, n_labels);
+        lp->n_labels_installed = n_labels;
+    }
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_HIP_TRY(hipStreamSynchronize(s));
+    lp->last_result = 0;
     return SSW_OK;
 }
 

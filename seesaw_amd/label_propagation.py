@@ -76,6 +76,11 @@ class LabelPropagation:
         else:
             print(f"warning: did not converge after {self.last_sweeps} iterations")
 
+    def prior_as_result(self, label_ids):
+        """the installed prior becomes the resident result, `label_ids` are marked labelled (nothing is propagated)"""
+        ids = np.ascontiguousarray(np.asarray(label_ids).reshape(-1), dtype=np.int64)
+        _lib.call("ssw_labelprop_prior_as_result", self._h, _p(ids), ids.shape[0])
+
     def fetch(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.float64)
         _lib.call("ssw_labelprop_fetch", self._h, _p(out))

@@ -73,6 +73,10 @@ class BaseLabelPropagationRanker:
             self._current_scores = self._propagate(self.prior_scores)
         else:
             print(" no negatives yet, skipping propagation")
+            self._no_negatives_yet()
+
+    def _no_negatives_yet(self):
+        """hook: the scores stay the prior (subclasses may keep them where they are)"""
 
     def current_scores(self):
         return self._current_scores
@@ -99,6 +103,8 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
         super().set_base_scores(init_scores)
         self.lp.set_prior(self.prior_scores)  # constant until the next text query: keep it on the device
         self._resident = False
+        if not self._label_map:
+            self._no_negatives_yet()
 
     def _propagate(self, scores):
         ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))  # == nonzero(is_labeled)
@@ -114,6 +120,16 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
         if scores is self.prior_scores:
             self.lp.set_prior(self.prior_scores)  # re-install for the following rounds
         return out
+
+    def _no_negatives_yet(self):
+        # the reference serves the prior until a negative label exists; here the prior is in the graph handle already
+        # (set_prior): it becomes the resident result with the labelled nodes marked, so these rounds select and
+        # re-score on the device like the later ones instead of uploading 12 MB of scores per round
+        if self.lp._prior_installed and self.lp.reg_values is self.prior_scores:
+            ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))
+            self.lp.prior_as_result(ids)
+            self._resident = True
+            self._current_scores = None
 
     def current_scores(self):
         if self._current_scores is None and getattr(self, "_resident", False):
