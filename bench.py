@@ -161,12 +161,17 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                                                  sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4,
                                                  prior_weight=1.0)),
     }
+    # "<loop>@avg": the same loop under the aggregation of the reference's standard bench config
+    # (scripts/configs/std_bench.yaml: agg_method avg_score, aug_larger all) -- HIP side only
+    loops["plain@avg"] = loops["plain"]
+    loops["knn_prop2@avg"] = loops["knn_prop2"]
     cpu_legs = ("plain", "multi_reg", "knn_prop2", "pseudo_lr")  # loops oracle/cpu_loop.py restates
     out = {}
     import contextlib
     import io
     for tag, n_images, knn_k, names in (("lvis_1109x13", 1109, 10, ("plain", "multi_reg", "knn_prop2", "pseudo_lr")),
-                                        (f"full_{full_images}x13", full_images, 10, ("plain", "multi_reg", "knn_prop2", "pseudo_lr"))):
+                                        (f"full_{full_images}x13", full_images, 10,
+                                         ("plain", "multi_reg", "knn_prop2", "pseudo_lr", "plain@avg", "knn_prop2@avg"))):
         ds = make_dataset("lvis", n_images=n_images, tiles_per_image=13, n_categories=2, positive_frac=0.05,
                           seed=11, knn_k=knn_k, device=device)
         ds.embedding.noise = 1.2  # a mediocre text query, so the loop runs all its rounds
@@ -181,10 +186,11 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
         res["knn_graph"] = {"k": knn_k, "build_s_incl_upload_and_dataframe": t_graph,
                             "pair_scores": nv * nv, "exact": True}
         for name in names:
-            p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale"), interactive=name,
+            avg = name.endswith("@avg")
+            p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale"), interactive=name.split("@")[0],
                               interactive_options=loops[name], batch_size=1, shortlist_size=50,
-                              agg_method="plain_score", aug_larger="greater", start_policy="after_first_batch",
-                              index_options={"use_vec_index": False})
+                              agg_method="avg_score" if avg else "plain_score", aug_larger="all" if avg else "greater",
+                              start_policy="after_first_batch", index_options={"use_vec_index": False})
             b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
             with contextlib.redirect_stdout(io.StringIO()):
                 ret = make_session(gdm, p, b=b)

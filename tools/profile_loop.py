@@ -17,6 +17,7 @@ from seesaw_amd.synthetic import GlobalDataManager, make_dataset
 
 name = sys.argv[1] if len(sys.argv) > 1 else "multi_reg"
 n_images = int(sys.argv[2]) if len(sys.argv) > 2 else 1109
+agg = sys.argv[3] if len(sys.argv) > 3 else "plain_score"  # or avg_score (aug_larger all: the reference's standard config)
 matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
 opts = {"plain": None,
         "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
@@ -36,7 +37,7 @@ ds.embedding.noise = 1.2
 gdm = GlobalDataManager().add(ds)
 boxes, _ = ds.load_ground_truth()
 p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale"), interactive=name, interactive_options=opts,
-                  batch_size=1, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                  batch_size=1, shortlist_size=50, agg_method=agg, aug_larger="greater" if agg == "plain_score" else "all",
                   start_policy="after_first_batch", index_options={"use_vec_index": False})
 b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
 for rep in range(2):
