@@ -348,6 +348,16 @@ class BoxFeedbackQuery(InteractiveQuery):
         """match_labels_to_vectors without the per-image pandas joins: for every seen image the
         max IoU of each of its tiles with the image's accepted boxes; results are cached per
         (image, label content) because earlier rounds' labels do not change."""
+        rows, miou = self._matched_arrays(target_description)
+        idx = self.index
+        if rows.shape[0] == 0:
+            return pd.DataFrame({"dbidx": np.zeros(0, np.int64), "ys": np.zeros(0), "max_iou": np.zeros(0)},
+                                index=pd.Index(np.zeros(0, dtype=np.int64)))
+        return pd.DataFrame({"dbidx": idx._row_dbidx[rows], "ys": (miou > 0).astype("float"), "max_iou": miou},
+                            index=pd.Index(rows))
+
+    def _matched_arrays(self, target_description=None):
+        """(tile rows of every seen image, their max IoU with the image's accepted boxes) as plain arrays"""
         idx = self.index
         cache = self.__dict__.setdefault("_match_cache", {})
         rows_all, iou_all = [], []
@@ -380,15 +390,11 @@ class BoxFeedbackQuery(InteractiveQuery):
             rows_all.append(hit[0])
             iou_all.append(hit[1])
         if not rows_all:
-            return pd.DataFrame({"dbidx": np.zeros(0, np.int64), "ys": np.zeros(0), "max_iou": np.zeros(0)},
-                                index=pd.Index(np.zeros(0, dtype=np.int64)))
-        rows = np.concatenate(rows_all)
-        miou = np.concatenate(iou_all)
-        return pd.DataFrame({"dbidx": idx._row_dbidx[rows], "ys": (miou > 0).astype("float"), "max_iou": miou},
-                            index=pd.Index(rows))
+            return np.zeros(0, dtype=np.int64), np.zeros(0)
+        return np.concatenate(rows_all), np.concatenate(iou_all)
 
     def getXy(self, get_positions=False, target_description=None):
-        matched = self._matched_fast(target_description=target_description)
-        if get_positions:
-            return matched.index[matched.ys > 0].values, matched.index[matched.ys == 0].values
-        return matched  # built with exactly the columns dbidx, ys, max_iou
+        if get_positions:  # the graph loops' form: vector positions only, no frame to build
+            rows, miou = self._matched_arrays(target_description)
+            return rows[miou > 0], rows[~(miou > 0)]
+        return self._matched_fast(target_description=target_description)  # columns dbidx, ys, max_iou

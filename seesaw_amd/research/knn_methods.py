@@ -60,13 +60,13 @@ class BaseLabelPropagationRanker:
         raise NotImplementedError("implement me")
 
     def update(self, idxs, labels):
-        for idx, label in zip(idxs, labels):
-            label = float(label)
-            # np.isclose(label, 0) or np.isclose(label, 1) (atol 1e-8, rtol 1e-5) without the per-call overhead
-            assert abs(label) <= 1e-8 or abs(label - 1.0) <= 1e-8 + 1e-5
-            self.labels[int(idx)] = label
-            self.is_labeled[int(idx)] = 1
-            self._label_map[int(idx)] = label
+        idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
+        labels = np.asarray(labels, dtype=np.float64).reshape(-1)
+        # np.isclose(label, 0) or np.isclose(label, 1) (atol 1e-8, rtol 1e-5) for the whole batch at once
+        assert np.all((np.abs(labels) <= 1e-8) | (np.abs(labels - 1.0) <= 1e-8 + 1e-5))
+        self.labels[idxs] = labels  # (a repeated id keeps its last label, as the per-item loop did)
+        self.is_labeled[idxs] = 1
+        self._label_map.update(zip(idxs.tolist(), labels.tolist()))
         has_negative = any(v == 0 for v in self._label_map.values())
         if has_negative:  # the reference skips propagation until a negative label exists
             print(" propagating")
