@@ -118,7 +118,8 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
         for (int64_t i0 = n - 1; i0 >= 1; i0 -= BATCH) {
             const int cnt = (int)(i0 < BATCH ? i0 : BATCH);  // i = i0, i0 - 1, ..., i0 - cnt + 1  (all >= 1)
             for (int b = 0; b < cnt; ++b) {
-                js[b] = (int64_t)mt.interval((uint64_t)(i0 - b));
+                const uint32_t mx = (uint32_t)(i0 - b);  // >= 1: the smallest all-ones mask covering it
+                js[b] = (int64_t)mt.interval32(mx, 0xffffffffu >> __builtin_clz(mx));
                 __builtin_prefetch(&a[(size_t)js[b]], 1);
             }
             for (int b = 0; b < cnt; ++b) {
