@@ -579,6 +579,10 @@ BENCH_LOOP_DATASETS = {
     # (loops/log_reg.py:21 unpacks CoarseQuery.getXy's pair)
     "C": dict(make=dict(n_images=3000, tiles_per_image=1, n_categories=3, positive_frac=0.02, seed=23, signal=0.2),
               noise=3.5),
+    # D: one vector per image WITH a k-NN graph: what the active-search loops plan over (loops/active_search.py takes
+    # vector_meta.dbidx.iloc[vector id], i.e. a coarse index); clustered positives as in B
+    "D": dict(make=dict(n_images=600, tiles_per_image=1, n_categories=3, positive_frac=0.04, seed=24, signal=0.5),
+              noise=3.0, graph=True),
 }
 BENCH_LOOP_SEEDS = (0, 1, 2, 3, 4)  # torch seeds per fitting variant: how far does the reference reproduce itself?
 BENCH_LOOP_KNN_POOL = 11  # neighbours in the stored graph; the loops keep dst_rank < knn_k = 10 of them
@@ -646,6 +650,12 @@ def gen_bench_loop():
         # one-element batch survives, seesaw_session.py:118-130) and the graph loop's own rescoring branch
         "plain_avg": ("A", "plain", None),
         "knn_prop2_b_avg": ("B", "knn_prop2", lp_opts),
+        # row f-4 end to end: the L-KNN model as a ranker, and the two-step look-ahead planner
+        "lknn_d": ("D", "lknn", dict(gamma=0.1, use_clip_as_gamma=False, **lp_opts)),
+        "active_search_d": ("D", "active_search",
+                            dict(gamma=dict(mode="clip", calibration="sigmoid", a=10.0, b=-0.2), reward_horizon=5,
+                                 adjust_horizon=True, max_steps=25, pruning_on=False, implementation="vectorized",
+                                 **{**lp_opts, "matrix_options": {**matrix, "symmetric": False}})),
     }
     session_overrides = {"plain_avg": dict(agg_method="avg_score", aug_larger="all", batch_size=1),
                          "knn_prop2_b_avg": dict(agg_method="avg_score", aug_larger="greater", batch_size=1)}
@@ -656,14 +666,19 @@ def gen_bench_loop():
            "variant_interactive": np.array([v[1] for v in variants.values()]),
            "session_overrides": np.asarray(json.dumps(session_overrides))}
     built = {}
+    W_directed = {}
     for key, spec in BENCH_LOOP_DATASETS.items():
         ds = make_dataset("lvis", knn_k=0, **spec["make"])
         ds.embedding.noise = spec["noise"]
-        if spec["make"]["tiles_per_image"] == 1:  # coarse: no graph-based loop runs on it
+        if spec["make"]["tiles_per_image"] == 1 and not spec.get("graph"):  # coarse: no graph-based loop runs on it
             built[key] = (ds, None, None)
             continue
         knn_df = kg.KNNGraph(kg.compute_exact_knn(ds.vectors, n_neighbors=BENCH_LOOP_KNN_POOL)).restrict_k(k=10).knn_df
         W = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
+        # the directed form (every vertex exactly its 9 nearest neighbours: a regular graph, which the look-ahead
+        # planner's vectorised implementation requires -- efficient_nonmyopic_search.py:178)
+        W_directed[key] = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False,
+                                               symmetric=False)
         L = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True,
                                  laplacian=True)
         xlx = np.asarray(ds.vectors.T @ ((L / L.diagonal().sum()) @ ds.vectors))
@@ -673,14 +688,17 @@ def gen_bench_loop():
     current = {}
 
     def fake_wm(idx, options, xlx_matrix=False):
-        return current["xlx"] if xlx_matrix else current["W"]
+        if xlx_matrix:
+            return current["xlx"]
+        return current["W"] if options.get("symmetric", True) else W_directed[current["key"]]
 
     mreg.get_weight_matrix_from_index = fake_wm
     gb.get_weight_matrix_from_index = fake_wm
     for name, (key, interactive, opts) in variants.items():
         ds, current["W"], current["xlx"] = built[key]
+        current["key"] = key
         boxes, _ = ds.load_ground_truth()
-        is_coarse = current["W"] is None
+        is_coarse = BENCH_LOOP_DATASETS[key]["make"]["tiles_per_image"] == 1
         if is_coarse:
             index = coarse.CoarseIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta)
         else:

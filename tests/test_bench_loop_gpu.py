@@ -123,7 +123,17 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 SEQUENCE_VARIANTS = ["plain", "rocchio_update", "multi_reg", "multi_reg_data", "knn_prop2", "plain_c", "log_reg2_c",
-                     "plain_b", "knn_prop2_b", "pseudo_lr_b", "plain_avg", "knn_prop2_b_avg"]
+                     "plain_b", "knn_prop2_b", "pseudo_lr_b", "plain_avg", "knn_prop2_b_avg", "lknn_d", "active_search_d"]
+
+# the active-search loops of the sequence fixture (row f-4 end to end; options as oracle/gen_golden.py wrote them)
+_LP = dict(matrix_options=MATRIX, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0, calib_b=-0.4,
+           prior_weight=1.0)
+SEQUENCE_LOOPS = {
+    "lknn": dict(gamma=0.1, use_clip_as_gamma=False, **_LP),
+    "active_search": dict(gamma=dict(mode="clip", calibration="sigmoid", a=10.0, b=-0.2), reward_horizon=5,
+                          adjust_horizon=True, max_steps=25, pruning_on=False, implementation="vectorized",
+                          **{**_LP, "matrix_options": {**MATRIX, "symmetric": False}}),
+}
 
 
 @pytest.fixture(scope="module")
@@ -136,7 +146,7 @@ def sequence_datasets():
     out = {}
     for key, spec in specs.items():
         coarse = spec["make"]["tiles_per_image"] == 1
-        ds = make_dataset("lvis", knn_k=0 if coarse else 10, **spec["make"])
+        ds = make_dataset("lvis", knn_k=10 if (not coarse or spec.get("graph")) else 0, **spec["make"])
         ds.embedding.noise = spec["noise"]
         out[key] = (GlobalDataManager().add(ds), ds, coarse)
     return g, out
@@ -164,7 +174,8 @@ def test_benchmark_loop_sequence_matches_reference(sequence_datasets, name):
     over = dict(agg_method="plain_score", aug_larger="greater", batch_size=1)
     over.update(json.loads(str(g["session_overrides"])).get(name, {}))  # plain_avg / knn_prop2_b_avg: avg_score sessions
     p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="coarse" if coarse else "multiscale", c_name=None),
-                      interactive=interactive, interactive_options=LOOPS[opts_name], shortlist_size=50, **over,
+                      interactive=interactive, interactive_options={**LOOPS, **SEQUENCE_LOOPS}[opts_name], shortlist_size=50,
+                      **over,
                       start_policy="from_start" if (interactive == "knn_prop2" or coarse) else "after_first_batch",
                       index_options={"use_vec_index": False})
     b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
