@@ -227,6 +227,170 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// skinny linear: out[R <= 32, N] = epilogue(LN?(X)[R, K] W[N, K]^T) for the handful of rows a single text query has.
+// The tile kernels above give such a product to N/128 workgroups that each walk all of K (a [8 x 2048] x [2048 x 512]
+// fc2 takes 20 us on four workgroups); here a workgroup owns 16 output columns and has one wave per 128 of K: each wave
+// reads its 16 x 128 slice of W straight from memory into four v_mfma_f32_16x16x32_bf16 fragments (X rows are the
+// other operand, zero beyond R), every load of the kernel is in flight before the first wait, and the K/128 partial
+// tiles are added through LDS in wave order.  With LN the layer norm of the rows (layernorm_rows's two-pass
+// arithmetic, eight lanes a row) is redone by every workgroup from the f32 residual stream -- R x D floats out of L2,
+// under the latency of the W loads -- instead of being a launch of its own.  Epilogues are gemm_bf16.hip's.
+// ---------------------------------------------------------------------------------------
+enum { SK_F32 = 0, SK_BF16_BIAS = 1, SK_BF16_BIAS_GELU = 2, SK_F32_BIAS_RESIDUAL = 3 };
+constexpr int SK_MAX_ROWS = 32;
+
+template <int CTRL>
+__device__ __forceinline__ float sk_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over each aligned group of eight lanes, in every lane of the group
+__device__ __forceinline__ float sk_sum8(float v) {
+    v += sk_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += sk_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += sk_dpp<0x141>(v);  // row_half_mirror: the other quad of the eight
+    return v;
+}
+
+template <int EPI, bool LN, int RT, int NW>
+__global__ __launch_bounds__(64 * NW) void skinny_linear(const void *__restrict__ Xv, const int *__restrict__ row_index,
+                                                         const float *__restrict__ lnw, const float *__restrict__ lnb,
+                                                         float eps, const bf16 *__restrict__ W,
+                                                         const float *__restrict__ bias,
+                                                         const float *__restrict__ residual, void *__restrict__ Cout,
+                                                         int R, int N) {
+    constexpr int K = NW * 128;
+    __shared__ f32x4 part[NW][RT][64];
+    __shared__ float stats[SK_MAX_ROWS][2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16, kb = wave * 128 + fq * 8;
+    // ---- every load of the kernel is issued here, before the first wait ----
+    const int slot = tid >> 3, sub = tid & 7;  // layer-norm statistics: threads 0..255, eight lanes a row
+    const bool stat_thread = LN && tid < 256 && slot < R;
+    float4 sv[LN ? K / 32 : 1];
+    if (stat_thread) {
+        const float4 *xr = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(Xv) +
+                                                             (int64_t)(row_index ? row_index[slot] : slot) * K);
+#pragma unroll
+        for (int i = 0; i < K / 32; ++i) sv[i] = xr[sub + 8 * i];
+    }
+    bf16x8 wf[4];
+    {
+        const bf16 *wrow = W + (int64_t)(n0 + fr) * K + kb;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const bf16x8 *>(wrow + 32 * u);
+    }
+    bool live[RT];
+    bf16x8 xb[LN ? 1 : RT][4];         // !LN: the bf16 rows as they are
+    float4 xf32[LN ? RT : 1][4][2];    // LN: the f32 rows, normalised below
+    float4 lw[LN ? 4 : 1][2], lb[LN ? 4 : 1][2];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const int r = t * 16 + fr;
+        live[t] = r < R;
+        const int64_t x0 = live[t] ? (int64_t)((LN && row_index) ? row_index[r] : r) * K + kb : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (LN) {
+                const float *xp = reinterpret_cast<const float *>(Xv) + x0 + 32 * u;
+                xf32[LN ? t : 0][u][0] = live[t] ? *reinterpret_cast<const float4 *>(xp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xf32[LN ? t : 0][u][1] = live[t] ? *reinterpret_cast<const float4 *>(xp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (live[t]) {
+                xb[LN ? 0 : t][u] = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const bf16 *>(Xv) + x0 + 32 * u);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xb[LN ? 0 : t][u][e] = to_bf16(0.f);
+            }
+        }
+    }
+    if (LN) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lw[u][0] = *reinterpret_cast<const float4 *>(lnw + kb + 32 * u);
+            lw[u][1] = *reinterpret_cast<const float4 *>(lnw + kb + 32 * u + 4);
+            lb[u][0] = *reinterpret_cast<const float4 *>(lnb + kb + 32 * u);
+            lb[u][1] = *reinterpret_cast<const float4 *>(lnb + kb + 32 * u + 4);
+        }
+    }
+    // the epilogue's operands (waves 0 .. RT-1 write rows wave*16 + fr, columns n0 + fq*4 ..)
+    const int erow = wave * 16 + fr, ecol = n0 + fq * 4;
+    const bool writer = wave < RT && erow < R;
+    const int64_t eo = (int64_t)erow * N + ecol;
+    f32x4 bias_v = f32x4{0.f, 0.f, 0.f, 0.f}, res_v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (writer) {
+        if (EPI != SK_F32) bias_v = *reinterpret_cast<const f32x4 *>(bias + ecol);
+        if (EPI == SK_F32_BIAS_RESIDUAL) res_v = *reinterpret_cast<const f32x4 *>(residual + eo);
+    }
+    // ---- layer-norm statistics (layernorm_rows's two passes over the registers) ----
+    if (LN) {
+        if (stat_thread) {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) sum += (sv[i].x + sv[i].y) + (sv[i].z + sv[i].w);
+            const float mean = sk_sum8(sum) / (float)K;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < K / 32; ++i) {
+                const float dx = sv[i].x - mean, dy = sv[i].y - mean, dz = sv[i].z - mean, dw = sv[i].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            q = sk_sum8(q);
+            if (sub == 0) {
+                stats[slot][0] = mean;
+                stats[slot][1] = rsqrtf(q / (float)K + eps);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- this wave's 128 of K ----
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int r = t * 16 + fr;
+        const float mean = (LN && live[t]) ? stats[r][0] : 0.f, rstd = (LN && live[t]) ? stats[r][1] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x8 xf;
+            if (!LN) {
+                xf = xb[LN ? 0 : t][u];
+            } else {
+                const float4 x0 = xf32[LN ? t : 0][u][0], x1 = xf32[LN ? t : 0][u][1];
+                const float4 w0 = lw[LN ? u : 0][0], w1 = lw[LN ? u : 0][1], b0 = lb[LN ? u : 0][0], b1 = lb[LN ? u : 0][1];
+                // rows beyond R: x = 0, mean = rstd = 0 -> the bias b, multiplied into tile rows nobody writes
+                xf[0] = to_bf16((x0.x - mean) * rstd * w0.x + b0.x);
+                xf[1] = to_bf16((x0.y - mean) * rstd * w0.y + b0.y);
+                xf[2] = to_bf16((x0.z - mean) * rstd * w0.z + b0.z);
+                xf[3] = to_bf16((x0.w - mean) * rstd * w0.w + b0.w);
+                xf[4] = to_bf16((x1.x - mean) * rstd * w1.x + b1.x);
+                xf[5] = to_bf16((x1.y - mean) * rstd * w1.y + b1.y);
+                xf[6] = to_bf16((x1.z - mean) * rstd * w1.z + b1.z);
+                xf[7] = to_bf16((x1.w - mean) * rstd * w1.w + b1.w);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf, acc, 0, 0, 0);  // lane: out[row fr][col fq*4 + e]
+        }
+        part[wave][t][lane] = acc;
+    }
+    __syncthreads();
+    if (!writer) return;
+    f32x4 v = part[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += part[w][wave][lane];
+    v += bias_v;
+    if (EPI == SK_BF16_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + __expf(-1.702f * v[e]));  // quick_gelu
+    }
+    v += res_v;
+    if (EPI == SK_BF16_BIAS || EPI == SK_BF16_BIAS_GELU) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = to_bf16(v[e]);
+        *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + eo) = ov;
+    } else {
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + eo) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // embeddings
 // ---------------------------------------------------------------------------------------
 // pixels [B,3,224,224] f32 -> patches [B*49, 3072] bf16, column = c*1024 + py*32 + px
@@ -551,12 +715,53 @@ ssw_status reserve(ssw_clip *c, int64_t batch) {
 }
 
 // the transformer stack on `R = B*S` token rows held in c->hidden (f32)
+template <int EPI, bool LN, int NW>
+void launch_skinny_nw(hipStream_t s, const void *X, const int *row_index, const float *lnw, const float *lnb, float eps,
+                      const bf16 *W, const float *bias, const float *residual, void *out, int R, int N) {
+    if (R <= 16)
+        hipLaunchKernelGGL((skinny_linear<EPI, LN, 1, NW>), dim3(N / 16), dim3(64 * NW), 0, s, X, row_index, lnw, lnb,
+                           eps, W, bias, residual, out, R, N);
+    else
+        hipLaunchKernelGGL((skinny_linear<EPI, LN, 2, NW>), dim3(N / 16), dim3(64 * NW), 0, s, X, row_index, lnw, lnb,
+                           eps, W, bias, residual, out, R, N);
+}
+template <int EPI, bool LN>
+void launch_skinny(hipStream_t s, const void *X, const int *row_index, const float *lnw, const float *lnb, float eps,
+                   const bf16 *W, const float *bias, const float *residual, void *out, int R, int N, int K) {
+    // one wave per 128 of K (skinny_rows() admits nothing else); the fused layer norm is over D = 512
+    if constexpr (LN) {
+        launch_skinny_nw<EPI, LN, 4>(s, X, row_index, lnw, lnb, eps, W, bias, residual, out, R, N);
+    } else {
+        if (K == 512) launch_skinny_nw<EPI, LN, 4>(s, X, row_index, lnw, lnb, eps, W, bias, residual, out, R, N);
+        else if (K == 1024) launch_skinny_nw<EPI, LN, 8>(s, X, row_index, lnw, lnb, eps, W, bias, residual, out, R, N);
+        else launch_skinny_nw<EPI, LN, 16>(s, X, row_index, lnw, lnb, eps, W, bias, residual, out, R, N);
+    }
+}
+
+// a handful of rows (one short text query): five launches a layer, every one over N/16 workgroups
+bool skinny_rows(int R, int D, int M) {
+    static const bool off = getenv("SSW_CLIP_NO_SKINNY") != nullptr;
+    return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);
+}
+
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     hipStream_t s = c->stream;
     const int R = B * S, D = tw.D, M = tw.M;
     const float eps = c->hdr.ln_eps;
     float *h = c->hidden, *h2 = c->hidden2;
-    for (int l = 0; l < tw.L; ++l) {
+    const bool skinny = skinny_rows(R, D, M);
+    for (int l = 0; l < tw.L && skinny; ++l) {
+        const Layer &ly = tw.layers[l];
+        launch_skinny<SK_BF16_BIAS, true>(s, h, nullptr, ly.ln1w, ly.ln1b, eps, ly.wqkv, ly.bqkv, nullptr, c->qkv, R,
+                                          3 * D, D);
+        const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
+        hipLaunchKernelGGL(attention_mfma<4>, dim3(B * tw.H), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
+                           causal);
+        launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->att, nullptr, nullptr, nullptr, eps, ly.wo, ly.bo, h, h2, R, D, D);
+        launch_skinny<SK_BF16_BIAS_GELU, true>(s, h2, nullptr, ly.ln2w, ly.ln2b, eps, ly.w1, ly.b1, nullptr, c->h1, R, M, D);
+        launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->h1, nullptr, nullptr, nullptr, eps, ly.w2, ly.b2, h2, h, R, D, M);
+    }
+    for (int l = 0; l < tw.L && !skinny; ++l) {
         const Layer &ly = tw.layers[l];
         hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h, (const int *)nullptr, R, D,
                            ly.ln1w, ly.ln1b, eps, c->xn);
@@ -584,7 +789,11 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
 ssw_status pool_and_project(ssw_clip *c, const Tower &tw, int B, int D, int normalize, float *out_dev) {
     hipStream_t s = c->stream;
     const Header &h = c->hdr;
-    if (h.proj % 128 == 0 && D % 64 == 0) {
+    if (h.proj % 16 == 0 && skinny_rows(B, D, tw.M)) {
+        launch_skinny<SK_F32, true>(s, c->hidden, c->rows, tw.lnf_w, tw.lnf_b, h.ln_eps, tw.proj, nullptr, nullptr,
+                                    out_dev, B, h.proj, D);
+        if (normalize) hipLaunchKernelGGL(l2norm_rows, dim3((B + 3) / 4), dim3(256), 0, s, out_dev, B, h.proj);
+    } else if (h.proj % 128 == 0 && D % 64 == 0) {
         hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((B + 3) / 4), dim3(256), 0, s, c->hidden, c->rows, B, D,
                            tw.lnf_w, tw.lnf_b, h.ln_eps, c->xn);
         SSW_TRY(gemm<EPI_F32>(s, c->xn, tw.proj, nullptr, nullptr, out_dev, B, h.proj, D));
@@ -627,6 +836,9 @@ ssw_status image_forward_u8(ssw_clip *c, const uint8_t *tiles_dev, int B, int no
     return image_forward_from_patches(c, B, normalize, out_dev);
 }
 
+// A single query is ~64 dependent launches of 4-6 us kernels.  Replaying them as a captured hipGraph was measured
+// (round 2: 0.300 ms eager, 0.298 ms replayed; 0.645 / 0.631 before the skinny kernels) and dropped: the launches are
+// not host-bound, the queue already holds them back to back.
 ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int normalize, float *out_dev) {
     hipStream_t s = c->stream;
     const Header &h = c->hdr;

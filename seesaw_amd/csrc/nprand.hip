@@ -4,13 +4,15 @@
 // (seesaw/loops/util.py:11-14): which rows are drawn decides the fit, so a drop-in has to reproduce the draw, i.e.
 // consume the global RandomState's stream exactly as numpy does.  numpy shuffles np.arange(n) with a generic
 // memcpy-swap per element (15 ms for the 1.56 M unlabelled rows of the LVIS-scale bench, most of a PseudoLR round);
-// this is the same algorithm on an int32 array:
+// this is the same algorithm, with the draws made word-wise (draw_targets) and only the k wanted positions followed
+// through the swaps (PrefixTrace):
 //     for i = n-1 ... 1:  j = random_interval(i);  swap(a[i], a[j])          (mtrand.pyx _shuffle_raw)
 //     random_interval(max): mask = 2^ceil(log2(max+1)) - 1; draw 32-bit words until (word & mask) <= max
 //                                                                          (distributions.c random_interval)
 //     word = MT19937 genrand with numpy's (randomkit's) reload and tempering    (mt19937.c)
 // The caller passes the 624-word key and position of np.random.get_state() and writes them back with set_state():
 // the stream continues exactly where numpy's own call would have left it (tests/test_nprand_cpu.py).
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
@@ -95,6 +97,106 @@ struct Mt {
     }
 };
 
+// Draw targets j_i = random_interval(i) for i = n-1 ... 1 into J[i].  The stream is walked word by word, not draw by
+// draw: every word is consumed whether it is accepted or not, and it is accepted iff (word & mask) <= i for the i
+// current at that word -- so the only loop-carried dependency is `i -= accepted` (two cycles), instead of the
+// load -> compare -> advance chain of a draw-by-draw loop (14 cycles a draw, 10 ms of the former 14).  All i of one
+// bit length share a mask, so the loop runs per bit length; a rejected word's value is stored too and overwritten by
+// the next one.
+void draw_targets(Mt &mt, int64_t n, uint32_t *J) {
+    int64_t i = n - 1;
+    while (i >= 1) {
+        const int b = 31 - __builtin_clz((uint32_t)i);
+        const int64_t lo = (int64_t)1 << b;                      // the smallest i of this bit length
+        const uint32_t mask = 0xffffffffu >> (31 - b);           // numpy's smallest all-ones mask covering i
+        while (i >= lo) {
+            if (mt.pos == MT_N) {
+                mt_reload(mt.key);
+                mt.pos = 0;
+                mt.temper_from(0);
+            }
+            const uint32_t *w = mt.out + mt.pos;
+            const int avail = MT_N - mt.pos;
+            int t = 0;
+            while (t < avail && i >= lo) {
+                const uint32_t v = w[t++] & mask;
+                J[i] = v;
+                i -= (int64_t)(v <= (uint32_t)i);
+            }
+            mt.pos += t;
+        }
+    }
+}
+
+// The first k entries of the shuffled arange(n), given every swap target.  The shuffle applies swap(a[i], a[J[i]]) for
+// i = n-1 ... 1; what ends at position p is found by walking the swaps backwards (i = 1 ... n-1) and moving a pointer
+// that starts at p: at i it jumps to J[i], at J[i] it jumps to i, and where it stands after the last step is the
+// value (a starts as the identity).  All k pointers are walked at once: a bitmap of the occupied positions (n/8 bytes,
+// cache-resident, one random bit test per step) says whether a step touches any of them -- about 4 % of the steps do
+// for 10 000 of 1.56 M -- and a small open-addressing table maps an occupied position to its pointer.  No n-sized
+// array is shuffled.
+class PrefixTrace {
+   public:
+    PrefixTrace(int64_t n, int64_t k) : bits_((size_t)((n + 63) / 64), 0), where_((size_t)k) {
+        hb_ = 4;
+        while (((int64_t)1 << hb_) < 4 * k) ++hb_;
+        pos_.assign((size_t)1 << hb_, EMPTY);
+        slot_.assign((size_t)1 << hb_, 0);
+        for (int64_t s = 0; s < k; ++s) {
+            where_[(size_t)s] = (int32_t)s;
+            set_bit((uint32_t)s);
+            put((int32_t)s, (int32_t)s);
+        }
+    }
+    inline bool occupied(uint32_t p) const { return (bits_[p >> 6] >> (p & 63)) & 1u; }
+    void swap_positions(uint32_t i, uint32_t j) {  // at least one of them is occupied, i != j
+        const int32_t si = occupied(i) ? take(i) : -1, sj = occupied(j) ? take(j) : -1;
+        if (si >= 0) place(j, si);
+        if (sj >= 0) place(i, sj);
+    }
+    const std::vector<int32_t> &where() const { return where_; }
+
+   private:
+    static constexpr int32_t EMPTY = -1, DEAD = -2;
+    inline void set_bit(uint32_t p) { bits_[p >> 6] |= (uint64_t)1 << (p & 63); }
+    inline void clear_bit(uint32_t p) { bits_[p >> 6] &= ~((uint64_t)1 << (p & 63)); }
+    inline uint32_t home(int32_t p) const { return ((uint32_t)p * 2654435761u) >> (32 - hb_); }
+    void put(int32_t p, int32_t s) {  // p is not in the table
+        const uint32_t m = ((uint32_t)1 << hb_) - 1;
+        uint32_t h = home(p);
+        while (pos_[h] >= 0) h = (h + 1) & m;
+        dead_ -= pos_[h] == DEAD;
+        pos_[h] = p;
+        slot_[h] = s;
+    }
+    int32_t take(uint32_t p) {  // p is in the table (its bit is set)
+        const uint32_t m = ((uint32_t)1 << hb_) - 1;
+        uint32_t h = home((int32_t)p);
+        while (pos_[h] != (int32_t)p) h = (h + 1) & m;
+        pos_[h] = DEAD;
+        ++dead_;
+        clear_bit(p);
+        where_[(size_t)slot_[h]] = -1;  // in hand until place()
+        return slot_[h];
+    }
+    void place(uint32_t p, int32_t s) {
+        // live + dead entries stay under half of the table (>= 4 k entries), so every probe sequence ends
+        if ((int64_t)dead_ + (int64_t)where_.size() > ((int64_t)1 << (hb_ - 1))) {
+            std::fill(pos_.begin(), pos_.end(), EMPTY);
+            dead_ = 0;
+            for (size_t t = 0; t < where_.size(); ++t)
+                if (where_[t] >= 0) put(where_[t], (int32_t)t);  // pointers in hand (taken, not yet placed) are -1
+        }
+        where_[(size_t)s] = (int32_t)p;
+        set_bit(p);
+        put((int32_t)p, s);
+    }
+    std::vector<uint64_t> bits_;
+    std::vector<int32_t> where_, pos_, slot_;
+    int hb_ = 4;
+    int64_t dead_ = 0;
+};
+
 }  // namespace
 
 extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt_pos, int64_t n, int64_t k,
@@ -108,43 +210,38 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
     mt.key = mt_key624;
     mt.pos = *mt_pos;
     mt.temper_from(mt.pos);
-    // The draws do not depend on the array, only on i: they are made a batch ahead and their targets prefetched, so
-    // the swaps (random accesses into a 6-MB array) do not wait for memory one at a time.
-    constexpr int BATCH = 64;
-    int64_t js[BATCH];
     if (n <= 0x7fffffffll) {
-        std::vector<int32_t> a((size_t)n);
-        for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (int32_t)i;
-        for (int64_t i0 = n - 1; i0 >= 1; i0 -= BATCH) {
-            const int cnt = (int)(i0 < BATCH ? i0 : BATCH);  // i = i0, i0 - 1, ..., i0 - cnt + 1  (all >= 1)
-            for (int b = 0; b < cnt; ++b) {
-                const uint32_t mx = (uint32_t)(i0 - b);  // >= 1: the smallest all-ones mask covering it
-                js[b] = (int64_t)mt.interval32(mx, 0xffffffffu >> __builtin_clz(mx));
-                __builtin_prefetch(&a[(size_t)js[b]], 1);
-            }
-            for (int b = 0; b < cnt; ++b) {
-                const int64_t i = i0 - b, j = js[b];
-                const int32_t t = a[(size_t)j];
-                a[(size_t)j] = a[(size_t)i];
+        std::vector<uint32_t> J((size_t)(n > 0 ? n : 1));
+        draw_targets(mt, n, J.data());  // consumes the stream for the whole shuffle, whatever k is
+        if (k * 16 <= n) {
+            PrefixTrace tr(n, k);
+            if (k > 0)
+                for (int64_t i = 1; i < n; ++i) {
+                    const uint32_t j = J[(size_t)i];
+                    if ((tr.occupied((uint32_t)i) || tr.occupied(j)) && j != (uint32_t)i) tr.swap_positions((uint32_t)i, j);
+                }
+            for (int64_t s = 0; s < k; ++s) out_prefix[s] = tr.where()[(size_t)s];
+        } else {  // a long prefix: shuffle the array itself
+            std::vector<int32_t> a((size_t)n);
+            for (int64_t i = 0; i < n; ++i) a[(size_t)i] = (int32_t)i;
+            constexpr int AHEAD = 32;
+            for (int64_t i = n - 1; i >= 1; --i) {
+                if (i > AHEAD) __builtin_prefetch(&a[J[(size_t)(i - AHEAD)]], 1);
+                const uint32_t j = J[(size_t)i];
+                const int32_t t = a[j];
+                a[j] = a[(size_t)i];
                 a[(size_t)i] = t;
             }
+            for (int64_t i = 0; i < k; ++i) out_prefix[i] = a[(size_t)i];
         }
-        for (int64_t i = 0; i < k; ++i) out_prefix[i] = a[(size_t)i];
     } else {
         std::vector<int64_t> a((size_t)n);
         for (int64_t i = 0; i < n; ++i) a[(size_t)i] = i;
-        for (int64_t i0 = n - 1; i0 >= 1; i0 -= BATCH) {
-            const int cnt = (int)(i0 < BATCH ? i0 : BATCH);
-            for (int b = 0; b < cnt; ++b) {
-                js[b] = (int64_t)mt.interval((uint64_t)(i0 - b));
-                __builtin_prefetch(&a[(size_t)js[b]], 1);
-            }
-            for (int b = 0; b < cnt; ++b) {
-                const int64_t i = i0 - b, j = js[b];
-                const int64_t t = a[(size_t)j];
-                a[(size_t)j] = a[(size_t)i];
-                a[(size_t)i] = t;
-            }
+        for (int64_t i = n - 1; i >= 1; --i) {
+            const int64_t j = (int64_t)mt.interval((uint64_t)i);
+            const int64_t t = a[(size_t)j];
+            a[(size_t)j] = a[(size_t)i];
+            a[(size_t)i] = t;
         }
         for (int64_t i = 0; i < k; ++i) out_prefix[i] = a[(size_t)i];
     }

@@ -69,6 +69,34 @@ def test_text_tower_vs_hf(models, L):
     assert np.abs(np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1) - 1).max() < 2e-2
 
 
+@pytest.mark.parametrize("B,L", [(1, 3), (1, 8), (1, 17), (1, 32), (2, 16), (3, 5), (1, 33)])
+def test_single_query_text_path_vs_hf(models, B, L):
+    """up to 32 rows (one short query) go through the skinny kernels (skinny_linear: layer norm fused, K split over the
+    waves, five launches a layer); (1, 33) is the first shape back on the tile kernels.  Same bar as the batched
+    path, and the two paths agree on the same query far inside that bar."""
+    import torch
+    hf, ours = models
+    rng = np.random.default_rng(100 * B + L)
+    ids = rng.integers(0, 49405, size=(B, L)).astype(np.int64)
+    ids[:, 0] = 49406
+    ids[:, L - 1] = 49407
+    if L > 4:
+        ids[B - 1, L - 2] = 49407  # an earlier EOS in the last row: pooled there
+    with torch.inference_mode():
+        ref = hf.get_text_features(input_ids=torch.from_numpy(ids))
+        ref = (ref.pooler_output if hasattr(ref, "pooler_output") else ref).numpy()
+    got = ours.embed_text(ids.astype(np.int32), normalize=False)
+    cos = (_unit(got) * _unit(ref)).sum(1)
+    assert cos.min() >= COS_MIN, cos
+    assert np.abs(_unit(got) - _unit(ref)).max() <= ABS_MAX
+    assert np.abs(np.linalg.norm(got, axis=1) / np.linalg.norm(ref, axis=1) - 1).max() < 2e-2
+    # the same rows inside a batch of 40+ rows take the tile kernels
+    reps = -(-41 // (B * L))
+    tiled = ours.embed_text(np.tile(ids, (reps + 1, 1)).astype(np.int32), normalize=False)[:B]
+    assert (_unit(got) * _unit(tiled)).sum(1).min() >= 0.99995
+    assert np.abs(_unit(got) - _unit(tiled)).max() <= 1e-3
+
+
 def test_text_pooling_legacy_eos_token_id_2():
     """The published openai/clip-vit-* configs still say text_config.eos_token_id = 2; transformers then pools
     at argmax(input_ids) (modeling_clip.py, CLIPTextTransformer.forward).  A tokenised string never contains
@@ -194,3 +222,33 @@ def test_more_tiles_than_one_device_chunk(models):
         part = ours.embed_tiles_u8(tiles[lo:hi], normalize=True)
         # a tile's embedding does not depend on its batch neighbours (same kernels, same per-row arithmetic)
         assert np.array_equal(part.view(np.uint32), whole[lo:hi].view(np.uint32)), (lo, hi)
+
+
+def test_repeated_single_queries_are_bit_identical(models):
+    """the same query embedded again gives the same bits (no state carried between forwards), another query of the
+    same shape gives its own embedding, and a reallocation of the workspace (a larger batch in between) changes
+    nothing"""
+    _, ours = models
+    rng = np.random.default_rng(77)
+
+    def query(L=9):
+        ids = rng.integers(0, 49405, size=(1, L)).astype(np.int32)
+        ids[0, 0], ids[0, L - 1] = 49406, 49407
+        return ids
+
+    a, b = query(), query()
+    first = ours.embed_text(a, normalize=True)
+    second = ours.embed_text(a, normalize=True)
+    third = ours.embed_text(a, normalize=True)
+    assert np.array_equal(first.view(np.uint32), second.view(np.uint32))
+    assert np.array_equal(first.view(np.uint32), third.view(np.uint32))
+    got_b = ours.embed_text(b, normalize=True)
+    both = ours.embed_text(np.concatenate([a, b]), normalize=True)
+    assert np.abs(got_b - first).max() > 1e-3
+    assert np.abs(both[0] - first[0]).max() < 1e-5 and np.abs(both[1] - got_b[0]).max() < 1e-5
+    big = rng.integers(0, 49405, size=(300, 9)).astype(np.int32)       # forces a larger workspace
+    big[:, 0], big[:, 8] = 49406, 49407
+    ours.embed_text(big, normalize=True)
+    again = [ours.embed_text(a, normalize=True) for _ in range(3)]
+    for x in again:
+        assert np.array_equal(x.view(np.uint32), first.view(np.uint32))

@@ -23,6 +23,20 @@ def test_prefix_and_stream_equal_numpy(n):
             assert np.array_equal(np.random.random(5), ref_next), "the stream must continue where numpy's call leaves it"
 
 
+@pytest.mark.parametrize("n,k", [(300001, 1000), (300001, 18750), (300001, 18751), (160000, 10000), (1000, 62), (1000, 63),
+                                 (64, 4), (17, 1), (16, 1)])
+def test_prefixes_on_both_sides_of_the_trace_threshold(n, k):
+    """prefixes up to n/16 are followed backwards through the swaps (a position table that is rebuilt as entries die),
+    longer ones shuffle the array: both against numpy, twice in a row on one stream"""
+    np.random.seed(n + k)
+    ref = [np.random.permutation(n)[:k] for _ in range(2)]
+    ref_next = np.random.random(3)
+    np.random.seed(n + k)
+    got = [permutation_prefix(n, k) for _ in range(2)]
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(np.random.random(3), ref_next)
+
+
 def test_makexy_rows_draw_is_the_reference_expression():
     from seesaw_amd.loops.util import makeXy_rows
 
