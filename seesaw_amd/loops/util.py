@@ -22,13 +22,22 @@ def makeXy(idx, lr, sample_size, pseudoLabel=True):
 
 
 def makeXy_rows(lr, sample_size):
-    """same draw, returning row positions so the vectors can be gathered on the device."""
-    is_labeled = lr.is_labeled > 0
-    rows = np.nonzero(is_labeled)[0]
-    y = lr.labels[is_labeled]
+    """same draw, returning row positions so the vectors can be gathered on the device.  A ranker that keeps its
+    labelled set as a map (`_label_map`) spares the three passes over all vectors: the p-th unlabelled row is
+    p + #{i : labelled[i] - i <= p} over the sorted labelled rows."""
+    label_map = getattr(lr, "_label_map", None)
+    if label_map is not None:
+        rows = np.fromiter(sorted(label_map), dtype=np.int64, count=len(label_map))  # == nonzero(is_labeled > 0)
+        y = lr.labels[rows]
+        p = permutation_prefix(lr.is_labeled.shape[0] - rows.shape[0], sample_size)
+        pick = p + np.searchsorted(rows - np.arange(rows.shape[0]), p, side="right")  # == nonzero(~is_labeled)[0][p]
+    else:
+        is_labeled = lr.is_labeled > 0
+        rows = np.nonzero(is_labeled)[0]
+        y = lr.labels[is_labeled]
+        unl = np.nonzero(~is_labeled)[0]
+        pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
     is_real = np.ones_like(y)
-    unl = np.nonzero(~is_labeled)[0]
-    pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
     return (np.concatenate((rows, pick)), np.concatenate((y, lr.current_scores()[pick])),
             np.concatenate((is_real, np.zeros(pick.shape[0]))))
 

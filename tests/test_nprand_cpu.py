@@ -62,6 +62,35 @@ def test_makexy_rows_draw_is_the_reference_expression():
     assert is_real.sum() == 3
 
 
+def test_makexy_rows_from_the_label_map_is_the_array_path():
+    """rankers that keep `_label_map` get the unlabelled rows by arithmetic on the sorted labelled rows"""
+    from seesaw_amd.loops.util import makeXy_rows
+
+    class _Ranker:
+        def __init__(self, n, labelled, with_map):
+            self.is_labeled = np.zeros(n)
+            self.labels = np.zeros(n)
+            rng = np.random.default_rng(5)
+            for i in labelled:
+                self.is_labeled[i] = 1
+                self.labels[i] = float(rng.integers(0, 2))
+            if with_map:
+                self._label_map = {int(i): float(self.labels[i]) for i in labelled}
+            self._s = np.linspace(0, 1, n)
+
+        def current_scores(self):
+            return self._s
+
+    for labelled in ([0], [4999], [0, 1, 2, 3], [7, 8, 9, 4998, 4999], list(range(0, 5000, 7)), [2500], []):
+        for k in (1, 100, 4900, 6000):
+            out = []
+            for with_map in (False, True):
+                np.random.seed(9)
+                out.append(makeXy_rows(_Ranker(5000, labelled, with_map), sample_size=k))
+            for a, b in zip(*out):
+                assert np.array_equal(a, b), (labelled, k)
+
+
 def test_generator_gaussian_cache_survives():
     """has_gauss / cached_gaussian of the legacy state tuple are passed through untouched"""
     np.random.seed(3)
@@ -73,3 +102,20 @@ def test_generator_gaussian_cache_survives():
     np.random.set_state(st)
     assert np.array_equal(permutation_prefix(50, 50), ref)
     assert np.array_equal(np.random.standard_normal(2), ref_n)
+
+
+def test_scalar_draw_path_in_a_process_without_avx512():
+    """the word-wise draws have an AVX-512 variant chosen at run time; SSW_NPRAND_NO_AVX512 forces the scalar one"""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np; from seesaw_amd.nprand import permutation_prefix\n"
+            "for n, k in ((300001, 1000), (70000, 70000), (1560, 97), (65537, 10)):\n"
+            "    np.random.seed(n); ref = np.random.permutation(n)[:k]; nxt = np.random.random(2)\n"
+            "    np.random.seed(n); got = permutation_prefix(n, k)\n"
+            "    assert np.array_equal(got, ref) and np.array_equal(np.random.random(2), nxt), (n, k)\n"
+            "print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSW_NPRAND_NO_AVX512="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
