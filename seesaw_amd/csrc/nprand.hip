@@ -189,68 +189,49 @@ SSW_AVX512 void draw_targets_avx512(Mt &mt, int64_t n, uint32_t *Jd) {
 // that starts at p: at i it jumps to J[i], at J[i] it jumps to i, and where it stands after the last step is the
 // value (a starts as the identity).  All k pointers are walked at once: a bitmap of the occupied positions (n/8 bytes,
 // cache-resident, one random bit test per step) says whether a step touches any of them -- about 4 % of the steps do
-// for 10 000 of 1.56 M -- and a small open-addressing table maps an occupied position to its pointer.  No n-sized
-// array is shuffled.
+// for 10 000 of 1.56 M -- and `slot_at[p]` names the pointer at an occupied position (read only where the bit is set,
+// so it is never initialised).  No n-sized array is shuffled.
+struct Scratch {  // per thread, kept between calls: fresh 6-MB allocations cost their page faults every round
+    std::vector<uint32_t> Jd;
+    std::vector<int32_t> slot_at;
+    std::vector<uint64_t> bits;
+};
+
 class PrefixTrace {
    public:
-    PrefixTrace(int64_t n, int64_t k) : bits_((size_t)((n + 63) / 64), 0), where_((size_t)k) {
-        hb_ = 4;
-        while (((int64_t)1 << hb_) < 4 * k) ++hb_;
-        pos_.assign((size_t)1 << hb_, EMPTY);
-        slot_.assign((size_t)1 << hb_, 0);
-        for (int64_t s = 0; s < k; ++s) {
-            where_[(size_t)s] = (int32_t)s;
-            set_bit((uint32_t)s);
-            put((int32_t)s, (int32_t)s);
-        }
+    PrefixTrace(int64_t n, int64_t k, Scratch &sc) : where_((size_t)k) {
+        if ((int64_t)sc.slot_at.size() < n) sc.slot_at.resize((size_t)n);
+        sc.bits.assign((size_t)((n + 63) / 64), 0);
+        bits_ = sc.bits.data();
+        slot_at_ = sc.slot_at.data();
+        for (int64_t s = 0; s < k; ++s) place((uint32_t)s, (int32_t)s);
     }
     inline bool occupied(uint32_t p) const { return (bits_[p >> 6] >> (p & 63)) & 1u; }
-    void swap_positions(uint32_t i, uint32_t j) {  // at least one of them is occupied, i != j
-        const int32_t si = occupied(i) ? take(i) : -1, sj = occupied(j) ? take(j) : -1;
-        if (si >= 0) place(j, si);
-        if (sj >= 0) place(i, sj);
+    inline void swap_positions(uint32_t i, uint32_t j) {  // at least one of them is occupied, i != j
+        const bool oi = occupied(i), oj = occupied(j);
+        const int32_t si = slot_at_[i], sj = slot_at_[j];  // meaningful where occupied
+        if (oi && oj) {
+            place(j, si);
+            place(i, sj);
+        } else if (oi) {
+            bits_[i >> 6] &= ~((uint64_t)1 << (i & 63));
+            place(j, si);
+        } else {
+            bits_[j >> 6] &= ~((uint64_t)1 << (j & 63));
+            place(i, sj);
+        }
     }
     const std::vector<int32_t> &where() const { return where_; }
 
    private:
-    static constexpr int32_t EMPTY = -1, DEAD = -2;
-    inline void set_bit(uint32_t p) { bits_[p >> 6] |= (uint64_t)1 << (p & 63); }
-    inline void clear_bit(uint32_t p) { bits_[p >> 6] &= ~((uint64_t)1 << (p & 63)); }
-    inline uint32_t home(int32_t p) const { return ((uint32_t)p * 2654435761u) >> (32 - hb_); }
-    void put(int32_t p, int32_t s) {  // p is not in the table
-        const uint32_t m = ((uint32_t)1 << hb_) - 1;
-        uint32_t h = home(p);
-        while (pos_[h] >= 0) h = (h + 1) & m;
-        dead_ -= pos_[h] == DEAD;
-        pos_[h] = p;
-        slot_[h] = s;
-    }
-    int32_t take(uint32_t p) {  // p is in the table (its bit is set)
-        const uint32_t m = ((uint32_t)1 << hb_) - 1;
-        uint32_t h = home((int32_t)p);
-        while (pos_[h] != (int32_t)p) h = (h + 1) & m;
-        pos_[h] = DEAD;
-        ++dead_;
-        clear_bit(p);
-        where_[(size_t)slot_[h]] = -1;  // in hand until place()
-        return slot_[h];
-    }
-    void place(uint32_t p, int32_t s) {
-        // live + dead entries stay under half of the table (>= 4 k entries), so every probe sequence ends
-        if ((int64_t)dead_ + (int64_t)where_.size() > ((int64_t)1 << (hb_ - 1))) {
-            std::fill(pos_.begin(), pos_.end(), EMPTY);
-            dead_ = 0;
-            for (size_t t = 0; t < where_.size(); ++t)
-                if (where_[t] >= 0) put(where_[t], (int32_t)t);  // pointers in hand (taken, not yet placed) are -1
-        }
+    inline void place(uint32_t p, int32_t s) {
         where_[(size_t)s] = (int32_t)p;
-        set_bit(p);
-        put((int32_t)p, s);
+        slot_at_[p] = s;
+        bits_[p >> 6] |= (uint64_t)1 << (p & 63);
     }
-    std::vector<uint64_t> bits_;
-    std::vector<int32_t> where_, pos_, slot_;
-    int hb_ = 4;
-    int64_t dead_ = 0;
+    uint64_t *bits_ = nullptr;
+    int32_t *slot_at_ = nullptr;
+    std::vector<int32_t> where_;
 };
 
 // steps i0 ... i1-1 of the backward walk
@@ -287,7 +268,9 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
     mt.pos = *mt_pos;
     mt.temper_from(mt.pos);
     if (n <= 0x7fffffffll) {
-        std::vector<uint32_t> Jd((size_t)n + 16);  // Jd[t] = the target of step i = n-1-t
+        static thread_local Scratch sc;
+        if ((int64_t)sc.Jd.size() < n + 16) sc.Jd.resize((size_t)n + 16);
+        std::vector<uint32_t> &Jd = sc.Jd;  // Jd[t] = the target of step i = n-1-t
         const bool wide = have_avx512();
         static const bool timing = getenv("SSW_NPRAND_TIMING") != nullptr;
         auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -296,7 +279,7 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
         else draw_targets(mt, n, Jd.data());  // either way the stream is consumed for the whole shuffle, whatever k is
         const double t1 = timing ? now_ms() : 0.0;
         if (k * 16 <= n) {
-            PrefixTrace tr(n, k);
+            PrefixTrace tr(n, k, sc);
             // (sixteen steps tested at once with a gather of their bitmap words was measured on the EPYC host: 2.16 ms
             // against 2.03 ms for this loop -- the walk's time is the 60 000 pointer moves, not the 1.56 M tests)
             if (k > 0) trace_steps(tr, n, Jd.data(), 1, n);

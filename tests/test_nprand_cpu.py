@@ -26,8 +26,8 @@ def test_prefix_and_stream_equal_numpy(n):
 @pytest.mark.parametrize("n,k", [(300001, 1000), (300001, 18750), (300001, 18751), (160000, 10000), (1000, 62), (1000, 63),
                                  (64, 4), (17, 1), (16, 1)])
 def test_prefixes_on_both_sides_of_the_trace_threshold(n, k):
-    """prefixes up to n/16 are followed backwards through the swaps (a position table that is rebuilt as entries die),
-    longer ones shuffle the array: both against numpy, twice in a row on one stream"""
+    """prefixes up to n/16 are followed backwards through the swaps (occupancy bitmap + pointer-at-position array, kept
+    per thread between calls), longer ones shuffle the array: both against numpy, twice in a row on one stream"""
     np.random.seed(n + k)
     ref = [np.random.permutation(n)[:k] for _ in range(2)]
     ref_next = np.random.random(3)
