@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/clip_trace" -o cli
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/clip_pmc" -o clip -- \
     python3 tools/perf_clip_b200.py 200 > "$OUT/clip_pmc.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/text_trace" -o text -- \
+    python3 tools/perf_text.py > "$OUT/text_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn -- \
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
@@ -33,5 +35,6 @@ cp "$OUT/bench.json" "profiles/${R}_bench_100M_output.json"
 cp "$OUT/bench_trace/bench_kernel_stats.csv" "profiles/${R}_bench_100M_kernel_stats.csv"
 cp "$OUT/clip_trace/clip_kernel_stats.csv" "profiles/${R}_clip_b200_kernel_stats.csv"
 cp "$OUT/knn_trace/knn_kernel_stats.csv" "profiles/${R}_knn_1560k_kernel_stats.csv"
+cp "$OUT/text_trace/text_kernel_stats.csv" "profiles/${R}_clip_text_1x8_kernel_stats.csv"
 for f in profiles/${R}_*; do cp "$f" "gpurun_out/collect/$(basename "$f")"; done   # the box's profiles/ does not travel back
 echo "summaries copied to gpurun_out/collect/: move them to profiles/ and run tools/make_traffic_json.py --stamp-git"

@@ -1,3 +1,4 @@
+"""one text query of 8 tokens, host ids in -> host embedding out, 50 repetitions (tools/collect_profiles.sh traces it)"""
 import time, numpy as np
 from seesaw_amd.models.clip import ClipModel
 m=ClipModel.random_init(seed=1234)
