@@ -96,9 +96,13 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 //                        of the fused qkv buffer, the GEMM's "NT" operand form); the lane holds
 //                        keys 16 j + 4 fq + r of query fr -> row max / sum need two shuffles
 //   softmax   in registers (f32), normalised before the bf16 rounding
-//   out^T   = V^T P^T    P goes through a per-wave 16-row LDS tile (8-byte writes), V is
-//                        transposed once per head into LDS by the whole workgroup; the lane ends
-//                        with 4 consecutive head-dim values of its query -> 8-byte stores
+//   out^T   = V^T P^T    P goes through a per-wave 16-row LDS tile (8-byte writes; 128-byte rows with the GEMM's
+//                        chunk ^= (row>>1)&7 swizzle when KP = 64, so the ds_read_b128 lane groups hit distinct
+//                        slots); V is copied row-major into LDS (16-byte writes) and its V^T fragments come out of
+//                        ds_read_b64_tr_b16 (round 2: the 2-byte transposing writes were 0.73 conflict cycles per
+//                        active LDS cycle); rows are 128 B, the 32-byte chunk of a key row is XORed with
+//                        (key>>1 & 1) | (key>>3 & 1) << 1 so that the eight rows a 32-lane half reads land on
+//                        disjoint banks; the lane ends with 4 consecutive head-dim values of its query
 // qkv [R, 3D] bf16 (q | k | v), out [R, D] bf16
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 80;
@@ -108,10 +112,17 @@ template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
                                                           int D, int H, float scale, int causal) {
     constexpr int KP = ((NT * 16 + 31) / 32) * 32;  // keys padded to the MFMA K step
-    constexpr int LDP = KP + 8;                     // LDS row stride (bf16)
+    constexpr bool PSW = KP == 64;                  // P rows of exactly 128 B: swizzled instead of padded
+    constexpr int LDP = PSW ? 64 : KP + 8;          // LDS row stride of the P tile (bf16)
     constexpr int VCH = (KP * 8 + NT * 64 - 1) / (NT * 64);  // 16-byte V chunks per thread
-    __shared__ __attribute__((aligned(16))) bf16 sVt[64 * LDP];
+    __shared__ __attribute__((aligned(16))) bf16 sV[KP * 64];  // [key][64 head dims], 32-byte chunks swizzled
     __shared__ __attribute__((aligned(16))) bf16 sP[NT][16 * LDP];
+    // element offset of column `col` (a multiple of 4) of P row `row`
+    auto p_off = [](int row, int col) {
+        return PSW ? row * 64 + ((((col >> 3) ^ ((row >> 1) & 7)) << 3) | (col & 7)) : row * LDP + col;
+    };
+    // element offset of 32-byte chunk `c32` (16 head dims) of V row `key`
+    auto v_off = [](int key, int c32) { return key * 64 + ((c32 ^ (((key >> 1) & 1) | (((key >> 3) & 1) << 1))) << 4); };
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -180,36 +191,42 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
             bf16x4 pv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pv[r] = to_bf16(sc[j][r] * inv);
-            *reinterpret_cast<bf16x4 *>(&pt[fr * LDP + j * 16 + fq * 4]) = pv;
+            *reinterpret_cast<bf16x4 *>(&pt[p_off(fr, j * 16 + fq * 4)]) = pv;
         }
         if (KP > NT * 16) {
             bf16x4 z;
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] = (bf16)0.f;
-            *reinterpret_cast<bf16x4 *>(&pt[fr * LDP + NT * 16 + fq * 4]) = z;
+            *reinterpret_cast<bf16x4 *>(&pt[p_off(fr, NT * 16 + fq * 4)]) = z;
         }
     }
-    // V^T into LDS: sVt[d][key]
+    // V into LDS as it is: sV[key][d]
 #pragma unroll
     for (int c = 0; c < VCH; ++c) {
-        const int ch = t + c * NT * 64, key = ch >> 3, d0 = (ch & 7) * 8;
-        if (ch < KP * 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sVt[(d0 + j) * LDP + key] = vreg[c][j];
-        }
+        const int ch = t + c * NT * 64, key = ch >> 3, c16 = ch & 7;
+        if (ch < KP * 8) *reinterpret_cast<bf16x8 *>(&sV[v_off(key, c16 >> 1) + (c16 & 1) * 8]) = vreg[c];
     }
     __syncthreads();
-    if (!tile_live) return;
+    if (!tile_live) return;  // whole waves leave: the transposed reads below need all 64 lanes of a wave
     // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KP / 32; ++ks) {
-        const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[fr * LDP + ks * 32 + fq * 8]);
+        const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[p_off(fr, ks * 32 + fq * 8)]);
+        // V^T fragment (row d = 16 dt + fr, keys ks*32 + 8 fq + 0..7) = two transposed reads of 4 keys x 16 dims: in
+        // each 16-lane group lane 4q + p supplies the address of key row q, dims 4p .. 4p+3, and receives dim `lane`
+        const int kq = ks * 32 + 8 * fq + (fr >> 2), dp = (fr & 3) * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(&sVt[(dt * 16 + fr) * LDP + ks * 32 + fq * 8]);
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sV[v_off(kq, dt) + dp]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sV[v_off(kq + 4, dt) + dp]));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 vb = __builtin_bit_cast(bf16x8, both);
             o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);
         }
     }
