@@ -408,6 +408,146 @@ __global__ __launch_bounds__(64 * NW) void skinny_linear(const void *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// skinny attention + out-projection: h2[R <= 32, 512] = h + bo + softmax(Q K^T / 8, block-causal) V  Wo^T straight from
+// the fused qkv rows -- the attention of a short text query is a few MFMAs, a launch of its own costs more than it
+// does.  Workgroup = 16 output columns, four waves; wave w owns heads 2w and 2w+1, i.e. the 128 of K = 512 that the
+// out-projection's wave w multiplies, so every wave computes exactly the attention output it consumes and nothing goes
+// through memory or LDS in between (each of the 32 workgroups redoes the 8 heads: 32 x a few microseconds of MFMA).
+//   scores^T = K Q^T        lane (fr, fq) ends with scores[query 16i + fr][key 16j + 4fq + r]   (as attention_mfma)
+//   out^T    = V^T P^T      the k index of an MFMA is only a summation label: k-slot 4c + r of lane group fq is
+//                           key 16c + 4fq + r, which is where the softmaxed scores already are; the V^T operand is
+//                           read to match (2-byte loads: V[key][d], eight keys per fragment)
+//   h2       = att Wo^T     same trick: k-slot 4c + r of group fq is head dim 16(2v + c) + 4fq + r, where the
+//                           attention output already is; the Wo fragment is two 8-byte loads to match
+// Rows of several sequences (B x L <= 32) share the tiles: a key counts for a query of the same sequence at or before
+// it (the text tower is causal; `causal = 0` keeps the whole sequence).
+// ---------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(256) void skinny_attn_out(const bf16 *__restrict__ qkv, const bf16 *__restrict__ Wo,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ residual, float *__restrict__ out,
+                                                       int R, int L, float scale, int causal) {
+    constexpr int D = 512, K3 = 3 * D;
+    __shared__ f32x4 part[4][RT][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    // the epilogue's operands first: their latency runs under the attention
+    const int erow = wave * 16 + fr, ecol = n0 + fq * 4;
+    const bool writer = wave < RT && erow < R;
+    const int64_t eo = (int64_t)erow * D + ecol;
+    f32x4 bias_v = f32x4{0.f, 0.f, 0.f, 0.f}, res_v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (writer) {
+        bias_v = *reinterpret_cast<const f32x4 *>(bias + ecol);
+        res_v = *reinterpret_cast<const f32x4 *>(residual + eo);
+    }
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int hcol = (2 * wave + hh) * 64;  // this head's columns inside q, k, v and inside Wo's K
+        // Wo fragments of the head's two k-steps (v = 0, 1): columns hcol + 32v + 16c + 4fq + r of row n0 + fr
+        s16x8 wf[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const bf16 *wp = Wo + (int64_t)(n0 + fr) * D + hcol + 32 * v + 4 * fq;
+            const s16x4 w0 = *reinterpret_cast<const s16x4 *>(wp), w1 = *reinterpret_cast<const s16x4 *>(wp + 16);
+            wf[v] = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        // Q and K fragments: rows 16t + fr (clamped; masked below), dims 32 ks + 8 fq ..
+        bf16x8 qf[RT][2], kf[RT][2];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const bf16 *rowp = qkv + (int64_t)min(t * 16 + fr, R - 1) * K3 + hcol + fq * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[t][ks] = *reinterpret_cast<const bf16x8 *>(rowp + ks * 32);
+                kf[t][ks] = *reinterpret_cast<const bf16x8 *>(rowp + D + ks * 32);
+            }
+        }
+        // V^T fragments: row d = 16 dt + fr, k-slot 4c + r = key 16c + 4fq + r
+        s16x8 vt[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int key = 16 * (e >> 2) + 4 * fq + (e & 3);
+                const bool live = key < R && (e >> 2) < RT;
+                vt[dt][e] = live ? *reinterpret_cast<const short *>(qkv + (int64_t)key * K3 + 2 * D + hcol + 16 * dt + fr)
+                                 : (short)0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            // scores of query 16i + fr against keys 16j + 4fq + r
+            f32x4 sc[RT];
+            const int q = i * 16 + fr, qseq = q / L;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[i][ks], sc[j], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j * 16 + fq * 4 + r;
+                    float v = sc[j][r] * scale;
+                    if (key >= R || key / L != qseq || (causal && key > q)) v = -INFINITY;
+                    sc[j][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (q >= R) mx = 0.f;  // rows nobody writes: keep them finite
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < RT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sc[j][r] - mx);
+                    sc[j][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = q < R ? 1.f / sum : 0.f;
+            // P^T operand: k-slot 4c + r = key 16c + 4fq + r (zero beyond the RT key tiles)
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[e] = (e >> 2) < RT ? to_bf16(sc[(e >> 2) < RT ? (e >> 2) : 0][e & 3] * inv) : to_bf16(0.f);
+            // attention output of the head: lane (fr = query, fq) holds dims 16 dt + 4fq + r
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dt]), pb,
+                                                                f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // into the out-projection: k-step v takes dims 16(2v + c) + 4fq + r, rounded to bf16 as the att buffer was
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                bf16x8 ab;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ab[e] = to_bf16(o[2 * v + (e >> 2)][e & 3]);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[v]), ab, acc[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (!writer) return;
+    f32x4 v = part[0][wave][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += part[w][wave][lane];
+    v += bias_v;
+    v += res_v;
+    *reinterpret_cast<f32x4 *>(out + eo) = v;
+}
+
+// ---------------------------------------------------------------------------------------
 // embeddings
 // ---------------------------------------------------------------------------------------
 // pixels [B,3,224,224] f32 -> patches [B*49, 3072] bf16, column = c*1024 + py*32 + px
@@ -755,10 +895,10 @@ void launch_skinny(hipStream_t s, const void *X, const int *row_index, const flo
     }
 }
 
-// a handful of rows (one short text query): five launches a layer, every one over N/16 workgroups
+// a handful of rows (one short text query): four launches a layer, every one over N/16 workgroups
 bool skinny_rows(int R, int D, int M) {
     static const bool off = getenv("SSW_CLIP_NO_SKINNY") != nullptr;
-    return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);
+    return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);  // (head dim 64: 8 heads)
 }
 
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
@@ -766,15 +906,24 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     const int R = B * S, D = tw.D, M = tw.M;
     const float eps = c->hdr.ln_eps;
     float *h = c->hidden, *h2 = c->hidden2;
-    const bool skinny = skinny_rows(R, D, M);
+    const bool skinny = skinny_rows(R, D, M) && tw.H * 64 == D;  // skinny_attn_out: 8 heads of 64
     for (int l = 0; l < tw.L && skinny; ++l) {
         const Layer &ly = tw.layers[l];
         launch_skinny<SK_BF16_BIAS, true>(s, h, nullptr, ly.ln1w, ly.ln1b, eps, ly.wqkv, ly.bqkv, nullptr, c->qkv, R,
                                           3 * D, D);
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
-        hipLaunchKernelGGL(attention_mfma<4>, dim3(B * tw.H), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
-                           causal);
-        launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->att, nullptr, nullptr, nullptr, eps, ly.wo, ly.bo, h, h2, R, D, D);
+        static const bool two_launches = getenv("SSW_CLIP_NO_FUSED_ATTN") != nullptr;  // A/B: attention as its own launch
+        if (two_launches) {
+            hipLaunchKernelGGL(attention_mfma<4>, dim3(B * tw.H), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
+                               causal);
+            launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->att, nullptr, nullptr, nullptr, eps, ly.wo, ly.bo, h, h2, R, D, D);
+        } else if (R <= 16) {
+            hipLaunchKernelGGL(skinny_attn_out<1>, dim3(D / 16), dim3(256), 0, s, c->qkv, ly.wo, ly.bo, h, h2, R, S,
+                               att_scale, causal);
+        } else {
+            hipLaunchKernelGGL(skinny_attn_out<2>, dim3(D / 16), dim3(256), 0, s, c->qkv, ly.wo, ly.bo, h, h2, R, S,
+                               att_scale, causal);
+        }
         launch_skinny<SK_BF16_BIAS_GELU, true>(s, h2, nullptr, ly.ln2w, ly.ln2b, eps, ly.w1, ly.b1, nullptr, c->h1, R, M, D);
         launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->h1, nullptr, nullptr, nullptr, eps, ly.w2, ly.b2, h2, h, R, D, M);
     }
