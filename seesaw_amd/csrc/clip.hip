@@ -1002,7 +1002,7 @@ ssw_status image_forward_u8(ssw_clip *c, const uint8_t *tiles_dev, int B, int no
     return image_forward_from_patches(c, B, normalize, out_dev);
 }
 
-// A single query is ~64 dependent launches of 4-6 us kernels.  Replaying them as a captured hipGraph was measured
+// A single query is ~52 dependent launches of 4-6 us kernels (85 through the tile kernels).  Replaying them as a captured hipGraph was measured
 // (round 2: 0.300 ms eager, 0.298 ms replayed; 0.645 / 0.631 before the skinny kernels) and dropped: the launches are
 // not host-bound, the queue already holds them back to back.
 ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int normalize, float *out_dev) {
