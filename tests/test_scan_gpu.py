@@ -127,6 +127,31 @@ def test_topk_massive_ties_take_deep_path(DeviceIndex, oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("spread", [1.0, 3e-2, 1e-3, 2e-5, 3e-7])
+def test_topk_of_loaded_scores_at_every_histogram_depth(DeviceIndex, oracle, spread):
+    """scores spread over the whole range (one histogram level), inside one 12-bit bin (second level, taken from 1024
+    first-level candidates on), inside one 24-bit prefix (more candidates than the final sort holds: deep path), with
+    negative values, duplicates and -inf rows: always the exact top-k in (score desc, position asc) order"""
+    rng = np.random.default_rng(int(1 / spread))
+    n = 60000
+    idx = DeviceIndex.synthetic(n, 512, seed=5)
+    for centre in (0.37, -0.37):
+        s = (centre + spread * rng.random(n)).astype(np.float32)
+        s[rng.integers(0, n, 500)] = s[rng.integers(0, n, 500)]      # duplicates
+        s[rng.integers(0, n, 50)] = -np.inf                          # rows that never take part
+        idx.load_scores(s)
+        excluded = rng.choice(n, 300, replace=False)
+        for k in (1, 50, 1000, 4096):
+            imgs, scores, rows = idx.topk(None, k, excluded=excluded)
+            sx = s.copy()
+            sx[excluded] = -np.inf
+            order = np.lexsort((np.arange(n), -sx.astype(np.float64)))[:k]
+            assert np.array_equal(imgs, order), (spread, centre, k)
+            assert np.array_equal(bits(scores), bits(sx[order]))
+            assert np.array_equal(rows, order)
+    idx.close()
+
+
 def test_nan_query_rejected(DeviceIndex, oracle):
     from seesaw_amd._lib import SeesawHipError
     idx = DeviceIndex.synthetic(128, 512, seed=0)
