@@ -596,6 +596,11 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 //  one barrier per step, 188 VGPRs: same results, 693 TFLOP/s on fc1 and 507 on fc2.  So the waits of the two-stage
 //  kernels are not a shortage of operands in flight either.  Removed again.)
 
+// (Staggering the two workgroups of a CU -- the second one sleeping 3, 5 or 8 us before its first load, so that their
+//  +residual epilogues do not hit HBM together -- was measured on the three EPI 3 shapes: every variant adds about half
+//  its delay to the launch (out-proj 21.5 -> 22.9 / 24.1 / 25.8 us).  A workgroup alone on its CU does not run faster
+//  than one that shares it: the K loop is bound by its own latency chain, not by the shared matrix pipes.)
+
 int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
