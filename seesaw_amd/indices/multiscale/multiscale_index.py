@@ -251,10 +251,7 @@ class MultiscaleIndex(AccessMethod):
         self._resident_q = None
         pos, scores, best_rows = self._dev.topk(None, max(1, min(int(topk_dbidx), self._dbidx.shape[0])), excluded=excl_pos)
         keep = np.isfinite(scores)
-        df = pd.DataFrame({"dbidx": self._dbidx[pos[keep]], "max_score": scores[keep]})
-        df.attrs["positions"] = pos[keep]
-        df.attrs["best_rows"] = best_rows[keep]
-        return df
+        return _Candidates(self._dbidx[pos[keep]], scores[keep], pos[keep], best_rows[keep])  # (`.df` for a frame)
 
     def _activations_from_best(self, candidate_df: pd.DataFrame, topk: int):
         rows = np.asarray(candidate_df.attrs["best_rows"][:topk], dtype=np.int64)
