@@ -601,6 +601,10 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 //  its delay to the launch (out-proj 21.5 -> 22.9 / 24.1 / 25.8 us).  A workgroup alone on its CU does not run faster
 //  than one that shares it: the K loop is bound by its own latency chain, not by the shared matrix pipes.)
 
+// (A sixth structure, same kernel template: 256 x 128 tiles, 16 waves of 64 x 32, three-stage ring, one workgroup per
+//  CU -- a quarter less L2->LDS traffic per flop and operands requested two K-steps ahead.  fc2 886 vs 880 TFLOP/s,
+//  out-proj 522 vs 523, patch 940 vs 926; qkv 651 vs 722, fc1 650 vs 700.  Not kept.)
+
 int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
