@@ -252,3 +252,25 @@ def test_repeated_single_queries_are_bit_identical(models):
     again = [ours.embed_text(a, normalize=True) for _ in range(3)]
     for x in again:
         assert np.array_equal(x.view(np.uint32), first.view(np.uint32))
+
+
+def test_single_query_path_agrees_with_tile_path_over_random_shapes(models):
+    """every (B, L) with B x L <= 32 takes the skinny kernels (one or two 16-row tiles, one or several sequences under
+    the block-causal mask, EOS anywhere): 24 random shapes against the same rows pushed through the tile kernels"""
+    _, ours = models
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1), (1, 2), (32, 1), (16, 2), (2, 15), (1, 16), (1, 17), (4, 8)]
+    while len(shapes) < 24:
+        L = int(rng.integers(1, 33))
+        shapes.append((int(rng.integers(1, 32 // L + 1)), L))
+    for B, L in shapes:
+        ids = rng.integers(0, 49405, size=(B, L)).astype(np.int32)
+        ids[:, 0] = 49406
+        for b in range(B):
+            ids[b, int(rng.integers(0, L))] = 49407  # (a one-token row is just its end-of-text token)
+        got = ours.embed_text(ids, normalize=True)
+        reps = -(-33 // (B * L))
+        tiled = ours.embed_text(np.tile(ids, (reps + 1, 1)), normalize=True)[:B]
+        assert np.isfinite(got).all()
+        assert (got * tiled).sum(1).min() >= 0.99995, (B, L)
+        assert np.abs(got - tiled).max() <= 1e-3, (B, L, np.abs(got - tiled).max())
