@@ -225,6 +225,9 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
  * same device path as the later ones. */
 ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels);
 ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host);
+/* out[i] = result[rows[i]] for m nodes (host arrays): the pseudo-labels makeXy takes from the propagated scores
+ * (seesaw/loops/util.py:19, `lr.current_scores()[~is_labeled][randsel]`) -- 8 m bytes back instead of 8 n. */
+ssw_status ssw_labelprop_gather(ssw_lp *lp, const int64_t *rows_host, int64_t m, double *out_host);
 ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled);
 /* device address of the [n] f64 result of the last propagation (valid until the next run on this handle). */
 ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores);

@@ -1216,6 +1216,7 @@ struct ssw_fb {
     double *loss_dev = nullptr, *loss_host = nullptr;  // total loss in f64
     int64_t *rows = nullptr;   // gather staging
     float *partial = nullptr;  // [nslabs(cap), dim]
+    float *rankg = nullptr;    // [cap] net position changes of the rank objective (SSW_FB_RANKREG)
     double *colsum = nullptr;  // [cap / FB_CENTER_ROWS, dim] block sums of the centring step
     float *w = nullptr;        // [dim + 1]
     float *qhat = nullptr;     // [dim]
@@ -1249,9 +1250,10 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
+    (void)hipFree(fb->rankg);
     (void)hipFree(fb->colsum);
     fb->colsum = nullptr;
-    fb->X = fb->y = fb->coef = fb->z = fb->r = fb->partial = nullptr;
+    fb->X = fb->y = fb->coef = fb->z = fb->r = fb->partial = fb->rankg = nullptr;
     fb->item = nullptr;
     fb->rows = nullptr;
     fb->cap = 0;
@@ -1266,6 +1268,7 @@ static ssw_status fb_reserve(ssw_fb *fb, int64_t n) {
     SSW_HIP_TRY(hipMalloc((void **)&fb->r, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->rows, (size_t)cap * sizeof(int64_t)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->partial, (size_t)nslabs * fb->dim * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->rankg, (size_t)cap * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&fb->colsum, (size_t)((cap + FB_CENTER_ROWS - 1) / FB_CENTER_ROWS) * fb->dim * sizeof(double)));
     fb->cap = cap;
     return SSW_OK;
@@ -1415,8 +1418,8 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
                                    pw, n, fb->item, fb->r, dev.exact);
         } else if (rankreg) {
             // z is ready: net position changes by counting (rank.hip), then |g| / total_pairs and g / total_pairs
-            SSW_TRY(launch_rank_quick(fb->y, fb->z, (int)n, fb->partial /* scratch: [n] floats */, nullptr, nullptr, s));
-            hipLaunchKernelGGL(k_fb_rank_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->partial,
+            SSW_TRY(launch_rank_quick(fb->y, fb->z, (int)n, fb->rankg, nullptr, nullptr, s));
+            hipLaunchKernelGGL(k_fb_rank_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fb->rankg,
                                fb->rank_factor, n, fb->item, fb->r);
         } else if (pairwise_active) {
             const size_t lds = (size_t)3 * n * sizeof(float);
@@ -1650,6 +1653,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
+    (void)hipFree(fb->rankg);
     (void)hipFree(fb->colsum);
     (void)hipFree(fb->w);
     (void)hipFree(fb->qhat);
@@ -1699,6 +1703,11 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         ssw_fb_destroy(fb);
         return SSW_ERR_NOMEM;
     }
+    // hipHostMalloc does not zero: a stale completion word equal to the first sequence number would end the
+    // first wait before the kernel has written anything
+    memset(fb->flag_host, 0, 64);
+    memset(fb->out_host, 0, outn * sizeof(float));
+    memset(fb->loss_host, 0, sizeof(double));
     if (hipHostGetDevicePointer((void **)&fb->out_host_dev, fb->out_host, 0) != hipSuccess ||
         hipHostGetDevicePointer((void **)&fb->loss_host_dev, fb->loss_host, 0) != hipSuccess ||
         hipHostGetDevicePointer((void **)&fb->flag_host_dev, fb->flag_host, 0) != hipSuccess) {
@@ -1867,11 +1876,8 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
         }
         const size_t lds = fit_wg_lds_bytes(fb->dim);
         auto kern = fb->dim + 1 <= 9 * 64 ? k_fb_fit_wg<9> : k_fb_fit_wg<16>;
-        static bool lds_attr[2] = {false, false};
-        if (!lds_attr[fb->dim + 1 <= 9 * 64 ? 0 : 1]) {
-            SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            lds_attr[fb->dim + 1 <= 9 * 64 ? 0 : 1] = true;
-        }
+        // the attribute is per device: set it on every fit (microseconds next to a fit) rather than cache a process-wide flag
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, fb->stream, a, w0v);
         SSW_HIP_TRY(hipGetLastError());
         {

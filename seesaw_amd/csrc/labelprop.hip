@@ -345,6 +345,14 @@ __global__ void k_xlx_reduce(const double *__restrict__ P, int n_chunks, int64_t
 
 using namespace ssw;
 
+namespace {
+__global__ void k_lp_gather(const double *__restrict__ f, const int64_t *__restrict__ rows, int64_t m,
+                            double *__restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < m) out[i] = f[rows[i]];
+}
+}  // namespace
+
 struct ssw_lp {
     int device = 0;
     int64_t n = 0, nnz = 0;
@@ -375,6 +383,10 @@ struct ssw_lp {
     std::vector<int64_t> bl_base;    // [nblk + 1] first non-zero of every slice
     int64_t *bl_base_dev = nullptr;  // device copy
     int groups = 6;                  // row groups of 256 per workgroup of k_lp_sweep_fused (grid just resident)
+    // ssw_labelprop_gather staging: device [cap] ids + values, pinned host mirror of both
+    int64_t *g_rows = nullptr, *g_rows_host = nullptr;
+    double *g_vals = nullptr, *g_vals_host = nullptr;
+    int64_t g_cap = 0;
 };
 
 extern "C" {
@@ -391,6 +403,10 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
     (void)hipFree(lp->f[0]);
     (void)hipFree(lp->f[1]);
     (void)hipFree(lp->is_label);
+    (void)hipFree(lp->g_rows);
+    (void)hipFree(lp->g_vals);
+    if (lp->g_rows_host) (void)hipHostFree(lp->g_rows_host);
+    if (lp->g_vals_host) (void)hipHostFree(lp->g_vals_host);
     (void)hipFree(lp->label_val);
     (void)hipFree(lp->ids);
     (void)hipFree(lp->vals);
@@ -741,6 +757,42 @@ ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host) {
     SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[lp->last_result], (size_t)lp->n * sizeof(double),
                                hipMemcpyDeviceToHost, lp->stream));
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    return SSW_OK;
+}
+
+// f[rows[i]] for a short list of nodes: what makeXy (loops/util.py:19) needs of the propagated scores -- the
+// pseudo-labels of `sample_size` nodes -- without moving the whole [n] f64 iterate over PCIe
+ssw_status ssw_labelprop_gather(ssw_lp *lp, const int64_t *rows_host, int64_t m, double *out_host) {
+    SSW_REQUIRE(lp != nullptr && m >= 0 && (m == 0 || (rows_host != nullptr && out_host != nullptr)), "bad argument");
+    SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_gather: nothing has been propagated yet");
+    if (m == 0) return SSW_OK;
+    for (int64_t i = 0; i < m; ++i)
+        SSW_REQUIRE(rows_host[i] >= 0 && rows_host[i] < lp->n, "ssw_labelprop_gather: node %lld outside [0, %lld)",
+                    (long long)rows_host[i], (long long)lp->n);
+    DeviceGuard guard(lp->device);
+    if (m > lp->g_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+        (void)hipFree(lp->g_rows);
+        (void)hipFree(lp->g_vals);
+        if (lp->g_rows_host) (void)hipHostFree(lp->g_rows_host);
+        if (lp->g_vals_host) (void)hipHostFree(lp->g_vals_host);
+        lp->g_rows = nullptr, lp->g_vals = nullptr, lp->g_rows_host = nullptr, lp->g_vals_host = nullptr, lp->g_cap = 0;
+        int64_t cap = 16384;
+        while (cap < m) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&lp->g_rows, (size_t)cap * sizeof(int64_t)));
+        SSW_HIP_TRY(hipMalloc((void **)&lp->g_vals, (size_t)cap * sizeof(double)));
+        SSW_HIP_TRY(hipHostMalloc((void **)&lp->g_rows_host, (size_t)cap * sizeof(int64_t), hipHostMallocDefault));
+        SSW_HIP_TRY(hipHostMalloc((void **)&lp->g_vals_host, (size_t)cap * sizeof(double), hipHostMallocDefault));
+        lp->g_cap = cap;
+    }
+    memcpy(lp->g_rows_host, rows_host, (size_t)m * sizeof(int64_t));
+    SSW_HIP_TRY(hipMemcpyAsync(lp->g_rows, lp->g_rows_host, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, lp->stream));
+    hipLaunchKernelGGL(k_lp_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, lp->stream,
+                       lp->f[lp->last_result], lp->g_rows, m, lp->g_vals);
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_HIP_TRY(hipMemcpyAsync(lp->g_vals_host, lp->g_vals, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, lp->stream));
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    memcpy(out_host, lp->g_vals_host, (size_t)m * sizeof(double));
     return SSW_OK;
 }
 

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank_quick(const float *__restri
     }
     if (act) {
         out_grad[x] = 2.f * (float)(pos2 - pos1);
-        out_maxrev[x] = (float)(n - same);
-        atomicAdd(out_total, (unsigned long long)(n - same));  // total_pairs = n^2 - sum of class sizes squared
+        if (out_maxrev) out_maxrev[x] = (float)(n - same);
+        if (out_total) atomicAdd(out_total, (unsigned long long)(n - same));  // total_pairs = n^2 - sum of class sizes squared
     }
 }
 
@@ -94,23 +94,8 @@ namespace ssw {
 ssw_status launch_rank_quick(const float *target_dev, const float *scores_dev, int n, float *grad_dev,
                              float *maxrev_dev_or_null, unsigned long long *total_dev_or_null, hipStream_t stream) {
     if (n <= 0) return SSW_OK;
-    static unsigned long long *sink = nullptr;  // where the totals go when the caller does not want them
-    static float *sinkf = nullptr;
-    static int sink_cap = 0;
-    if (!total_dev_or_null && !sink) SSW_HIP_TRY(hipMalloc((void **)&sink, sizeof(unsigned long long)));
-    if (!maxrev_dev_or_null && sink_cap < n) {
-        SSW_HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(sinkf);
-        sinkf = nullptr;
-        sink_cap = 0;
-        int cap = 4096;
-        while (cap < n) cap <<= 1;
-        SSW_HIP_TRY(hipMalloc((void **)&sinkf, (size_t)cap * sizeof(float)));
-        sink_cap = cap;
-    }
     hipLaunchKernelGGL(k_rank_quick, dim3((unsigned)((n + RK_THREADS - 1) / RK_THREADS)), dim3(RK_THREADS), 0, stream,
-                       target_dev, scores_dev, n, grad_dev, maxrev_dev_or_null ? maxrev_dev_or_null : sinkf,
-                       total_dev_or_null ? total_dev_or_null : sink);
+                       target_dev, scores_dev, n, grad_dev, maxrev_dev_or_null, total_dev_or_null);  // NULL outputs are skipped
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

@@ -144,12 +144,9 @@ static ssw_status launch_avg_score_t(const float *boxes, const int32_t *zoom, co
     }
     const size_t lds = avg_score_lds_bytes(max_tiles, sizeof(ST));
     if (lds > (size_t)64 * 1024) {  // 2048 tiles of f64 scores: 80 KB
-        static bool attr_set = false;
-        if (!attr_set) {
-            SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_avg_score<ST>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
-        }
+        // per device and cheap: set on every such launch instead of caching a process-wide flag
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_avg_score<ST>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
     hipLaunchKernelGGL(k_avg_score<ST>, dim3((unsigned)m), dim3(RS_THREADS), lds, stream,
                        reinterpret_cast<const float4 *>(boxes), zoom, scores, minus_or_null, row_start, cand_pos,

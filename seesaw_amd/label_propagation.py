@@ -86,6 +86,13 @@ class LabelPropagation:
         _lib.call("ssw_labelprop_fetch", self._h, _p(out))
         return out
 
+    def gather(self, rows) -> np.ndarray:
+        """result[rows] of the last propagation: 8 bytes per asked node cross PCIe, not the whole iterate"""
+        rows = np.ascontiguousarray(np.asarray(rows).reshape(-1), dtype=np.int64)
+        out = np.empty(rows.shape[0], dtype=np.float64)
+        _lib.call("ssw_labelprop_gather", self._h, _p(rows), rows.shape[0], _p(out))
+        return out
+
     def device_scores_ptr(self) -> int:
         """device address of the f64 result of the last propagation"""
         out = ctypes.c_void_p()

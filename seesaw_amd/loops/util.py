@@ -6,6 +6,13 @@ import numpy as np
 from ..nprand import permutation_prefix
 
 
+def _scores_at(lr, pick):
+    """lr.current_scores()[pick] (seesaw/loops/util.py:19); a ranker whose scores are still on the device hands
+    back just those entries"""
+    at = getattr(lr, "scores_at", None)
+    return at(pick) if at is not None else lr.current_scores()[pick]
+
+
 def makeXy(idx, lr, sample_size, pseudoLabel=True):
     """real labels + a random sample of pseudo-labelled vectors (their propagated scores)."""
     is_labeled = lr.is_labeled > 0
@@ -16,7 +23,7 @@ def makeXy(idx, lr, sample_size, pseudoLabel=True):
         unl = np.nonzero(~is_labeled)[0]
         pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
         rows = np.concatenate((rows, pick))
-        y = np.concatenate((y, lr.current_scores()[pick]))
+        y = np.concatenate((y, _scores_at(lr, pick)))
         is_real = np.concatenate((is_real, np.zeros(pick.shape[0])))
     return idx.vectors[rows], y, is_real
 
@@ -38,7 +45,7 @@ def makeXy_rows(lr, sample_size):
         unl = np.nonzero(~is_labeled)[0]
         pick = unl[permutation_prefix(unl.shape[0], sample_size)]  # == np.random.permutation(n)[:sample_size]
     is_real = np.ones_like(y)
-    return (np.concatenate((rows, pick)), np.concatenate((y, lr.current_scores()[pick])),
+    return (np.concatenate((rows, pick)), np.concatenate((y, _scores_at(lr, pick))),
             np.concatenate((is_real, np.zeros(pick.shape[0]))))
 
 

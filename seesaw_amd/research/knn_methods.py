@@ -136,6 +136,12 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
             self._current_scores = self.lp.fetch()
         return self._current_scores
 
+    def scores_at(self, rows) -> np.ndarray:
+        """current_scores()[rows] without fetching the whole vector when it still lives on the device"""
+        if self._current_scores is None and getattr(self, "_resident", False):
+            return self.lp.gather(rows)
+        return self.current_scores()[rows]
+
     def scores_on_device(self) -> bool:
         """True when the latest scores live in the label-propagation handle (not yet fetched)"""
         return bool(getattr(self, "_resident", False))

@@ -132,6 +132,12 @@ def test_resident_chaining_equals_host_round_trip(oracle):
         lp.fit_resident(label_ids=ids, label_values=vals)
         assert lp.last_sweeps == sweeps
         assert np.array_equal(lp.fetch(), want)
+    # a short list of nodes (PseudoLR's pseudo-labels, loops/util.py:19) without fetching the iterate
+    pick = rng.choice(n, size=300, replace=True).astype(np.int64)
+    assert np.array_equal(lp.gather(pick), want[pick])
+    assert lp.gather(np.zeros(0, np.int64)).shape == (0,)
+    with pytest.raises(RuntimeError):
+        lp.gather(np.array([n], np.int64))
     dev = DeviceIndex.from_numpy(g["X"])
     lp.scores_to_index(dev, mask_labeled=True)
     s32 = want.astype(np.float32)

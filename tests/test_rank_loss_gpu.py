@@ -137,3 +137,30 @@ def test_rank_regression_lossgrad_along_reference_trajectory_and_fit(g, oracle):
         Xc = X - X.mean(axis=0)
         print(f"rank regression {k}: final loss ours {ours:.3e} vs reference {L[-1]:.3e}; |scores diff| = "
               f"{np.abs(Xc @ (model.get_coeff().reshape(-1) - g[f'rr{k}_coeff'].reshape(-1))).max():.2e}")
+
+
+def test_rank_regression_narrow_dim_equals_zero_padded_wide_dim():
+    """dim = 16 with 300 rows: the rank objective's [n] scratch is larger than the [n / 32, dim] partial-gradient
+    buffer it once borrowed (out-of-bounds for dim < 32).  The same data zero-padded to dim = 32 is the
+    same objective, so loss and gradient must agree and the padded gradient entries must vanish."""
+    from seesaw_amd.logistic_regression import RankRegressionPT
+    rng = np.random.default_rng(5)
+    n, d = 300, 16
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    q /= np.linalg.norm(q)
+    y = (X @ q + 0.5 * rng.standard_normal(n) > 0.8).astype(np.float32)
+    Xp = np.concatenate([X, np.zeros((n, 16), np.float32)], axis=1)
+    qp = np.concatenate([q, np.zeros(16, np.float32)])
+    narrow = RankRegressionPT(scale="centered", reg_lambda=1.0, regularizer_vector=q, max_iter=20, lr=1.0)
+    wide = RankRegressionPT(scale="centered", reg_lambda=1.0, regularizer_vector=qp, max_iter=20, lr=1.0)
+    narrow.fit(X, y.reshape(-1, 1), w0=q.copy())
+    wide.fit(Xp, y.reshape(-1, 1), w0=qp.copy())
+    for t in range(4):
+        w = (q + 0.3 * rng.standard_normal(d)).astype(np.float32)
+        l1, g1, _ = narrow.lossgrad(w)
+        l2, g2, _ = wide.lossgrad(np.concatenate([w, np.zeros(16, np.float32)]))
+        assert abs(l1 - l2) <= 1e-6 * max(1.0, abs(l2)), (t, l1, l2)
+        assert np.abs(g1[:d] - g2[:d]).max() <= 1e-6 * max(1.0, np.abs(g2).max()), t
+        assert np.abs(g2[d:32]).max() == 0.0
+    assert np.abs(narrow.get_coeff().reshape(-1)[:d] - wide.get_coeff().reshape(-1)[:d]).max() <= 1e-5
