@@ -144,7 +144,7 @@ ssw_status ssw_index_score_rows(ssw_index *idx, const float *q_host, const int64
 
 /* ------------------------------------------------------------------------- */
 /* Second stage of the multiscale lookup: `avg_score` aggregation on the device */
-/* replaces: score_frame2 (aug_weight='level_max') + box_join as driven by      */
+/* replaces: score_frame2 (both aug_weight modes) + box_join as driven by        */
 /*           rescore_candidates   seesaw/indices/multiscale/multiscale_index.py */
 /*           :112-150, 379-403;   seesaw/box_utils.py:336-372                   */
 /* ------------------------------------------------------------------------- */
@@ -157,7 +157,10 @@ ssw_status ssw_index_set_tile_meta(ssw_index *idx, const float *boxes_host, cons
  * represented by its first tile with the highest aggregated score.  Tile scores are the ones the last scan left
  * on the device, minus minus_scores (optional; one value per candidate tile, candidates in the given order, tiles
  * in row order: the `vector2` form, multiscale_index.py:347-349).  IoU in f32 as torchvision forms it, mean as
- * pandas' float32 group mean (Kahan sum): bit-identical to the reference on identical tile scores. */
+ * pandas' float32 group mean (Kahan sum): bit-identical to the reference on identical tile scores.
+ * aug_larger + 4 selects aug_weight = 'cont_weighted' (multiscale_index.py:133-145): tile i's score := softmax over
+ * ALL its joined partners of the containment inter / area_i, dotted with the partners' scores (f32; 1e-6 of the
+ * reference, whose dot runs in BLAS order). */
 ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions, int32_t m, int32_t aug_larger,
                                  const float *minus_scores_or_null, float *out_scores, int64_t *out_best_rows);
 /* the same aggregation over float64 tile scores that live on the device, one per index row (the output of
@@ -277,6 +280,20 @@ typedef struct ssw_fb_objective {
     float reg_data_lambda; /* MULTIREG (needs ssw_fb_set_xlx when != 0)                        */
     float reg_query_lambda;/* MULTIREG                                                         */
 } ssw_fb_objective;
+
+/* Two linear outputs sharing the rows: MultiRegModule, the scorer of the multi_reg_neg loop
+ * (seesaw/loops/multi_reg_module.py:40-165, loops/multi_reg_neg.py:26-109).  W [2, dim] raw weights (row 0 the target
+ * query, row 1 the confusion class); logits use the L2-normalised rows.  loss = sum_i s_i [bce(z_i0, y_i0) +
+ * bce(z_i1, y_i1)] + sum_{i: y_i0 + y_i1 > 0} s_i CE(z_i, y_i) + reg_norm_lambda sum_c (cosh(log |W_c|) - 1)
+ * + reg_query_lambda sum_c (1 - <W_c / |W_c|, q^>) / 2, all f32 as in the reference.  Rows come from
+ * ssw_fb_set_data[_from_device] (centred), the query from ssw_fb_set_query; y2 is [n, 2] row-major.
+ * ssw_fb_fit2 = one torch.optim.LBFGS(strong_wolfe).step from W_inout (BasicTrainer.fit, max_epochs = 1).
+ * out_parts5: loss_norm, loss_queryreg, loss_queryreg2, vertical, horizontal.  dim <= 512. */
+ssw_status ssw_fb_set_targets2(ssw_fb *fb, const float *y2_host, const float *sample_weight_or_null);
+ssw_status ssw_fb_lossgrad2(ssw_fb *fb, const float *W_host, float reg_norm_lambda, float reg_query_lambda,
+                            float *out_loss, float *out_grad, float *out_parts5_or_null);
+ssw_status ssw_fb_fit2(ssw_fb *fb, float *W_inout, float reg_norm_lambda, float reg_query_lambda, int32_t max_iter,
+                       float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss);
 
 ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out);
 ssw_status ssw_fb_destroy(ssw_fb *fb);

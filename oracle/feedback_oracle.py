@@ -164,3 +164,48 @@ def multireg_optimum(X, y, img, q, xlx, *, loss_type, margin=0.2, l_norm=100.0, 
     for _ in range(3):
         opt.step(closure)
     return F.normalize(w.detach(), dim=-1).float().numpy().copy()
+
+
+# ---- MultiRegModule: seesaw/loops/multi_reg_module.py:40-165 (the multi_reg_neg loop's scorer) -------------
+def multiregneg_loss(W, Xc, ys, vec_weight, qhat, *, l_norm, l_query):
+    """W [2, d] raw weights, ys [n, 2] f32 (target, confusion class), vec_weight [n].  Restates _step
+    (multi_reg_module.py:64-128): per-output BCE summed per row ("vertical"), cross entropy with probability targets on
+    the rows carrying any label ("horizontal"), both weighted by the per-image sample weight; norm and query
+    regularisers on both rows of W."""
+    sw = vec_weight.float()
+    nw = F.normalize(W, dim=1)
+    logits = Xc @ nw.t()
+    vertical = F.binary_cross_entropy_with_logits(logits, ys, reduction="none").sum(dim=1)
+    near = ys.sum(dim=1)
+    horizontal = F.cross_entropy(logits[near > 0], ys[near > 0], reduction="none")
+    vsum = vertical @ sw
+    hsum = horizontal @ sw[near > 0]
+    loss_norm = l_norm * (torch.cosh(W.norm(dim=1).log()) - 1.0).sum()
+    lq0 = l_query * ((1 - nw[0] @ qhat) / 2.0)
+    lq1 = l_query * ((1 - nw[1] @ qhat) / 2.0)
+    return vsum + hsum + loss_norm + lq0 + lq1, (loss_norm, lq0, lq1, vsum, hsum)
+
+
+def multiregneg_prepare(X, ys, img, q):
+    X = np.asarray(X, dtype=np.float32)
+    Xc = torch.from_numpy(X - X.mean(axis=0).reshape(1, -1))
+    _, inv, counts = np.unique(img, return_inverse=True, return_counts=True)
+    vec_weight = torch.from_numpy(1.0 / counts[inv].astype(np.float64))
+    qhat = F.normalize(torch.from_numpy(np.asarray(q, dtype=np.float32)).reshape(-1), dim=-1)
+    return Xc, torch.from_numpy(np.asarray(ys, dtype=np.float32)), vec_weight, qhat
+
+
+def multiregneg_fit(X, ys, img, q, W0, *, l_norm, l_query, max_iter=100, lr=1.0):
+    """MultiRegModule.fit from the start weights W0 -> raw weights [2, d]."""
+    Xc, yt, vw, qhat = multiregneg_prepare(X, ys, img, q)
+    W = torch.from_numpy(np.asarray(W0, dtype=np.float32).copy()).requires_grad_(True)
+    opt = torch.optim.LBFGS([W], max_iter=max_iter, lr=lr, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        loss, _ = multiregneg_loss(W, Xc, yt, vw, qhat, l_norm=l_norm, l_query=l_query)
+        loss.backward()
+        return loss
+
+    opt.step(closure)
+    return W.detach().numpy().copy()

@@ -814,8 +814,178 @@ def gen_lknn():
     save("lknn", **out)
 
 
+def gen_multiregneg():
+    """(viii) the multi_reg_neg loop: MultiRegModule.fit (loops/multi_reg_module.py:40-165) on seeded rows -- start
+    weights (nn.Linear's draw), the closure trajectory of the first shuffle seed, the fitted weights of all FIT_SEEDS,
+    one evaluation with the rows in storage order -- and whole sessions of the loop (loops/multi_reg_neg.py) under the
+    simulated user's textual feedback (seesaw_bench.py:246-258, confusion class registered for the synthetic category)."""
+    import contextlib
+    import io
+    import json
+    import pandas as pd
+    import torch
+    from seesaw_amd.synthetic import make_dataset
+    mrm = R.ref("seesaw.loops.multi_reg_module")
+    out = {}
+    i = 0
+    # (n, n_pos, n_conf, conf_overlap, l_norm, l_query, q_noise)
+    configs = [(60, 8, 6, 0, 100.0, 10.0, 0.8), (150, 20, 15, 3, 100.0, 1.0, 0.8), (100, 12, 0, 0, 100.0, 10.0, 3.0),
+               (40, 5, 8, 2, 10.0, 0.0, 0.8)]
+    for (n, n_pos, n_conf, overlap, l_norm, l_query, q_noise) in configs:
+        X, y, q = _labelled_set(900 + i, n, n_pos, q_noise=q_noise)
+        rng = np.random.default_rng(50 + i)
+        img = np.sort(rng.integers(0, max(2, n // 3), n))
+        yconf = np.zeros(n)
+        neg = np.flatnonzero(y == 0)
+        pos = np.flatnonzero(y == 1)
+        yconf[rng.choice(neg, size=n_conf - overlap, replace=False)] = 1.0
+        if overlap:
+            yconf[rng.choice(pos, size=overlap, replace=False)] = 1.0  # a vector overlapping boxes of both classes
+        ys = np.stack([y, yconf], axis=1).astype("float32")
+        matchdf = pd.DataFrame({"dbidx": img, "ys": y, "max_iou": y * 0.5})
+
+        def make():
+            torch.manual_seed(3000 + i)  # nn.Linear's start weights: the same for every shuffle seed of a case
+            return mrm.MultiRegModule(qvec=torch.from_numpy(q).float(), reg_norm_lambda=l_norm, reg_query_lambda=l_query,
+                                      verbose=False, max_iter=100, lr=1.0)
+
+        weights = []
+        for seed in FIT_SEEDS:
+            model = make()
+            w0 = model.weight.detach().clone().numpy()
+            traj = _Trajectory(model, model.linear.weight)
+            torch.manual_seed(seed)
+            losses = model.fit(X, ys, matchdf)
+            weights.append(model.weight.detach().clone().numpy())
+            if seed == FIT_SEEDS[0]:
+                first, first_traj, first_w0 = model, traj, w0
+        tw, tl, tg = first_traj.arrays()
+        out[f"c{i}_X"], out[f"c{i}_ys"], out[f"c{i}_q"], out[f"c{i}_img"] = X, ys, q, img
+        out[f"c{i}_l_norm"], out[f"c{i}_l_query"] = np.asarray(l_norm), np.asarray(l_query)
+        out[f"c{i}_w0"] = first_w0
+        out[f"c{i}_weight_seeds"] = np.stack(weights)
+        out[f"c{i}_coeff"] = first.get_coeff()
+        out[f"c{i}_traj_w"], out[f"c{i}_traj_loss"], out[f"c{i}_traj_grad"] = tw, tl, tg
+        m0 = make()
+        vw = 1.0 / pd.Series(img).map(pd.Series(img).value_counts()).values
+        Xc = X - X.mean(axis=0).reshape(1, -1)
+        ret = m0._step((torch.from_numpy(Xc), torch.from_numpy(ys), torch.from_numpy(vw)))
+        ret["loss"].backward()
+        out[f"c{i}_loss0"] = np.asarray(ret["loss"].item())
+        out[f"c{i}_grad0"] = m0.weight.grad.numpy().copy()
+        out[f"c{i}_parts0"] = np.array([ret[k].item() for k in ["loss_norm", "loss_queryreg", "loss_queryreg2", "vertical_loss",
+                                                                "horizontal_loss"]])
+        print("multiregneg case", i, "evals", tw.shape[0], "loss", tl[0], "->", tl[-1])
+        i += 1
+    out["n_cases"] = np.asarray(i)
+    out["fit_seeds"] = np.asarray(FIT_SEEDS)
+
+    # ---- whole sessions ------------------------------------------------------------------
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    sess = R.ref("seesaw.seesaw_session")
+    bench = R.ref("seesaw.seesaw_bench")
+    bt = R.ref("seesaw.basic_types")
+    mrn = R.ref("seesaw.loops.multi_reg_neg")
+    pr = sys.modules["pyroaring"]
+
+    class FakeDataset:
+        def __init__(self, d):
+            self.d = d
+            self.file_meta = d.file_meta
+            self.paths = d.paths
+
+        def load_ground_truth(self):
+            return self.d.load_ground_truth()
+
+        def get_urls(self, idxbatch):
+            return self.d.get_urls(idxbatch)
+
+    spec = BENCH_LOOP_DATASETS["A"]
+    ds = make_dataset("lvis", knn_k=0, **spec["make"])
+    ds.embedding.noise = spec["noise"]
+    boxes, _ = ds.load_ground_truth()
+    mrn.get_weight_matrix_from_index = lambda idx, options, xlx_matrix=False: np.zeros((512, 512), np.float32)  # unused by the module
+    bench.objnet_dict["c1"] = "c2"  # the synthetic dataset's confusion pair (the reference's table is ObjectNet's)
+    out["confusion"] = np.asarray(json.dumps({"c1": "c2"}))
+    matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    variants = {"multi_reg_neg": dict(discount_neg=True), "multi_reg_neg_nodiscount": dict(discount_neg=False)}
+    out["names"] = np.array(list(variants))
+    for name, extra in variants.items():
+        opts = dict(reg_norm_lambda=100.0, reg_query_lambda=10.0, reg_data_lambda=0.0, verbose=False, max_iter=100, lr=1.0,
+                    matrix_options=matrix, **extra)
+        for seed in BENCH_LOOP_SEEDS[:3]:
+            index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+            p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="multiscale", c_name=None),
+                                 interactive="multi_reg_neg", interactive_options=opts, shortlist_size=50,
+                                 agg_method="plain_score", aug_larger="greater", batch_size=1,
+                                 start_policy="after_first_batch", index_options={"use_vec_index": False})
+            b = bt.BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10,
+                               provide_textual_feedback=True)
+            np.random.seed(0)
+            torch.manual_seed(seed)
+            with contextlib.redirect_stdout(io.StringIO()):
+                session = sess.Session(None, FakeDataset(ds), index, p)
+                res = bench.benchmark_loop(session=session, subset=pr.BitMap(ds.file_meta.index.values), box_data=boxes,
+                                           b=b, p=p)
+            shown = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in session.acc_indices])
+            suffix = "" if seed == BENCH_LOOP_SEEDS[0] else f"_seed{seed}"
+            out[f"{name}_shown{suffix}"] = shown
+            out[f"{name}_nfound{suffix}"] = np.asarray(res["nfound"])
+            out[f"{name}_nseen{suffix}"] = np.asarray(res["nseen"])
+            print(name, seed, res["nfound"], res["nseen"], shown[:16])
+    out["session_seeds"] = np.asarray(BENCH_LOOP_SEEDS[:3])
+    save("multiregneg", **out)
+
+
+def gen_contweighted():
+    """(ii-b) MultiscaleIndex.query(agg_method='avg_score', aug_weight='cont_weighted') -- score_frame2's softmax-of-
+    containment branch (multiscale_index.py:133-145) on the 3-level tile pyramid of the multiscale_query family; per
+    aug_larger mode the returned images / activations, every candidate image's aggregated best score, and the
+    candidate tiles' scores as the reference formed them."""
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    pr = sys.modules["pyroaring"]
+    pseed, pn = 311, 300
+    prng = np.random.default_rng(pseed)
+    pmeta = synth_pyramid_meta(pn, np.arange(pn) * 3 + 1, prng)
+    PX = orc.synth_rows(pseed, 0, pmeta.shape[0], 512)
+    pq = orc.synth_query(pseed)
+    pindex = msi.MultiscaleIndex(embedding=None, vectors=PX, vector_meta=pmeta, vec_index=None)
+    out = {"pyr_seed": np.asarray(pseed), "pyr_n_images": np.asarray(pn),
+           "pyr_meta": pmeta[["dbidx", "zoom_level", "x1", "y1", "x2", "y2"]].values.astype(np.float64)}
+    orig_rescore, orig_frame = msi.rescore_candidates, msi.score_frame2
+    for aug in ["all", "greater", "adjacent"]:
+        seen = {"img": [], "score": []}
+
+        def recording(fullmeta, topk, _o=orig_rescore, **kw):
+            seen["rows"] = fullmeta.index.values.astype(np.int64).copy()
+            seen["scores"] = fullmeta.score.values.astype(np.float32).copy()
+            return _o(fullmeta, topk, **kw)
+
+        def frame(meta_df, _o=orig_frame, **kw):
+            tup = _o(meta_df, **kw)
+            seen["img"].append(int(meta_df.dbidx.iloc[0]))
+            seen["score"].append(float(tup.score.iloc[0]))
+            return tup
+
+        msi.rescore_candidates, msi.score_frame2 = recording, frame
+        try:
+            res = pindex.query(vector=pq, topk=10, shortlist_size=50, exclude=pr.BitMap(pmeta.dbidx.values[:40]),
+                               force_exact=True, agg_method="avg_score", aug_larger=aug, aug_weight="cont_weighted",
+                               rescore_method=None)
+        finally:
+            msi.rescore_candidates, msi.score_frame2 = orig_rescore, orig_frame
+        out[f"cw_{aug}_dbidxs"] = np.asarray(res["dbidxs"], dtype=np.int64)
+        out[f"cw_{aug}_activations"] = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64)
+                                                 for a in res["activations"]])
+        out[f"cw_{aug}_cand_rows"], out[f"cw_{aug}_cand_scores"] = seen["rows"], seen["scores"]
+        out[f"cw_{aug}_frame_dbidx"] = np.asarray(seen["img"], dtype=np.int64)
+        out[f"cw_{aug}_frame_score"] = np.asarray(seen["score"], dtype=np.float64)
+    save("contweighted", **out)
+
+
 FAMILIES = {"lknn": gen_lknn, "scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
-            "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop}
+            "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop,
+            "multiregneg": gen_multiregneg, "contweighted": gen_contweighted}
 
 def main(argv):
     """python oracle/gen_golden.py [--check] [family ...]

@@ -88,6 +88,9 @@ _SIGNATURES = {
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_knn_build": (c_i32, [c_void_p, c_i32, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),
+    "ssw_fb_set_targets2": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_fb_lossgrad2": (c_i32, [c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
+    "ssw_fb_fit2": (c_i32, [c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_i32, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_get_mean": (c_i32, [c_void_p, c_void_p]),
     "ssw_fb_lossgrad": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_scores": (c_i32, [c_void_p, c_void_p, c_i32, c_void_p]),

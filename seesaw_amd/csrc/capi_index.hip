@@ -387,7 +387,8 @@ ssw_status ssw_index_rescore_avg(ssw_index *idx, const int64_t *image_positions,
     SSW_REQUIRE(idx != nullptr, "idx is NULL");
     if (m <= 0) return SSW_OK;
     SSW_REQUIRE(image_positions && out_scores && out_best_rows, "NULL argument");
-    SSW_REQUIRE(aug_larger >= 0 && aug_larger <= 2, "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent)", aug_larger);
+    SSW_REQUIRE(aug_larger >= 0 && (aug_larger & 3) <= 2 && aug_larger <= 6,
+                "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent), optionally + 4 (aug_weight = cont_weighted)", aug_larger);
     SSW_REQUIRE(idx->has_map && idx->tile_boxes && idx->tile_zoom,
                 "rescore_avg needs ssw_index_set_row2image and ssw_index_set_tile_meta first");
     DeviceGuard guard(idx->device);
@@ -449,7 +450,8 @@ ssw_status ssw_index_rescore_avg_f64(ssw_index *idx, const double *dev_scores, c
     SSW_REQUIRE(idx != nullptr, "idx is NULL");
     if (m <= 0) return SSW_OK;
     SSW_REQUIRE(dev_scores && image_positions && out_scores && out_best_rows, "NULL argument");
-    SSW_REQUIRE(aug_larger >= 0 && aug_larger <= 2, "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent)", aug_larger);
+    SSW_REQUIRE(aug_larger >= 0 && (aug_larger & 3) <= 2 && aug_larger <= 6,
+                "aug_larger=%d is not 0 (all), 1 (greater) or 2 (adjacent), optionally + 4 (aug_weight = cont_weighted)", aug_larger);
     SSW_REQUIRE(idx->has_map && idx->tile_boxes && idx->tile_zoom,
                 "rescore_avg needs ssw_index_set_row2image and ssw_index_set_tile_meta first");
     DeviceGuard guard(idx->device);

@@ -276,6 +276,94 @@ __global__ void k_fb_grad(const float *__restrict__ X, const float *__restrict__
     partial[(int64_t)blockIdx.x * dim + c] = g;
 }
 
+// ---- two linear outputs: MultiRegModule (seesaw/loops/multi_reg_module.py:40-165), the scorer of the multi_reg_neg
+// loop.  Row i has logits z_ic = <x_i, W_c / |W_c|>, c = 0 (target) / 1 (confusion class), f32 targets y_ic and a
+// sample weight s_i.  loss_labels = sum_i s_i [ bce(z_i0, y_i0) + bce(z_i1, y_i1) ]          ("vertical")
+//                                 + sum_{i : y_i0 + y_i1 > 0} s_i * -(sum_c y_ic log_softmax(z_i)_c)  ("horizontal")
+// Everything is f32 in the reference (targets are cast with .astype('float32'), multi_reg_neg.py:73), so it is here.
+// z, y, r are stored as two planes of `plane` floats so the single-output gradient kernel serves both outputs.
+__global__ __launch_bounds__(256) void k_fb2_logits_elem(const float *__restrict__ X, const float *__restrict__ nw /* [2, dim] */,
+                                                         int64_t n, int dim, int64_t plane, const float *__restrict__ y2,
+                                                         const float *__restrict__ sw, float *__restrict__ z2,
+                                                         float *__restrict__ r2, float *__restrict__ item_v,
+                                                         float *__restrict__ item_h) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float4 *x4 = reinterpret_cast<const float4 *>(X + row * dim);
+    const float4 *w0 = reinterpret_cast<const float4 *>(nw), *w1 = reinterpret_cast<const float4 *>(nw + dim);
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < dim / 4; c += 64) {
+        const float4 xv = x4[c], p = w0[c], q = w1[c];
+        a = fmaf(xv.x, p.x, a); a = fmaf(xv.y, p.y, a); a = fmaf(xv.z, p.z, a); a = fmaf(xv.w, p.w, a);
+        b = fmaf(xv.x, q.x, b); b = fmaf(xv.y, q.y, b); b = fmaf(xv.z, q.z, b); b = fmaf(xv.w, q.w, b);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if (lane != 0) return;
+    const float y0 = y2[row], y1 = y2[plane + row], s = sw[row];
+    // binary_cross_entropy_with_logits: (1 - y) z - log_sigmoid(z), log_sigmoid(z) = min(z, 0) - log1p(exp(-|z|))
+    const float ls0 = fminf(a, 0.f) - log1pf(expf(-fabsf(a))), ls1 = fminf(b, 0.f) - log1pf(expf(-fabsf(b)));
+    const float vert = ((1.f - y0) * a - ls0) + ((1.f - y1) * b - ls1);
+    const float sg0 = 1.f / (1.f + expf(-a)), sg1 = 1.f / (1.f + expf(-b));
+    float g0 = sg0 - y0, g1 = sg1 - y1, hor = 0.f;
+    const float near = y0 + y1;
+    if (near > 0.f) {  // cross_entropy with probability targets on the rows that carry any label
+        const float m = fmaxf(a, b);
+        const float lse = m + logf(expf(a - m) + expf(b - m));
+        hor = -(y0 * (a - lse) + y1 * (b - lse));
+        g0 += near * expf(a - lse) - y0;
+        g1 += near * expf(b - lse) - y1;
+    }
+    z2[row] = a;
+    z2[plane + row] = b;
+    r2[row] = s * g0;
+    r2[plane + row] = s * g1;
+    item_v[row] = s * vert;
+    item_h[row] = s * hor;
+}
+
+// out[0] = sum item_v, out[1] = sum item_h, out[2 + c*dim + k] = sum over slabs of partial_c[slab][k]; then the flag
+__global__ __launch_bounds__(1024) void k_fb2_reduce(const float *__restrict__ partial /* [2][nslabs_cap][dim] */,
+                                                     int64_t partial_plane, int nslabs, const float *__restrict__ item_v,
+                                                     const float *__restrict__ item_h, int64_t n, int dim,
+                                                     float *__restrict__ out, unsigned *__restrict__ done_flag,
+                                                     unsigned seqno) {
+    __shared__ float rv[1024], rh[1024];
+    const int t = threadIdx.x;
+    if (t < 2 * dim) {
+        const float *pp = partial + (t / dim) * partial_plane + (t % dim);
+        float g = 0.f;
+        for (int s = 0; s < nslabs; ++s) g += pp[(int64_t)s * dim];
+        out[2 + t] = g;
+    }
+    float v = 0.f, h = 0.f;
+    for (int64_t i = t; i < n; i += 1024) {
+        v += item_v[i];
+        h += item_h[i];
+    }
+    rv[t] = v;
+    rh[t] = h;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (t < off) {
+            rv[t] += rv[t + off];
+            rh[t] += rh[t + off];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = rv[0];
+        out[1] = rh[0];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(done_flag, seqno, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct FbObjDev {
     int kind;          // 0 logreg, 1 multireg
     int has_bias;
@@ -1217,6 +1305,12 @@ struct ssw_fb {
     int64_t *rows = nullptr;   // gather staging
     float *partial = nullptr;  // [nslabs(cap), dim]
     float *rankg = nullptr;    // [cap] net position changes of the rank objective (SSW_FB_RANKREG)
+    // two-output objective (ssw_fb_*2): planes of cap floats / [2][nslabs(cap)][dim] partial gradients
+    float *y2 = nullptr, *sw2 = nullptr, *z2 = nullptr, *r2 = nullptr, *itemv = nullptr, *itemh = nullptr;
+    float *partial2 = nullptr, *nw2 = nullptr;
+    float *out2_host = nullptr, *out2_host_dev = nullptr;  // mapped pinned [2 + 2 dim]
+    int64_t cap2 = 0;
+    bool has_targets2 = false;
     double *colsum = nullptr;  // [cap / FB_CENTER_ROWS, dim] block sums of the centring step
     float *w = nullptr;        // [dim + 1]
     float *qhat = nullptr;     // [dim]
@@ -1232,6 +1326,7 @@ struct ssw_fb {
     hipStream_t stream = nullptr;
     // targets (host copies, for the objective set-up)
     std::vector<float> y_host, sw_host;
+    std::vector<float> qhat_host;  // the normalised query (host copy, for the two-output objective's host part)
     // diagnostics of the last fit
     int last_iters = 0, last_evals = 0;
     float rank_factor = 0.f;   // 1 / total_pairs of the installed targets (SSW_FB_RANKREG)
@@ -1467,6 +1562,121 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
     return SSW_OK;
 }
 
+// ---- two-output objective: device buffers, one closure evaluation ----------------------------
+static ssw_status fb2_reserve(ssw_fb *fb) {
+    if (fb->cap2 >= fb->cap && fb->cap2 > 0) return SSW_OK;
+    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    for (float **p : {&fb->y2, &fb->sw2, &fb->z2, &fb->r2, &fb->itemv, &fb->itemh, &fb->partial2}) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    fb->cap2 = 0;
+    const int64_t cap = fb->cap > 0 ? fb->cap : 256;
+    const int64_t nslabs = (cap + FB_SLAB - 1) / FB_SLAB;
+    SSW_HIP_TRY(hipMalloc((void **)&fb->y2, (size_t)2 * cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->sw2, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->z2, (size_t)2 * cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->r2, (size_t)2 * cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->itemv, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->itemh, (size_t)cap * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&fb->partial2, (size_t)2 * nslabs * fb->dim * sizeof(float)));
+    if (!fb->nw2) SSW_HIP_TRY(hipMalloc((void **)&fb->nw2, (size_t)2 * fb->dim * sizeof(float)));
+    if (!fb->out2_host) {
+        SSW_HIP_TRY(hipHostMalloc((void **)&fb->out2_host, (size_t)(2 + 2 * fb->dim) * sizeof(float), hipHostMallocMapped));
+        memset(fb->out2_host, 0, (size_t)(2 + 2 * fb->dim) * sizeof(float));
+        SSW_HIP_TRY(hipHostGetDevicePointer((void **)&fb->out2_host_dev, fb->out2_host, 0));
+    }
+    fb->cap2 = cap;
+    return SSW_OK;
+}
+
+// One evaluation of MultiRegModule._step (multi_reg_module.py:64-128) at the raw weights W = fb->w_host [2, dim]:
+// the data part (logits, per-row losses, X' r per output) on the device; the O(dim) part -- F.normalize and its
+// chain rule, the norm and query regularisers -- here, in f32 like the reference's tensors.
+// Results: fb->loss_host[0] = total loss, fb->out_host[1 .. 1 + 2 dim) = d loss / d W.  parts5 (optional):
+// loss_norm, loss_queryreg, loss_queryreg2, vertical, horizontal.
+static ssw_status fb_eval2(ssw_fb *fb, float l_norm, float l_query, float *parts5) {
+    hipStream_t s = fb->stream;
+    const int64_t n = fb->n;
+    const int dim = fb->dim;
+    const float *W = fb->w_host;
+    float nrm[2], nw[2][1024];
+    for (int c = 0; c < 2; ++c) {
+        float ss = 0.f;
+        for (int k = 0; k < dim; ++k) ss += W[c * dim + k] * W[c * dim + k];
+        nrm[c] = std::sqrt(ss);
+        const float den = std::fmax(nrm[c], 1e-12f);  // F.normalize's eps
+        for (int k = 0; k < dim; ++k) nw[c][k] = W[c * dim + k] / den;
+    }
+    float vsum = 0.f, hsum = 0.f;
+    const float *g = nullptr;  // [2, dim] d labels / d (normalised weights)
+    std::vector<float> gz;
+    if (n > 0) {
+        SSW_REQUIRE(fb->has_targets2 && fb->cap2 >= fb->cap, "feedback: ssw_fb_set_targets2 has not been called for these rows");
+        const int64_t plane = fb->cap2;
+        const int nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
+        const int64_t pplane = ((fb->cap2 + FB_SLAB - 1) / FB_SLAB) * dim;
+        SSW_HIP_TRY(hipMemcpyAsync(fb->nw2, &nw[0][0], (size_t)dim * sizeof(float), hipMemcpyHostToDevice, s));
+        SSW_HIP_TRY(hipMemcpyAsync(fb->nw2 + dim, &nw[1][0], (size_t)dim * sizeof(float), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_fb2_logits_elem, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->nw2, n, dim, plane,
+                           fb->y2, fb->sw2, fb->z2, fb->r2, fb->itemv, fb->itemh);
+        const int tx = dim < 256 ? dim : 256;
+        for (int c = 0; c < 2; ++c)
+            hipLaunchKernelGGL(k_fb_grad, dim3((unsigned)nslabs, (unsigned)((dim + tx - 1) / tx)), dim3(tx), 0, s, fb->X,
+                               fb->r2 + c * plane, n, dim, fb->partial2 + c * pplane);
+        hipLaunchKernelGGL(k_fb2_reduce, dim3(1), dim3(1024), 0, s, fb->partial2, pplane, nslabs, fb->itemv, fb->itemh, n,
+                           dim, fb->out2_host_dev, fb->flag_host_dev, ++fb->seqno);
+        SSW_HIP_TRY(hipGetLastError());
+        const unsigned want = fb->seqno;
+        bool seen = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            if (__atomic_load_n(fb->flag_host, __ATOMIC_ACQUIRE) == want) {
+                seen = true;
+                break;
+            }
+            if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        if (!seen) SSW_HIP_TRY(hipStreamSynchronize(s));
+        vsum = fb->out2_host[0];
+        hsum = fb->out2_host[1];
+        g = fb->out2_host + 2;
+    } else {
+        gz.assign((size_t)2 * dim, 0.f);
+        g = gz.data();
+    }
+    SSW_REQUIRE(fb->has_q, "feedback: the two-output objective needs ssw_fb_set_query first");
+    const std::vector<float> &qh = fb->qhat_host;
+    // regularisers (multi_reg_module.py:112-117), f32
+    float loss_norm = 0.f, lq[2];
+    float *grad = fb->out_host + 1;
+    for (int c = 0; c < 2; ++c) {
+        const float lg = std::log(nrm[c]);
+        loss_norm += std::cosh(lg) - 1.f;
+        float nq = 0.f;
+        for (int k = 0; k < dim; ++k) nq += nw[c][k] * qh[(size_t)k];
+        lq[c] = l_query * ((1.f - nq) / 2.f);
+        // G = d total / d nw_c ; d nw / d W = (I - nw nw') / |W|
+        float dotg = 0.f;
+        for (int k = 0; k < dim; ++k) dotg += nw[c][k] * (g[c * dim + k] - 0.5f * l_query * qh[(size_t)k]);
+        const float den = std::fmax(nrm[c], 1e-12f);
+        const float radial = l_norm * std::sinh(lg) / den;  // d [l_norm (cosh(log |W|) - 1)] / d|W|, times d|W|/dW = nw
+        for (int k = 0; k < dim; ++k) {
+            const float G = g[c * dim + k] - 0.5f * l_query * qh[(size_t)k];
+            grad[c * dim + k] = (G - nw[c][k] * dotg) / den + radial * nw[c][k];
+        }
+    }
+    loss_norm *= l_norm;
+    const float labels = vsum + hsum;
+    const float total = ((labels + loss_norm) + lq[0]) + lq[1];
+    fb->loss_host[0] = (double)total;
+    if (parts5) {
+        parts5[0] = loss_norm; parts5[1] = lq[0]; parts5[2] = lq[1]; parts5[3] = vsum; parts5[4] = hsum;
+    }
+    fb->last_evals++;
+    return SSW_OK;
+}
+
 static double g_fit_eval_s = 0;  // diagnostic (SSW_FB_TIMING): seconds of the last fit spent inside closure evaluations
 
 // ---- L-BFGS with strong-Wolfe line search ----------------------------------------------
@@ -1526,12 +1736,14 @@ struct Evaluator {
     float pw;
     bool pairwise_active;
     int P;
+    bool two = false;            // the two-output objective (fb_eval2) instead of fb_eval
+    float l_norm2 = 0.f, l_query2 = 0.f;
     ssw_status status = SSW_OK;
     // f(x + t d) and its gradient
     bool eval(const Vec &x, double t, const Vec &d, double *f, Vec *g) {
         for (int i = 0; i < P; ++i) fb->w_host[i] = x[i] + (float)t * d[i];
         const auto t0 = std::chrono::steady_clock::now();
-        status = fb_eval(fb, o, dev, pw, pairwise_active, P);
+        status = two ? fb_eval2(fb, l_norm2, l_query2, nullptr) : fb_eval(fb, o, dev, pw, pairwise_active, P);
         g_fit_eval_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (status != SSW_OK) return false;
         *f = fb->loss_host[0];
@@ -1638,6 +1850,95 @@ bool strong_wolfe(Evaluator &E, const Vec &x, double t, const Vec &d, double f, 
 
 }  // namespace
 
+// torch.optim.LBFGS.step(closure) driven from the host: x [E.P] in/out; `zero_slot` (or -1) is a parameter slot the
+// objective does not use (the bias of a fit without intercept) whose gradient is held at zero
+static ssw_status lbfgs_host(Evaluator &E, Vec &x, int zero_slot, int max_iter, float lr, int *n_iter_out,
+                             double *loss_out) {
+    const int history = 100;
+    const double tol_grad = 1e-7, tol_change = 1e-9;
+    const int max_eval = max_iter * 5 / 4;
+    Vec d(E.P, 0.f), g, prev_g, zero(E.P, 0.f);
+    double loss;
+    if (!E.eval(x, 0.0, zero, &loss, &g)) return E.status;
+    if (zero_slot >= 0) g[zero_slot] = 0.f;
+    int current_evals = 1, n_iter = 0;
+    double t = 0, prev_loss = loss, H_diag = 1.0;
+    std::vector<Vec> old_dirs, old_stps;
+    std::vector<double> ro;
+    bool opt_cond = vabsmax(g) <= tol_grad;
+    while (!opt_cond && n_iter < max_iter) {
+        n_iter++;
+        if (n_iter == 1) {
+            for (int i = 0; i < E.P; ++i) d[i] = -g[i];
+            H_diag = 1.0;
+        } else {
+            Vec yv(E.P), sv(E.P);
+            for (int i = 0; i < E.P; ++i) {
+                yv[i] = g[i] - prev_g[i];
+                sv[i] = d[i] * (float)t;
+            }
+            const double ys = vdot(yv, sv);
+            if (ys > 1e-10) {
+                if ((int)old_dirs.size() == history) {
+                    old_dirs.erase(old_dirs.begin());
+                    old_stps.erase(old_stps.begin());
+                    ro.erase(ro.begin());
+                }
+                old_dirs.push_back(yv);
+                old_stps.push_back(sv);
+                ro.push_back(1.0 / ys);
+                H_diag = ys / vdot(yv, yv);
+            }
+            const int m = (int)old_dirs.size();
+            std::vector<double> al((size_t)m);
+            Vec q(E.P);
+            for (int i = 0; i < E.P; ++i) q[i] = -g[i];
+            for (int i = m - 1; i >= 0; --i) {
+                al[(size_t)i] = vdot(old_stps[(size_t)i], q) * ro[(size_t)i];
+                for (int j = 0; j < E.P; ++j) q[j] -= (float)al[(size_t)i] * old_dirs[(size_t)i][j];
+            }
+            for (int j = 0; j < E.P; ++j) d[j] = q[j] * (float)H_diag;
+            for (int i = 0; i < m; ++i) {
+                const double be = vdot(old_dirs[(size_t)i], d) * ro[(size_t)i];
+                for (int j = 0; j < E.P; ++j) d[j] += (float)(al[(size_t)i] - be) * old_stps[(size_t)i][j];
+            }
+        }
+        prev_g = g;
+        prev_loss = loss;
+        if (n_iter == 1) {
+            double pa[1032];
+            for (size_t i = 0; i < g.size(); ++i) pa[i] = (double)std::fabs(g[i]);
+            const double gs = wave_sum_host(pa, g.size());
+            t = std::fmin(1.0, 1.0 / gs) * lr;
+        } else {
+            t = lr;
+        }
+        const double gtd = vdot(g, d);
+        if (gtd > -tol_change) break;
+        double f_new, t_new;
+        Vec g_new;
+        int ls_evals = 0;
+        if (!strong_wolfe(E, x, t, d, loss, g, gtd, &f_new, &g_new, &t_new, &ls_evals)) return E.status;
+        loss = f_new;
+        g = g_new;
+        if (zero_slot >= 0) g[zero_slot] = 0.f;
+        t = t_new;
+        for (int i = 0; i < E.P; ++i) x[i] += (float)t * d[i];
+        opt_cond = vabsmax(g) <= tol_grad;
+        current_evals += ls_evals;
+        if (n_iter == max_iter) break;
+        if (current_evals >= max_eval) break;
+        if (opt_cond) break;
+        double dm = 0;
+        for (int i = 0; i < E.P; ++i) dm = std::fmax(dm, std::fabs((double)d[i] * t));
+        if (dm <= tol_change) break;
+        if (std::fabs(loss - prev_loss) < tol_change) break;
+    }
+    *n_iter_out = n_iter;
+    *loss_out = loss;
+    return SSW_OK;
+}
+
 extern "C" {
 
 ssw_status ssw_fb_destroy(ssw_fb *fb) {
@@ -1654,6 +1955,8 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
     (void)hipFree(fb->rankg);
+    for (float *p2 : {fb->y2, fb->sw2, fb->z2, fb->r2, fb->itemv, fb->itemh, fb->partial2, fb->nw2}) (void)hipFree(p2);
+    if (fb->out2_host) (void)hipHostFree(fb->out2_host);
     (void)hipFree(fb->colsum);
     (void)hipFree(fb->w);
     (void)hipFree(fb->qhat);
@@ -1686,7 +1989,7 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
     if (!fb) return SSW_ERR_NOMEM;
     fb->device = device;
     fb->dim = dim;
-    const size_t outn = (size_t)(1 + dim + 1 + 4);
+    const size_t outn = (size_t)(1 + 2 * dim + 8);  // [loss, gradient (dim + 1, or 2 dim for the two-output objective), parts]
     if (hipStreamCreateWithFlags(&fb->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&fb->mu, (size_t)dim * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&fb->w, (size_t)(dim + 1) * sizeof(float)) != hipSuccess ||
@@ -1698,7 +2001,7 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->flag_host, 64, hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc((void **)&fb->w_host, (size_t)(dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&fb->w_host, (size_t)(2 * dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("feedback: allocation failed");
         ssw_fb_destroy(fb);
         return SSW_ERR_NOMEM;
@@ -1724,6 +2027,7 @@ ssw_status ssw_fb_set_data(ssw_fb *fb, const float *X_host, int64_t n, int32_t c
     DeviceGuard guard(fb->device);
     SSW_TRY(fb_reserve(fb, n));
     fb->n = n;
+    fb->has_targets2 = false;
     if (n > 0)
         SSW_HIP_TRY(hipMemcpyAsync(fb->X, X_host, (size_t)n * fb->dim * sizeof(float), hipMemcpyHostToDevice, fb->stream));
     SSW_TRY(fb_center(fb, center));
@@ -1740,6 +2044,7 @@ ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int6
     DeviceGuard guard(fb->device);
     SSW_TRY(fb_reserve(fb, n));
     fb->n = n;
+    fb->has_targets2 = false;
     if (n > 0) {
         SSW_HIP_TRY(hipMemcpyAsync(fb->rows, rows_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, fb->stream));
         hipLaunchKernelGGL(k_fb_gather_rows, dim3((unsigned)n), dim3(128), 0, fb->stream, dev_matrix, fb->rows, n,
@@ -1779,6 +2084,7 @@ ssw_status ssw_fb_set_query(ssw_fb *fb, const float *q_host) {
     std::vector<float> qh((size_t)fb->dim);
     for (int i = 0; i < fb->dim; ++i) qh[(size_t)i] = (float)(q_host[i] * inv);  // F.normalize
     SSW_HIP_TRY(hipMemcpy(fb->qhat, qh.data(), (size_t)fb->dim * sizeof(float), hipMemcpyHostToDevice));
+    fb->qhat_host = qh;
     fb->has_q = true;
     return SSW_OK;
 }
@@ -1924,90 +2230,14 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
         if (out_final_loss) *out_final_loss = (float)fb->loss_host[0];
         return SSW_OK;
     }
-    const int history = 100;
-    const double tol_grad = 1e-7, tol_change = 1e-9;
-    const int max_eval = max_iter * 5 / 4;
-    Vec x(E.P, 0.f), d(E.P, 0.f), g, prev_g, zero(E.P, 0.f);
+    Vec x(E.P, 0.f);
     for (int i = 0; i < P; ++i) {
         SSW_REQUIRE(std::isfinite(w_inout[i]), "initial weight %d is not finite", i);
         x[i] = w_inout[i];
     }
-    double loss;
-    if (!E.eval(x, 0.0, zero, &loss, &g)) return E.status;
-    if (P == fb->dim) g[fb->dim] = 0.f;
-    int current_evals = 1, n_iter = 0;
-    double t = 0, prev_loss = loss, H_diag = 1.0;
-    std::vector<Vec> old_dirs, old_stps;
-    std::vector<double> ro;
-    bool opt_cond = vabsmax(g) <= tol_grad;
-    while (!opt_cond && n_iter < max_iter) {
-        n_iter++;
-        if (n_iter == 1) {
-            for (int i = 0; i < E.P; ++i) d[i] = -g[i];
-            H_diag = 1.0;
-        } else {
-            Vec yv(E.P), sv(E.P);
-            for (int i = 0; i < E.P; ++i) {
-                yv[i] = g[i] - prev_g[i];
-                sv[i] = d[i] * (float)t;
-            }
-            const double ys = vdot(yv, sv);
-            if (ys > 1e-10) {
-                if ((int)old_dirs.size() == history) {
-                    old_dirs.erase(old_dirs.begin());
-                    old_stps.erase(old_stps.begin());
-                    ro.erase(ro.begin());
-                }
-                old_dirs.push_back(yv);
-                old_stps.push_back(sv);
-                ro.push_back(1.0 / ys);
-                H_diag = ys / vdot(yv, yv);
-            }
-            const int m = (int)old_dirs.size();
-            std::vector<double> al((size_t)m);
-            Vec q(E.P);
-            for (int i = 0; i < E.P; ++i) q[i] = -g[i];
-            for (int i = m - 1; i >= 0; --i) {
-                al[(size_t)i] = vdot(old_stps[(size_t)i], q) * ro[(size_t)i];
-                for (int j = 0; j < E.P; ++j) q[j] -= (float)al[(size_t)i] * old_dirs[(size_t)i][j];
-            }
-            for (int j = 0; j < E.P; ++j) d[j] = q[j] * (float)H_diag;
-            for (int i = 0; i < m; ++i) {
-                const double be = vdot(old_dirs[(size_t)i], d) * ro[(size_t)i];
-                for (int j = 0; j < E.P; ++j) d[j] += (float)(al[(size_t)i] - be) * old_stps[(size_t)i][j];
-            }
-        }
-        prev_g = g;
-        prev_loss = loss;
-        if (n_iter == 1) {
-            double pa[1032];
-            for (size_t i = 0; i < g.size(); ++i) pa[i] = (double)std::fabs(g[i]);
-            const double gs = wave_sum_host(pa, g.size());
-            t = std::fmin(1.0, 1.0 / gs) * lr;
-        } else {
-            t = lr;
-        }
-        const double gtd = vdot(g, d);
-        if (gtd > -tol_change) break;
-        double f_new, t_new;
-        Vec g_new;
-        int ls_evals = 0;
-        if (!strong_wolfe(E, x, t, d, loss, g, gtd, &f_new, &g_new, &t_new, &ls_evals)) return E.status;
-        loss = f_new;
-        g = g_new;
-        if (P == fb->dim) g[fb->dim] = 0.f;
-        t = t_new;
-        for (int i = 0; i < E.P; ++i) x[i] += (float)t * d[i];
-        opt_cond = vabsmax(g) <= tol_grad;
-        current_evals += ls_evals;
-        if (n_iter == max_iter) break;
-        if (current_evals >= max_eval) break;
-        if (opt_cond) break;
-        double dm = 0;
-        for (int i = 0; i < E.P; ++i) dm = std::fmax(dm, std::fabs((double)d[i] * t));
-        if (dm <= tol_change) break;
-        if (std::fabs(loss - prev_loss) < tol_change) break;
-    }
+    int n_iter = 0;
+    double loss = 0;
+    SSW_TRY(lbfgs_host(E, x, P == fb->dim ? fb->dim : -1, max_iter, lr, &n_iter, &loss));
     for (int i = 0; i < P; ++i) {
         if (!std::isfinite(x[i])) {
             set_error("feedback: weights diverged");
@@ -2027,12 +2257,90 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
     return SSW_OK;
 }
 
+// ---- MultiRegModule (multi_reg_neg loop): two-output objective -------------------------------
+ssw_status ssw_fb_set_targets2(ssw_fb *fb, const float *y2_host, const float *sample_weight_or_null) {
+    SSW_REQUIRE(fb != nullptr && (fb->n == 0 || y2_host != nullptr), "bad argument");
+    DeviceGuard guard(fb->device);
+    SSW_REQUIRE(2 * fb->dim <= 1024, "feedback: the two-output objective takes dim <= 512, got %d", fb->dim);
+    SSW_TRY(fb2_reserve(fb));
+    const int64_t n = fb->n, plane = fb->cap2;
+    std::vector<float> buf((size_t)3 * n);
+    for (int64_t i = 0; i < n; ++i) {
+        SSW_REQUIRE(std::isfinite(y2_host[2 * i]) && std::isfinite(y2_host[2 * i + 1]), "target %lld is not finite", (long long)i);
+        buf[(size_t)i] = y2_host[2 * i];
+        buf[(size_t)(n + i)] = y2_host[2 * i + 1];
+        buf[(size_t)(2 * n + i)] = sample_weight_or_null ? sample_weight_or_null[i] : 1.f;
+        SSW_REQUIRE(std::isfinite(buf[(size_t)(2 * n + i)]), "sample weight %lld is not finite", (long long)i);
+    }
+    if (n > 0) {
+        SSW_HIP_TRY(hipMemcpyAsync(fb->y2, buf.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+        SSW_HIP_TRY(hipMemcpyAsync(fb->y2 + plane, buf.data() + n, (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+        SSW_HIP_TRY(hipMemcpyAsync(fb->sw2, buf.data() + 2 * n, (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+        SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    }
+    fb->has_targets2 = true;
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_lossgrad2(ssw_fb *fb, const float *W_host, float reg_norm_lambda, float reg_query_lambda,
+                            float *out_loss, float *out_grad, float *out_parts5_or_null) {
+    SSW_REQUIRE(fb && W_host && out_loss && out_grad, "NULL argument");
+    DeviceGuard guard(fb->device);
+    SSW_REQUIRE(2 * fb->dim <= 1024, "feedback: the two-output objective takes dim <= 512, got %d", fb->dim);
+    memcpy(fb->w_host, W_host, (size_t)2 * fb->dim * sizeof(float));
+    SSW_TRY(fb_eval2(fb, reg_norm_lambda, reg_query_lambda, out_parts5_or_null));
+    *out_loss = (float)fb->loss_host[0];
+    memcpy(out_grad, fb->out_host + 1, (size_t)2 * fb->dim * sizeof(float));
+    return SSW_OK;
+}
+
+ssw_status ssw_fb_fit2(ssw_fb *fb, float *W_inout, float reg_norm_lambda, float reg_query_lambda, int32_t max_iter,
+                       float lr, int32_t *out_iters, int32_t *out_evals, float *out_final_loss) {
+    SSW_REQUIRE(fb && W_inout, "NULL argument");
+    SSW_REQUIRE(max_iter >= 1, "max_iter < 1");
+    DeviceGuard guard(fb->device);
+    SSW_REQUIRE(2 * fb->dim <= 1024, "feedback: the two-output objective takes dim <= 512, got %d", fb->dim);
+    Evaluator E;
+    E.fb = fb;
+    E.o = nullptr;
+    E.P = 2 * fb->dim;
+    E.two = true;
+    E.l_norm2 = reg_norm_lambda;
+    E.l_query2 = reg_query_lambda;
+    E.pw = 1.f;
+    E.pairwise_active = false;
+    memset(&E.dev, 0, sizeof(E.dev));
+    fb->last_evals = 0;
+    fb->last_fit_on_device = false;
+    Vec x((size_t)E.P);
+    for (int i = 0; i < E.P; ++i) {
+        SSW_REQUIRE(std::isfinite(W_inout[i]), "initial weight %d is not finite", i);
+        x[(size_t)i] = W_inout[i];
+    }
+    int n_iter = 0;
+    double loss = 0;
+    SSW_TRY(lbfgs_host(E, x, -1, max_iter, lr, &n_iter, &loss));
+    for (int i = 0; i < E.P; ++i) {
+        if (!std::isfinite(x[(size_t)i])) {
+            set_error("feedback: weights diverged");
+            return SSW_ERR_NUMERIC;
+        }
+        W_inout[i] = x[(size_t)i];
+    }
+    fb->last_iters = n_iter;
+    if (out_iters) *out_iters = n_iter;
+    if (out_evals) *out_evals = fb->last_evals;
+    if (out_final_loss) *out_final_loss = (float)loss;
+    return SSW_OK;
+}
+
 ssw_status ssw_fb_reset(ssw_fb *fb) {
     SSW_REQUIRE(fb != nullptr, "NULL argument");
     DeviceGuard guard(fb->device);
     SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
     fb->n = 0;
     fb->has_q = fb->has_xlx = false;
+    fb->has_targets2 = false;
     fb->y_host.clear();
     fb->sw_host.clear();
     fb->last_iters = fb->last_evals = 0;

@@ -18,6 +18,8 @@
 //   IoU in f32 exactly as torchvision's _box_inter_union forms it on float32 boxes
 //     (area = (x2-x1)*(y2-y1); wh = max(min(rb) - max(lt), 0); inter = w*h; union = (a_i + a_j) - inter),
 //   the mean as pandas' float32 group_mean: Kahan-compensated f32 sum in ascending zoom level, f32 division.
+// aug_weight = 'cont_weighted' (bit 2 of `aug`): softmax-of-containment weights over all partners instead (f32 like
+// scipy.special.softmax on float32 input; the weighted sum runs in partner order, numpy's dot in BLAS order: 1e-6).
 // Explicitly rounded intrinsics keep the compiler from contracting w*h into the union's subtraction.
 #include "ssw_common.h"
 
@@ -79,7 +81,53 @@ __global__ __launch_bounds__(RS_THREADS) void k_avg_score(const float4 *__restri
     }
     __syncthreads();
     const unsigned levels = level_mask;
-    for (int i = threadIdx.x; i < T; i += RS_THREADS) {
+    const bool cont_weighted = (aug & 4) != 0;
+    aug &= 3;
+    for (int i = threadIdx.x; i < T && cont_weighted; i += RS_THREADS) {
+        // aug_weight = 'cont_weighted' (multiscale_index.py:133-145): over ALL joined partners j (IoU > 0, level
+        // filter), weights = softmax(containment_ij), containment = inter / area_i (box_utils.py:347-349, f32);
+        // score_i = weights . score_j.  scipy.special.softmax: exp(x - max) / sum(exp(x - max)), f32 on f32 input.
+        const float4 bi = sbox[i];
+        const float ai = sarea[i];
+        const int zi = szoom[i];
+        float cmax = -1.f;
+        for (int j = 0; j < T; ++j) {
+            const int z = szoom[j];
+            if ((aug == 1 && z < zi) || (aug == 2 && z != zi)) continue;
+            const float4 bj = sbox[j];
+            const float w = fmaxf(__fsub_rn(fminf(bi.z, bj.z), fmaxf(bi.x, bj.x)), 0.f);
+            const float h = fmaxf(__fsub_rn(fminf(bi.w, bj.w), fmaxf(bi.y, bj.y)), 0.f);
+            const float inter = __fmul_rn(w, h);
+            const float v = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, sarea[j]), inter));
+            if (!(v > 0.f)) continue;
+            cmax = fmaxf(cmax, __fdiv_rn(inter, ai));
+        }
+        if (cmax < 0.f) {  // no partner at all (not even itself: a degenerate box)
+            sagg[i] = (ST)__builtin_nanf("");
+            continue;
+        }
+        float esum = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
+            ST acc = 0;
+            for (int j = 0; j < T; ++j) {
+                const int z = szoom[j];
+                if ((aug == 1 && z < zi) || (aug == 2 && z != zi)) continue;
+                const float4 bj = sbox[j];
+                const float w = fmaxf(__fsub_rn(fminf(bi.z, bj.z), fmaxf(bi.x, bj.x)), 0.f);
+                const float h = fmaxf(__fsub_rn(fminf(bi.w, bj.w), fmaxf(bi.y, bj.y)), 0.f);
+                const float inter = __fmul_rn(w, h);
+                const float v = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, sarea[j]), inter));
+                if (!(v > 0.f)) continue;
+                const float e = expf(__fsub_rn(__fdiv_rn(inter, ai), cmax));
+                if (pass == 0)
+                    esum = __fadd_rn(esum, e);
+                else
+                    acc = acc + (ST)__fdiv_rn(e, esum) * sscore[j];
+            }
+            if (pass == 1) sagg[i] = acc;
+        }
+    }
+    for (int i = threadIdx.x; i < T && !cont_weighted; i += RS_THREADS) {
         const float4 bi = sbox[i];
         const float ai = sarea[i];
         const int zi = szoom[i];

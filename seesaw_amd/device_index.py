@@ -169,7 +169,8 @@ class DeviceIndex:
         assert b.shape == (self.n_rows, 4) and z.shape == (self.n_rows,)
         _lib.call("ssw_index_set_tile_meta", self._h, _ptr(b), _ptr(z))
 
-    def rescore_avg(self, image_positions: np.ndarray, aug_larger: str, minus_scores: Optional[np.ndarray] = None):
+    def rescore_avg(self, image_positions: np.ndarray, aug_larger: str, minus_scores: Optional[np.ndarray] = None,
+                    aug_weight: str = "level_max"):
         """score_frame2's `avg_score` for the given candidate images over the resident tile scores:
         -> (aggregated score of the image's best tile f32 [m], that tile's row int64 [m])"""
         pos = np.ascontiguousarray(image_positions, dtype=np.int64)
@@ -177,19 +178,21 @@ class DeviceIndex:
         minus = None if minus_scores is None else np.ascontiguousarray(minus_scores, dtype=np.float32)
         scores = np.empty(m, dtype=np.float32)
         rows = np.empty(m, dtype=np.int64)
-        _lib.call("ssw_index_rescore_avg", self._h, _ptr(pos), m, self.AUG_LARGER[aug_larger], _ptr(minus),
-                  _ptr(scores), _ptr(rows))
+        aug = self.AUG_LARGER[aug_larger] | {"level_max": 0, "cont_weighted": 4}[aug_weight]
+        _lib.call("ssw_index_rescore_avg", self._h, _ptr(pos), m, aug, _ptr(minus), _ptr(scores), _ptr(rows))
         return scores, rows
 
-    def rescore_avg_f64(self, dev_scores_ptr: int, image_positions: np.ndarray, aug_larger: str):
+    def rescore_avg_f64(self, dev_scores_ptr: int, image_positions: np.ndarray, aug_larger: str,
+                        aug_weight: str = "level_max"):
         """rescore_avg over float64 tile scores resident on the device (one per index row, e.g. the label-propagation
         output): -> (aggregated score f64 [m], best tile's row int64 [m])"""
         pos = np.ascontiguousarray(image_positions, dtype=np.int64)
         m = pos.shape[0]
         scores = np.empty(m, dtype=np.float64)
         rows = np.empty(m, dtype=np.int64)
-        _lib.call("ssw_index_rescore_avg_f64", self._h, ctypes.c_void_p(int(dev_scores_ptr)), _ptr(pos), m,
-                  self.AUG_LARGER[aug_larger], _ptr(scores), _ptr(rows))
+        aug = self.AUG_LARGER[aug_larger] | {"level_max": 0, "cont_weighted": 4}[aug_weight]
+        _lib.call("ssw_index_rescore_avg_f64", self._h, ctypes.c_void_p(int(dev_scores_ptr)), _ptr(pos), m, aug,
+                  _ptr(scores), _ptr(rows))
         return scores, rows
 
     # -- device-resident forms (bench / sharded index) --------------------------------

@@ -128,3 +128,31 @@ class FeedbackEngine:
         _lib.call("ssw_fb_last_fit_on_device", self._h, ctypes.byref(on_dev))
         return w, {"n_iter": iters.value, "func_evals": evals.value, "loss": float(loss.value),
                    "on_device": bool(on_dev.value)}
+
+    # ---- two linear outputs (MultiRegModule, loops/multi_reg_neg.py) ---------------------
+    def set_targets2(self, y2: np.ndarray, sample_weight: Optional[np.ndarray] = None):
+        y2 = np.ascontiguousarray(np.asarray(y2), dtype=np.float32)
+        assert y2.shape == (self.n, 2)
+        sw = None
+        if sample_weight is not None:
+            sw = np.ascontiguousarray(np.asarray(sample_weight).reshape(-1), dtype=np.float32)
+            assert sw.shape[0] == self.n
+        _lib.call("ssw_fb_set_targets2", self._h, _p(y2), _p(sw))
+
+    def lossgrad2(self, W: np.ndarray, reg_norm_lambda: float, reg_query_lambda: float):
+        W = np.ascontiguousarray(np.asarray(W), dtype=np.float32)
+        assert W.shape == (2, self.dim)
+        loss = ctypes.c_float(0)
+        grad = np.empty((2, self.dim), dtype=np.float32)
+        parts = np.empty(5, dtype=np.float32)
+        _lib.call("ssw_fb_lossgrad2", self._h, _p(W), float(reg_norm_lambda), float(reg_query_lambda),
+                  ctypes.byref(loss), _p(grad), _p(parts))
+        return float(loss.value), grad, parts
+
+    def fit2(self, W0: np.ndarray, reg_norm_lambda: float, reg_query_lambda: float, max_iter: int, lr: float = 1.0):
+        W = np.array(np.asarray(W0), dtype=np.float32)
+        assert W.shape == (2, self.dim)
+        iters, evals, loss = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(0)
+        _lib.call("ssw_fb_fit2", self._h, _p(W), float(reg_norm_lambda), float(reg_query_lambda), int(max_iter), float(lr),
+                  ctypes.byref(iters), ctypes.byref(evals), ctypes.byref(loss))
+        return W, {"n_iter": iters.value, "func_evals": evals.value, "loss": float(loss.value), "on_device": False}

@@ -19,7 +19,7 @@ import numpy as np
 import pandas as pd
 
 from ...bitmap import BitMap, FrozenBitMap
-from ...box_utils import box_join, left_iou_join
+from ...box_utils import box_iou, left_iou_join
 from ...device_index import DeviceIndex
 from ...labeldb import LabelDB
 from ...query_interface import AccessMethod, InteractiveQuery
@@ -50,24 +50,57 @@ def match_labels_to_vectors(label_db: LabelDB, vec_meta: pd.DataFrame, target_de
     return out.assign(ys=(out.max_iou > 0).astype("float"))
 
 
+def _kahan_mean_rows(vals: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """per row: mean of vals where mask, summed column by column with a Kahan-compensated sum in vals' dtype --
+    pandas' group_mean, which is what the reference's `.groupby('iloc_left').score_right.mean()` runs"""
+    dt = vals.dtype
+    total = np.zeros(vals.shape[0], dtype=dt)
+    comp = np.zeros(vals.shape[0], dtype=dt)
+    count = mask.sum(axis=1)
+    for col in range(vals.shape[1]):
+        m = mask[:, col]
+        y = np.where(m, vals[:, col] - comp, dt.type(0))
+        t = total + y
+        comp = np.where(m, (t - total) - y, comp)
+        total = np.where(m, t, total)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.where(count > 0, total / count.astype(dt), dt.type(np.nan))
+
+
 def _avg_score_per_tile(meta_df: pd.DataFrame, aug_larger: str, aug_weight: str = "level_max"):
-    """`avg_score` aggregation of one image's tiles (multiscale_index.py:112-150): every tile's
-    score becomes the mean, over zoom levels, of the score of the best-overlapping tile."""
-    from scipy.special import softmax
-    mdf = meta_df[["x1", "x2", "y1", "y2", "zoom_level", "score"]]
-    joined = box_join(mdf, mdf)
+    """Host form of the `avg_score` aggregation for the tiles of ONE image, as [T, T] matrices (the product path is the
+    device kernel, csrc/rescore.hip; this serves indexes whose tile geometry is not float32 / zoom level > 31).
+    Semantics of score_frame2 (multiscale_index.py:112-150): tile i is joined with every tile j of IoU > 0 whose zoom
+    level passes `aug_larger`; 'level_max': mean over the partner levels of the score of the first best-overlapping
+    partner of that level; 'cont_weighted': softmax(containment) weights over all partners."""
+    iou, cont = box_iou(meta_df, meta_df, return_containment=True)
+    zoom = meta_df.zoom_level.to_numpy()
+    score = meta_df.score.to_numpy()
+    joined = iou > 0
     if aug_larger == "greater":
-        joined = joined[joined.zoom_level_right >= joined.zoom_level_left]
+        joined &= zoom[None, :] >= zoom[:, None]
     elif aug_larger == "adjacent":
-        joined = joined[joined.zoom_level_right == joined.zoom_level_left]
+        joined &= zoom[None, :] == zoom[:, None]
     else:
         assert aug_larger == "all", aug_larger
-    joined = joined.reset_index(drop=True)
-    if aug_weight == "level_max":
-        best = joined.groupby(["iloc_left", "zoom_level_right"]).iou.idxmax()
-        return joined.iloc[best.values].groupby("iloc_left").score_right.mean()
-    assert aug_weight == "cont_weighted", aug_weight
-    return joined.groupby("iloc_left").apply(lambda g: softmax(g.cont.values) @ g.score_right.values)
+    T = zoom.shape[0]
+    if aug_weight == "cont_weighted":
+        from scipy.special import softmax
+        out = np.full(T, np.nan, dtype=score.dtype)
+        for i in np.flatnonzero(joined.any(axis=1)):
+            out[i] = softmax(cont[i, joined[i]]) @ score[joined[i]]
+        return pd.Series(out)
+    assert aug_weight == "level_max", aug_weight
+    levels = np.unique(zoom)  # ascending: the order pandas sums the groups in
+    picked = np.zeros((T, levels.shape[0]), dtype=score.dtype)
+    has = np.zeros((T, levels.shape[0]), dtype=bool)
+    for k, z in enumerate(levels):
+        cols = np.flatnonzero(zoom == z)
+        sub = np.where(joined[:, cols], iou[:, cols], -1.0)
+        best = sub.argmax(axis=1)  # first maximum, as idxmax
+        has[:, k] = sub[np.arange(T), best] > 0
+        picked[:, k] = score[cols[best]]
+    return pd.Series(_kahan_mean_rows(picked, has))
 
 
 def score_frame2(meta_df: pd.DataFrame, **aug_options):
@@ -280,10 +313,11 @@ class MultiscaleIndex(AccessMethod):
             # would produce -- so the stage-2 gather is not needed
             return self._activations_from_best(candidate_df, topk)
         agg_method = kwargs.get("agg_method")
-        if agg_method != "plain_score" and kwargs.get("aug_weight", "level_max") == "level_max" and self._has_tile_meta:
+        if agg_method != "plain_score" and self._has_tile_meta:
             # score_frame2 takes every agg_method other than plain_score down its averaging branch
             # (multiscale_index.py:112-150: 'avg_vector' included): ssw_index_rescore_avg over the resident scores
-            return self._rescore_avg_on_device(candidate_df, topk, kwargs["aug_larger"], vector2)
+            return self._rescore_avg_on_device(candidate_df, topk, kwargs["aug_larger"], vector2,
+                                               aug_weight=kwargs.get("aug_weight", "level_max"))
         ilocs = self._candidate_rows(candidate_df.attrs["positions"])
         scores = self._dev.gather_scores(ilocs)  # tile scores of the scan that just ran
         if vector2 is not None:
@@ -291,7 +325,7 @@ class MultiscaleIndex(AccessMethod):
         fullmeta = self.vector_meta.iloc[ilocs].assign(score=scores)
         return rescore_candidates(fullmeta, topk, **kwargs)
 
-    def _rescore_avg_on_device(self, candidate_df, topk, aug_larger, vector2=None):
+    def _rescore_avg_on_device(self, candidate_df, topk, aug_larger, vector2=None, aug_weight="level_max"):
         """rescore_candidates for the averaging aggregation (multiscale_index.py:379-403): frames in ascending
         dbidx order, per frame the first tile with the highest aggregated score, then the topk frames by
         np.argsort(-score) -- the per-frame work runs in one kernel launch instead of a pandas loop"""
@@ -299,7 +333,8 @@ class MultiscaleIndex(AccessMethod):
         minus = None
         if vector2 is not None:
             minus = self._dev.score_rows(vector2, self._candidate_rows(positions))
-        scores, rows = self._dev.rescore_avg(positions, aug_larger, minus)
+        assert aug_weight in ("level_max", "cont_weighted"), aug_weight  # score_frame2's `assert False`
+        scores, rows = self._dev.rescore_avg(positions, aug_larger, minus, aug_weight=aug_weight)
         top = np.argsort(-scores.astype(np.float64))[:topk]
         return {"dbidxs": self._dbidx[positions[top]].astype("int"),
                 "activations": ActivationFrames(self._box[rows[top]], self._row_dbidx[rows[top]], scores[top])}

@@ -1,5 +1,4 @@
-"""name -> loop class (seesaw/loops/registry.py:7-37).  `multi_reg_neg` of the reference is outside the
-accelerated hot path and is not registered."""
+"""name -> loop class (seesaw/loops/registry.py:7-37)."""
 
 
 def build_loop_from_params(gdm, q, params):
@@ -7,6 +6,7 @@ def build_loop_from_params(gdm, q, params):
     from .graph_based import KnnProp2
     from .log_reg import LogReg2
     from .multi_reg import MultiReg
+    from .multi_reg_neg import MultiRegNeg
     from .point_based import Plain
     from .pseudo_lr import PseudoLR
     from .random_results import RandomResults
@@ -18,6 +18,7 @@ def build_loop_from_params(gdm, q, params):
         "log_reg2": LogReg2,
         "pseudo_lr": PseudoLR,
         "multi_reg": MultiReg,
+        "multi_reg_neg": MultiRegNeg,
         "rocchio_update": RocchioUpdate,
         "random": RandomResults,
         "active_search": ActiveSearch,

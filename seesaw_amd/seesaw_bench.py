@@ -37,6 +37,12 @@ def category2query(dataset_name: str, cat: str) -> str:
     return cat
 
 
+# ground-truth category -> the class a user would say the results are being confused with (what
+# `provide_textual_feedback` annotates as rejected boxes).  The reference hard-codes a table for ObjectNet
+# (seesaw_bench.py:170-235, `objnet_dict`); it is dataset knowledge, not code: register the pairs of your dataset here.
+objnet_dict: dict = {}
+
+
 def _group_boxes(box_data: pd.DataFrame) -> dict:
     """dbidx -> (category array, list of box records): fill_imdata's per-image filter, done once"""
     cols = ["x1", "x2", "y1", "y2", "description"]
@@ -64,14 +70,20 @@ def fill_imdata(imdata: Imdata, box_data: pd.DataFrame, b: BenchParams, _groups:
         hit = _groups.get(int(imdata.dbidx))
         if hit is not None:
             cats, recs = hit
-            sel = [r for c, r in zip(cats, recs) if c == b.ground_truth_category]
+            sel = [(r, True) for c, r in zip(cats, recs) if c == b.ground_truth_category]
+            if b.provide_textual_feedback:  # the confusion class's boxes, marked as rejected (seesaw_bench.py:246-258)
+                confusion_class = objnet_dict[b.ground_truth_category]
+                sel += [(r, False) for c, r in zip(cats, recs) if c == confusion_class]
             keep = np.random.rand(len(sel)) >= b.box_drop_prob
-            boxes = [Box(marked_accepted=True, **r) for r, k in zip(sel, keep) if k]
+            boxes = [Box(marked_accepted=acc, **r) for (r, acc), k in zip(sel, keep) if k]
         imdata.boxes = boxes
         return imdata
     rows = box_data[box_data.dbidx.values == imdata.dbidx]
     if rows.shape[0] > 0:
         feedback = rows[rows.category == b.ground_truth_category].assign(marked_accepted=True)
+        if b.provide_textual_feedback:
+            negatives = rows[rows.category == objnet_dict[b.ground_truth_category]].assign(marked_accepted=False)
+            feedback = pd.concat([feedback, negatives], axis=0, ignore_index=True)
         feedback = feedback[["x1", "x2", "y1", "y2", "description", "marked_accepted"]]
         keep = np.random.rand(feedback.shape[0]) >= b.box_drop_prob
         boxes = [Box(**r) for r in feedback[keep].to_dict(orient="records")]
@@ -83,11 +95,13 @@ def benchmark_loop(*, session: Session, subset: FrozenBitMap, box_data: pd.DataF
                    p: SessionParams):
     box_data = box_data.assign(description=box_data.category.map(
         lambda cat: b.query_template.format(category2query(p.index_spec.d_name, cat))))
+    all_box_data = box_data
     box_data = box_data[box_data.category == b.ground_truth_category]
     positives = FrozenBitMap(box_data.dbidx.values)
     assert positives.intersection(subset) == positives, "index mismatch"
     max_results = len(positives) if b.max_results is None else min(len(positives), b.max_results)
-    groups = _group_boxes(box_data)
+    # textual feedback looks at every category's boxes of an image (seesaw_bench.py:327-330)
+    groups = _group_boxes(all_box_data if b.provide_textual_feedback else box_data)
     total_results = total_seen = 0
     seen_dbidxs = BitMap()
     session.set_text(b.qstr)

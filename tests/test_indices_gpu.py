@@ -141,6 +141,28 @@ def test_avg_score_query_matches_reference(oracle, aug):
     assert res["activations"][0].score.dtype == np.float32
 
 
+@pytest.mark.parametrize("aug", ["all", "greater", "adjacent"])
+def test_cont_weighted_query_matches_reference(oracle, aug):
+    """aug_weight='cont_weighted' on the device (k_avg_score's softmax-of-containment branch): the reference's images
+    and activation boxes, scores to 2e-6 (f32 softmax + dot in partner order against scipy / BLAS); every candidate
+    image's aggregated score against what the reference's score_frame2 returned for it"""
+    from seesaw_amd.bitmap import BitMap
+    g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
+    gc = np.load(os.path.join(GOLDEN, "contweighted.npz"))
+    index, meta, X, q = _pyramid_index(g, oracle)
+    res = index.query(vector=q, topk=10, shortlist_size=50, exclude=BitMap(meta.dbidx.values[:40]), force_exact=True,
+                      agg_method="avg_score", aug_larger=aug, aug_weight="cont_weighted", rescore_method=None)
+    ref = gc[f"cw_{aug}_activations"]
+    assert np.array_equal(res["dbidxs"], gc[f"cw_{aug}_dbidxs"])
+    acts = np.stack([a[["x1", "y1", "x2", "y2", "dbidx", "score"]].values[0].astype(np.float64) for a in res["activations"]])
+    assert np.array_equal(acts[:, :5], ref[:, :5])
+    assert np.abs(acts[:, 5] - ref[:, 5]).max() <= 2e-6
+    pos = np.searchsorted(index._dbidx, gc[f"cw_{aug}_frame_dbidx"])
+    index._dev.scores(q)
+    scores, _ = index._dev.rescore_avg(pos, aug, aug_weight="cont_weighted")
+    assert np.abs(scores.astype(np.float64) - gc[f"cw_{aug}_frame_score"]).max() <= 2e-6
+
+
 def test_avg_score_vector2_matches_reference(oracle):
     from seesaw_amd.bitmap import BitMap
     g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
