@@ -417,8 +417,16 @@ ssw_status ssw_clip_sync(ssw_clip *clip);
 ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
                           float *out_ms, float *out_maxdiff);
 /* Selects the GEMM variant the towers use (0 register-staged, 2 LDS-DMA ring with 4 waves per tile,
- * 14 the same with 8 waves per tile [default], 7 256-row pipelined). */
+ * 14 the same with 8 waves per tile, 7 256-row pipelined, 9 the 8-wave 256 x 256 tile, 20-23 the persistent
+ * four-wave kernel of csrc/gemm_pw4.hip with its column tile chosen / 256 / 192 / 128). */
 ssw_status ssw_tune_gemm(int32_t variant);
+/* Diagnostics of csrc/gemm_pw4.hip for tools/perf_gemm.py: mode 0 the kernel, 1 cycle stamps (out6 = cycles in the
+ * mid-step wait + barrier, cycles in K-steps, K-steps, waves, s_memtime and s_memrealtime ticks per kernel; read and reset), 2-4 ablations (no LDS-DMA / no MFMA /
+ * no fragment reads inside the loop: wrong results, timing only). */
+ssw_status ssw_debug_gemm_pw4_mode(int32_t mode, uint64_t *out6_or_null);
+/* mode 1's per-workgroup record of the last launch: [1024][4] = start, end (100-MHz ticks), HW_ID, XCC_ID; then mode 5's
+ * [20] = cycles per interleave group (16), wait + barrier, sub-stages (summed over waves; read and reset) */
+ssw_status ssw_debug_gemm_pw4_wg(uint64_t *out4116);
 
 #ifdef __cplusplus
 }

@@ -663,6 +663,12 @@ ssw_status launch_gemm_bf16_nt(int epi, hipStream_t s, const void *A_, const voi
         set_error("gemm_bf16_nt: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
         return SSW_ERR_UNSUPPORTED;
     }
+    if (g_gemm_variant >= 20 && g_gemm_variant <= 23 && gemm_pw4_supports(M, N, K)) {
+        static const int bn_of[4] = {0, 256, 192, 128};
+        int bn = bn_of[g_gemm_variant - 20];
+        if (bn != 0 && N % bn != 0) bn = 0;
+        return launch_gemm_pw4(epi, s, A_, W_, bias, res, C, M, N, K, bn);
+    }
     const bf16 *A = static_cast<const bf16 *>(A_), *W = static_cast<const bf16 *>(W_);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(s, A, W, bias, res, C, M, N, K);
@@ -708,12 +714,25 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" int ssw_tune_gemm(int variant) {
-    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15) {
+    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15 &&
+        !(variant >= 20 && variant <= 23)) {
         ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
         return SSW_ERR_INVALID;
     }
     ssw::tune_gemm(variant);
     return SSW_OK;
+}
+
+// diagnostics of the persistent kernel (gemm_pw4.hip): mode 1 accumulates cycle stamps, read back here as
+// out4 = {cycles in the mid-step wait + barrier, cycles in K-steps, K-steps, waves}; modes 2-4 are ablations
+extern "C" int ssw_debug_gemm_pw4_mode(int32_t mode, uint64_t *out6_or_null) {
+    ssw::gemm_pw4_set_mode(mode);
+    if (out6_or_null) return ssw::gemm_pw4_read_diag(reinterpret_cast<unsigned long long *>(out6_or_null), true);
+    return SSW_OK;
+}
+
+extern "C" int ssw_debug_gemm_pw4_wg(uint64_t *out4096) {
+    return ssw::gemm_pw4_read_wg(reinterpret_cast<unsigned long long *>(out4096));
 }
 
 extern "C" int ssw_debug_gemm(int M, int N, int K, int epi, int variant, int iters, float *out_ms,

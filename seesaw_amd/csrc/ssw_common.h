@@ -72,6 +72,15 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// the same with the address split into a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16s(unsigned voff, const void *sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = false;
@@ -116,6 +125,13 @@ ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, 
 ssw_status launch_gemm_bf16_nt(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K);
 void tune_gemm(int variant);
+// gemm_pw4.hip: the persistent four-wave kernel (256 x bn tiles, bn = 256 / 192 / 128, 0 = choose); N % 128, K % 128
+bool gemm_pw4_supports(int M, int N, int K);
+void gemm_pw4_set_mode(int mode);  // diagnostics of tools/perf_gemm.py (0 = the kernel)
+ssw_status gemm_pw4_read_diag(unsigned long long out[6], bool reset);
+ssw_status gemm_pw4_read_wg(unsigned long long *out);
+ssw_status launch_gemm_pw4(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
+                           const float *residual, void *C, int M, int N, int K, int bn);
 // rng.hip: synthetic unit-norm rows.
 ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
                               hipStream_t stream);

@@ -1,8 +1,11 @@
 """A/B the tower GEMM variants in one process (GPU box): ms, TFLOP/s and max |diff| to variant 0."""
 import ctypes
 
-import torch  # noqa: F401  (first: its bundled HIP runtime must be the one the process uses)
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (first: its bundled HIP runtime must be the one the process uses)
 
 from seesaw_amd import _lib
 
@@ -34,7 +37,53 @@ def main():
         print(line, flush=True)
 
 
-if __name__ == "__main__":
+def pw_diag():
+    """where a K-step of the persistent kernel spends its cycles (fc1: 256 x 256 tiles; patch: 256 x 128), and what the
+    loop costs without its LDS-DMA / MFMAs / fragment reads"""
+    import numpy as np
+    lib = _lib.load()
+    for (M, N, K, epi, what, v) in [(10000, 3072, 768, 2, "fc1+gelu", 21), (9800, 768, 3072, 0, "patch", 23)]:
+        line = f"{what:10s} pw4:"
+        for mode in (0, 1, 2, 3, 4, 5):
+            lib.ssw_debug_gemm_pw4_mode(mode, None)
+            ms, md = ctypes.c_float(), ctypes.c_float()
+            out = np.zeros(6, dtype=np.uint64)
+            lib.ssw_debug_gemm_pw4_mode(mode, ctypes.c_void_p(out.ctypes.data))  # reset the counters
+            rc = lib.ssw_debug_gemm(M, N, K, epi, v, 20, ctypes.byref(ms), ctypes.byref(md))
+            if rc != 0:
+                raise RuntimeError(lib.ssw_last_error().decode())
+            line += f" | mode {mode} {ms.value*1e3:6.1f}us"
+            if mode == 1:
+                lib.ssw_debug_gemm_pw4_mode(1, ctypes.c_void_p(out.ctypes.data))
+                wait, steps, n, waves, ticks, rticks = (float(x) for x in out)
+                buf = np.zeros(4096 + 20, dtype=np.uint64)
+                lib.ssw_debug_gemm_pw4_wg(ctypes.c_void_p(buf.ctypes.data))
+                wg = buf[:4096].reshape(1024, 4)
+                wg = wg[wg[:, 1] > 0].astype(np.int64)
+                t0 = wg[:, 0].min()
+                dur = (wg[:, 1] - wg[:, 0]) / 100.0
+                start = (wg[:, 0] - t0) / 100.0
+                cu = (wg[:, 2] >> 8) & 0xF, 
+                ident = wg[:, 3] * 100000 + ((wg[:, 2] >> 13) & 0x7) * 1000 + ((wg[:, 2] >> 12) & 1) * 100 + ((wg[:, 2] >> 8) & 0xF)
+                print(f"   workgroups {wg.shape[0]}: lifetime us min/med/max {dur.min():.1f}/{np.median(dur):.1f}/{dur.max():.1f}; start offsets us "
+                      f"min/med/max {start.min():.1f}/{np.median(start):.1f}/{start.max():.1f}; distinct (xcc, se, sh, cu) ids {np.unique(ident).shape[0]}; "
+                      f"span {((wg[:, 1].max() - t0) / 100.0):.1f} us")
+                line += (f" (per K-step {steps / max(n, 1):.0f} cycles, of them wait+barrier {wait / max(n, 1):.0f}; "
+                         f"s_memtime runs at {ticks / max(rticks, 1) * 100:.0f} MHz)")
+            if mode == 5:
+                buf = np.zeros(4096 + 20, dtype=np.uint64)
+                lib.ssw_debug_gemm_pw4_wg(ctypes.c_void_p(buf.ctypes.data))
+                grp = buf[4096:].astype(np.float64)
+                nb = max(grp[17], 1.0)
+                print("   mode 5, cycles per interleave group (2 reads | piece, 4 MFMAs): " + " ".join(f"{v / nb:.0f}" for v in grp[:16])
+                      + f" ; between bodies (waits + barrier) {grp[16] / nb:.0f}")
+        lib.ssw_debug_gemm_pw4_mode(0, None)
+        print(line, flush=True)
+
+
+if __name__ == "__main__" and "--pw-diag" in sys.argv:
+    pw_diag()
+elif __name__ == "__main__":
     main()
 
 
