@@ -31,8 +31,10 @@ namespace {
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3 };
+enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3, EPI_BF16_LN = 4, EPI_BF16_LN_GELU = 5,
+                EPI_F32_BIAS_RESIDUAL_STATS = 6 };  // as gemm_bf16.hip
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 
 // ---------------------------------------------------------------------------------------
@@ -89,6 +91,85 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
     }
 }
 
+// The row that ENTERS the transformer stack of the tile path (vision: the pre-LayerNorm's output; text: the token +
+// position embedding): besides the f32 residual row, the stack's first QKV product wants its bf16 copy and its
+// LayerNorm statistics as `np` partial (sum, sum of squares) pairs (GemmLn, ssw_common.h) -- the whole row in partial 0.
+// LN = true: y = LayerNorm(x) with (w, b) is the row (x is consumed); LN = false: y = x.
+template <bool LN>
+__global__ __launch_bounds__(256) void stack_input_rows(const float *__restrict__ x, int n_rows, int D,
+                                                        const float *__restrict__ w, const float *__restrict__ b,
+                                                        float eps, float *__restrict__ y_out, bf16 *__restrict__ y_bf16,
+                                                        float *__restrict__ stats, int np) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)r * D);
+    const int nv = D >> 2;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    if (LN) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (lane + 64 * i < nv) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = rsqrtf(q / (float)D + eps);
+        const float4 *w4 = reinterpret_cast<const float4 *>(w), *b4 = reinterpret_cast<const float4 *>(b);
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 ww = w4[c], bb = b4[c];
+                v[i].x = (v[i].x - mean) * rstd * ww.x + bb.x;
+                v[i].y = (v[i].y - mean) * rstd * ww.y + bb.y;
+                v[i].z = (v[i].z - mean) * rstd * ww.z + bb.z;
+                v[i].w = (v[i].w - mean) * rstd * ww.w + bb.w;
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+        }
+    }
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        q2 += __shfl_xor(q2, off, 64);
+    }
+    float4 *yo = reinterpret_cast<float4 *>(y_out + (int64_t)r * D);
+    bf16x4 *yb = reinterpret_cast<bf16x4 *>(y_bf16 + (int64_t)r * D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            if (LN) yo[c] = v[i];
+            bf16x4 h;
+            h[0] = (bf16)v[i].x; h[1] = (bf16)v[i].y; h[2] = (bf16)v[i].z; h[3] = (bf16)v[i].w;
+            yb[c] = h;
+        }
+    }
+    if (lane < np) {
+        float *st = stats + ((int64_t)r * np + lane) * 2;
+        st[0] = lane == 0 ? s : 0.f;
+        st[1] = lane == 0 ? q2 : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // attention: one WORKGROUP per (batch, head), one wave per 16-query tile; S <= 16*NT tokens,
 // head_dim 64.  The MFMA operands are ordered so that a lane owns ONE query:
@@ -106,7 +187,6 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 // qkv [R, 3D] bf16 (q | k | v), out [R, D] bf16
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 80;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 template <int NT>
 __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
@@ -727,6 +807,10 @@ namespace {
 struct Layer {
     float *ln1w, *ln1b, *ln2w, *ln2b, *bqkv, *bo, *b1, *b2;
     bf16 *wqkv, *wo, *w1, *w2;
+    // LayerNorm folded into the tile path's QKV / fc1 products (GemmLn, ssw_common.h): W' = gamma (.) W in bf16,
+    // c1_n = sum_k W'_nk, c2_n = sum_k beta_k W_nk + b_n
+    bf16 *wqkv_ln = nullptr, *w1_ln = nullptr;
+    float *c1qkv = nullptr, *c2qkv = nullptr, *c1fc1 = nullptr, *c2fc1 = nullptr;
 };
 
 struct Tower {
@@ -762,6 +846,7 @@ struct ssw_clip {
     int64_t cap_rows = 0, cap_mlp = 0, cap_batch = 0;
     float *hidden = nullptr, *hidden2 = nullptr, *pooled = nullptr, *patch_out = nullptr;
     bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *h1 = nullptr, *patches = nullptr;
+    float *stats_a = nullptr, *stats_b = nullptr;  // [rows][D / 128][2] partial LayerNorm statistics of hidden / hidden2
     float *pixels = nullptr, *out = nullptr;
     int *ids = nullptr, *rows = nullptr;
 };
@@ -799,12 +884,46 @@ ssw_status upload_bf16(ssw_clip *c, const float *&cur, const float *end, size_t 
     return SSW_OK;
 }
 
+// f32 -> bf16 -> f32 the way the device's conversion rounds (nearest even); the blob holds finite weights
+inline float bf16_round_host(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// W [N, D] (f32, host), gamma / beta [D], b [N]  ->  W' = gamma (.) W (bf16 on the device), c1, c2 (f32 on the device)
+ssw_status fold_layernorm(ssw_clip *c, const float *W, const float *gamma, const float *beta, const float *b, size_t N,
+                          size_t D, bf16 **w_ln, float **c1, float **c2, float *scratch) {
+    std::vector<float> wf(N * D), v1(N), v2(N);
+    for (size_t n = 0; n < N; ++n) {
+        double s1 = 0.0, s2 = 0.0;
+        for (size_t k = 0; k < D; ++k) {
+            const float wp = W[n * D + k] * gamma[k];
+            wf[n * D + k] = wp;
+            s1 += (double)bf16_round_host(wp);  // what the matrix cores will multiply by
+            s2 += (double)beta[k] * (double)W[n * D + k];
+        }
+        v1[n] = (float)s1;
+        v2[n] = (float)(s2 + (double)b[n]);
+    }
+    const float *p = wf.data();
+    SSW_TRY(upload_bf16(c, p, p + wf.size(), wf.size(), w_ln, scratch));
+    p = v1.data();
+    SSW_TRY(upload_f32(c, p, p + N, N, c1));
+    p = v2.data();
+    SSW_TRY(upload_f32(c, p, p + N, N, c2));
+    return SSW_OK;
+}
+
 // q, k, v weights/biases are consecutive in the blob; fuse them into one [3D, D] operand
 ssw_status load_tower(ssw_clip *c, Tower &tw, const float *&cur, const float *end, float *scratch) {
     const size_t D = tw.D, M = tw.M;
     tw.layers.resize(tw.L);
     for (int l = 0; l < tw.L; ++l) {
         Layer &ly = tw.layers[l];
+        const float *ln1w_h = cur, *ln1b_h = cur + D;
         SSW_TRY(upload_f32(c, cur, end, D, &ly.ln1w));
         SSW_TRY(upload_f32(c, cur, end, D, &ly.ln1b));
         // blob order: q.w q.b k.w k.b v.w v.b -> gather into wqkv / bqkv on the host side
@@ -822,10 +941,17 @@ ssw_status load_tower(ssw_clip *c, Tower &tw, const float *&cur, const float *en
         const float *wc = w.data(), *bc = b.data();
         SSW_TRY(upload_bf16(c, wc, wc + w.size(), w.size(), &ly.wqkv, scratch));
         SSW_TRY(upload_f32(c, bc, bc + b.size(), b.size(), &ly.bqkv));
+        SSW_TRY(fold_layernorm(c, w.data(), ln1w_h, ln1b_h, b.data(), 3 * D, D, &ly.wqkv_ln, &ly.c1qkv, &ly.c2qkv, scratch));
         SSW_TRY(upload_bf16(c, cur, end, D * D, &ly.wo, scratch));
         SSW_TRY(upload_f32(c, cur, end, D, &ly.bo));
+        const float *ln2w_h = cur, *ln2b_h = cur + D;
         SSW_TRY(upload_f32(c, cur, end, D, &ly.ln2w));
         SSW_TRY(upload_f32(c, cur, end, D, &ly.ln2b));
+        if (cur + M * D + M > end) {
+            set_error("clip: weight blob truncated");
+            return SSW_ERR_INVALID;
+        }
+        SSW_TRY(fold_layernorm(c, cur, ln2w_h, ln2b_h, cur + M * D, M, D, &ly.w1_ln, &ly.c1fc1, &ly.c2fc1, scratch));
         SSW_TRY(upload_bf16(c, cur, end, M * D, &ly.w1, scratch));
         SSW_TRY(upload_f32(c, cur, end, M, &ly.b1));
         SSW_TRY(upload_bf16(c, cur, end, D * M, &ly.w2, scratch));
@@ -847,7 +973,7 @@ ssw_status reserve(ssw_clip *c, int64_t batch) {
     SSW_HIP_TRY(hipStreamSynchronize(c->stream));
     for (void *p : {(void *)c->hidden, (void *)c->hidden2, (void *)c->pooled, (void *)c->patch_out, (void *)c->xn,
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
-                    (void *)c->out, (void *)c->ids, (void *)c->rows})
+                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
         (void)hipFree(p);
     const Header &h = c->hdr;
     const int64_t Tv = (int64_t)(h.image / h.patch) * (h.image / h.patch) + 1;
@@ -867,6 +993,8 @@ ssw_status reserve(ssw_clip *c, int64_t batch) {
     SSW_HIP_TRY(hipMalloc((void **)&c->out, batch * h.proj * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&c->ids, batch * h.t_maxpos * sizeof(int)));
     SSW_HIP_TRY(hipMalloc((void **)&c->rows, batch * sizeof(int)));
+    SSW_HIP_TRY(hipMalloc((void **)&c->stats_a, rows * (D / 128 + 1) * 2 * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&c->stats_b, rows * (D / 128 + 1) * 2 * sizeof(float)));
     c->cap_batch = batch;
     return SSW_OK;
 }
@@ -927,11 +1055,29 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         launch_skinny<SK_BF16_BIAS_GELU, true>(s, h2, nullptr, ly.ln2w, ly.ln2b, eps, ly.w1, ly.b1, nullptr, c->h1, R, M, D);
         launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->h1, nullptr, nullptr, nullptr, eps, ly.w2, ly.b2, h2, h, R, D, M);
     }
+    // ---- tile path: five launches a layer.  Both LayerNorms are folded into the products that consume them (GemmLn,
+    // ssw_common.h): the out-projection / fc2 epilogues leave, next to the f32 residual row, its bf16 copy (c->xn) and
+    // its partial statistics; QKV / fc1 multiply that copy by gamma (.) W and apply mean / rstd in their epilogue.
+    // c->xn and stats_in arrive filled by whoever produced c->hidden (stack_input_rows).
+    static const bool unfused_ln = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
+    const int np = D / 128;
+    float *st_h = c->stats_a, *st_h2 = c->stats_b;
     for (int l = 0; l < tw.L && !skinny; ++l) {
         const Layer &ly = tw.layers[l];
-        hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h, (const int *)nullptr, R, D,
-                           ly.ln1w, ly.ln1b, eps, c->xn);
-        SSW_TRY(gemm<EPI_BF16_BIAS>(s, c->xn, ly.wqkv, ly.bqkv, nullptr, c->qkv, R, 3 * D, D));
+        GemmLn cons, prod;
+        cons.np_in = np;
+        cons.inv_dim = 1.0f / (float)D;
+        cons.eps = eps;
+        prod.xcopy = c->xn;
+        if (unfused_ln || D % 128 != 0) {
+            hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h, (const int *)nullptr, R, D,
+                               ly.ln1w, ly.ln1b, eps, c->xn);
+            SSW_TRY(gemm<EPI_BF16_BIAS>(s, c->xn, ly.wqkv, ly.bqkv, nullptr, c->qkv, R, 3 * D, D));
+        } else {
+            cons.stats_in = st_h;
+            cons.c1 = ly.c1qkv;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN, s, c->xn, ly.wqkv_ln, ly.c2qkv, nullptr, c->qkv, R, 3 * D, D, cons));
+        }
         const int n_heads = B * tw.H;
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
         if (S <= 64)
@@ -940,11 +1086,21 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         else
             hipLaunchKernelGGL(attention_mfma<5>, dim3(n_heads), dim3(320), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
                                causal);
-        SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->att, ly.wo, ly.bo, h, h2, R, D, D));
-        hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h2, (const int *)nullptr, R, D,
-                           ly.ln2w, ly.ln2b, eps, c->xn);
-        SSW_TRY(gemm<EPI_BF16_BIAS_GELU>(s, c->xn, ly.w1, ly.b1, nullptr, c->h1, R, M, D));
-        SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->h1, ly.w2, ly.b2, h2, h, R, D, M));
+        if (unfused_ln || D % 128 != 0) {
+            SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->att, ly.wo, ly.bo, h, h2, R, D, D));
+            hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h2, (const int *)nullptr, R, D,
+                               ly.ln2w, ly.ln2b, eps, c->xn);
+            SSW_TRY(gemm<EPI_BF16_BIAS_GELU>(s, c->xn, ly.w1, ly.b1, nullptr, c->h1, R, M, D));
+            SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->h1, ly.w2, ly.b2, h2, h, R, D, M));
+        } else {
+            prod.stats_out = st_h2;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->att, ly.wo, ly.bo, h, h2, R, D, D, prod));
+            cons.stats_in = st_h2;
+            cons.c1 = ly.c1fc1;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->xn, ly.w1_ln, ly.c2fc1, nullptr, c->h1, R, M, D, cons));
+            prod.stats_out = st_h;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
+        }
     }
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -981,8 +1137,9 @@ ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *
     const int pcols = 3 * h.patch * h.patch;
     SSW_TRY(gemm<EPI_F32>(s, c->patches, c->patch_w, nullptr, nullptr, c->patch_out, B * (T - 1), D, pcols));
     hipLaunchKernelGGL(vision_assemble, dim3(2048), dim3(256), 0, s, c->patch_out, c->cls, c->vpos, c->hidden2, B, T, D);
-    hipLaunchKernelGGL(layernorm_rows<float>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->hidden2, (const int *)nullptr,
-                       B * T, D, c->pre_w, c->pre_b, h.ln_eps, c->hidden);
+    // pre-LayerNorm = the stack's input row: f32 into c->hidden, bf16 copy and statistics for layer 0's QKV
+    hipLaunchKernelGGL(stack_input_rows<true>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->hidden2, B * T, D, c->pre_w,
+                       c->pre_b, h.ln_eps, c->hidden, c->xn, c->stats_a, D / 128 > 0 ? D / 128 : 1);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
     hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
     return pool_and_project(c, c->vis, B, D, normalize, out_dev);
@@ -1010,6 +1167,10 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
     const Header &h = c->hdr;
     const int D = h.t_hidden;
     hipLaunchKernelGGL(text_embed, dim3(1024), dim3(256), 0, s, ids_dev, c->tok, c->tpos, c->hidden, B, L, D);
+    if (!(skinny_rows(B * L, D, c->txt.M) && c->txt.H * 64 == D))  // the tile path wants the row's bf16 copy + statistics
+        hipLaunchKernelGGL(stack_input_rows<false>, dim3((B * L + 3) / 4), dim3(256), 0, s, c->hidden, B * L, D,
+                           (const float *)nullptr, (const float *)nullptr, h.ln_eps, c->hidden, c->xn, c->stats_a,
+                           D / 128 > 0 ? D / 128 : 1);
     SSW_TRY(run_tower(c, c->txt, B, L, 1));
     hipLaunchKernelGGL(eos_rows, dim3((B + 255) / 256), dim3(256), 0, s, ids_dev, B, L, h.eos, c->rows);
     return pool_and_project(c, c->txt, B, D, normalize, out_dev);
@@ -1026,7 +1187,7 @@ ssw_status ssw_clip_destroy(ssw_clip *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     for (void *p : {(void *)c->hidden, (void *)c->hidden2, (void *)c->pooled, (void *)c->patch_out, (void *)c->xn,
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
-                    (void *)c->out, (void *)c->ids, (void *)c->rows})
+                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
         (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

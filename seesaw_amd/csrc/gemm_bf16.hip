@@ -32,9 +32,59 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3 };
-
 __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
+
+// 4 / 5: LayerNorm folded into the product (GemmLn, ssw_common.h) -> bf16 [+ quick-GELU]; 6: +bias +residual -> f32, plus the
+// bf16 copy of the new residual row and its partial LayerNorm statistics for the next product
+enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3, EPI_BF16_LN = 4,
+                EPI_BF16_LN_GELU = 5, EPI_F32_BIAS_RESIDUAL_STATS = 6 };
+constexpr bool epi_ln(int e) { return e == EPI_BF16_LN || e == EPI_BF16_LN_GELU; }
+constexpr bool epi_bf16_out(int e) { return e == EPI_BF16_BIAS || e == EPI_BF16_BIAS_GELU || epi_ln(e); }
+constexpr bool epi_gelu(int e) { return e == EPI_BF16_BIAS_GELU || e == EPI_BF16_LN_GELU; }
+constexpr bool epi_residual(int e) { return e == EPI_F32_BIAS_RESIDUAL || e == EPI_F32_BIAS_RESIDUAL_STATS; }
+
+// LayerNorm folded into a product (no layernorm launch in the tile path).  With x the f32 residual row,
+// LN(x) W^T + b = rstd * (x W'^T - mean * c1) + c2,  W' = gamma (.) W (folded once at load, bf16), c1_n = sum_k W'_nk,
+// c2_n = sum_k beta_k W_nk + b_n: the product runs on bf16(x) -- which the kernel that produced x wrote next to the f32
+// row -- and the row statistics arrive as per-column-tile partial sums (sum, sum of squares) from that kernel's
+// epilogue (EPI_F32_BIAS_RESIDUAL_STATS), np_in of them per row, added here in ascending order.
+
+// One epilogue for the tile kernels: acc holds C[row][col .. col + 3] (before bias); rows' LayerNorm statistics (mean,
+// rstd) come from LDS (ln_stats[2 * local_row]).
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, const float *__restrict__ bias,
+                                               const float *__restrict__ residual, void *__restrict__ Cout,
+                                               const GemmLn &ln, float mean, float rstd, float *sum, float *sq) {
+    if constexpr (epi_ln(EPI)) {  // (the accumulators of these variants start from zero; c2 is in `bias`)
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(ln.c1 + col), c2 = *reinterpret_cast<const f32x4 *>(bias + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * c1[r]) + c2[r];
+    }
+    (void)col;
+    if constexpr (epi_gelu(EPI)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // quick_gelu: x * sigmoid(1.702 x), v_exp + v_rcp
+            v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
+    }
+    if constexpr (epi_residual(EPI)) v += *reinterpret_cast<const f32x4 *>(residual + o);
+    if constexpr (epi_bf16_out(EPI)) {
+        bf16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
+        *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + o) = h;
+    } else {
+        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
+    }
+    if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {
+        bf16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
+        *reinterpret_cast<bf16x4 *>(ln.xcopy + o) = h;
+        *sum += (v[0] + v[1]) + (v[2] + v[3]);
+        *sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------
 // variant 0: register-staged double buffer (global -> VGPR -> padded LDS), one tile of lookahead
@@ -177,7 +227,7 @@ template <int EPI, int DEPTH, int TM, bool PIPE, int WN = 2>
 __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
-                                                    int M, int N, int K, int m_tiles, int n_tiles) {
+                                                    int M, int N, int K, int m_tiles, int n_tiles, GemmLn ln) {
     constexpr int NW = (TM / 64) * WN;     // waves
     constexpr int NJ = 128 / WN / 16;      // 16-column accumulator tiles per wave
     constexpr int AP = (TM / 8) / NW;      // A pieces (8 rows x 128 B) per wave
@@ -234,9 +284,20 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     for (int j = 0; j < NJ; ++j) {
         const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_F32) bv = *reinterpret_cast<const f32x4 *>(bias + col);
+        if (EPI != EPI_F32 && !epi_ln(EPI)) bv = *reinterpret_cast<const f32x4 *>(bias + col);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+    }
+    float *const ln_lds = reinterpret_cast<float *>(smem + DEPTH * STAGE);  // [TM][2] statistics / [WN][TM][2] partials
+    // LayerNorm-folded variants: thread t < TM requests the partial sums of row m0 + t NOW (ordinary loads, ahead of the
+    // ring's first pieces) and touches them only behind the K loop, where the compiler's vmcnt(0) for them finds every
+    // LDS-DMA piece long landed; in between they cost eight registers and no wait.
+    constexpr int LN_NP = 8;  // partial pairs held in registers (hidden width <= 1024)
+    float2 ln_part[LN_NP];
+    if constexpr (epi_ln(EPI)) {
+        const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < TM ? t : 0), M - 1) * ln.np_in;
+#pragma unroll
+        for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];  // unconditional: no select, hence no early wait
     }
 
     // fragment byte offset inside an image: row (16-row block + fr), chunk (4 ks + fq) ^ (fr >> 1)
@@ -356,30 +417,62 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #undef SSW_READ_FRAGS
 #undef SSW_MFMA_BLOCK
 
-    // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+    // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*(128/WN) + j*16 + fq*4 + r]
+    if constexpr (epi_ln(EPI)) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int p = 0; p < LN_NP; ++p) {
+            asm volatile("" : "+v"(ln_part[p].x), "+v"(ln_part[p].y));  // keep the sums (and their wait) behind the loop
+            sm += p < ln.np_in ? ln_part[p].x : 0.f;
+            sq += p < ln.np_in ? ln_part[p].y : 0.f;
+        }
+        if (t < TM) {
+            const float mean = sm * ln.inv_dim;
+            const float var = fmaxf(sq * ln.inv_dim - mean * mean, 0.f);
+            ln_lds[2 * t] = mean;
+            ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + fr;
-        if (row >= M) continue;
+        const int lrow = wm * 64 + i * 16 + fr;
+        const int row = m0 + lrow;
+        float mean = 0.f, rstd = 1.f, ssum = 0.f, ssq = 0.f;
+        if constexpr (epi_ln(EPI)) {
+            mean = ln_lds[2 * lrow];
+            rstd = ln_lds[2 * lrow + 1];
+        }
+        if (row < M) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
-            const int64_t o = (int64_t)row * N + col;
-            f32x4 v = acc[i][j];
-            if (EPI == EPI_BF16_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)  // quick_gelu: x * sigmoid(1.702 x), v_exp + v_rcp
-                    v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
+            for (int j = 0; j < NJ; ++j) {
+                const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
+                epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq);
             }
-            if (EPI == EPI_F32_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4 *>(residual + o);
-            if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
-                bf16x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
-                *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + o) = h;
-            } else {
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
+        }
+        if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {  // this wave's 128 / WN columns of the row: the four fq lanes
+            ssum += __shfl_xor(ssum, 16, 64);
+            ssq += __shfl_xor(ssq, 16, 64);
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (fq == 0) {
+                ln_lds[(wn * TM + lrow) * 2] = ssum;
+                ln_lds[(wn * TM + lrow) * 2 + 1] = ssq;
             }
+        }
+    }
+    if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {
+        __syncthreads();
+        if (t < TM && m0 + t < M) {  // the tile's 128 columns of row t: the WN wave partials in wave order
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                sm += ln_lds[(w * TM + t) * 2];
+                sq += ln_lds[(w * TM + t) * 2 + 1];
+            }
+            float *o = ln.stats_out + ((int64_t)(m0 + t) * n_tiles + nt) * 2;
+            o[0] = sm;
+            o[1] = sq;
         }
     }
 }
@@ -412,7 +505,8 @@ constexpr int T256_STAGE = 4 * T256_HALF;   // A0 A1 W0 W1
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                 const float *__restrict__ bias, const float *__restrict__ residual,
-                                                void *__restrict__ Cout, int M, int N, int K, int m_tiles, int n_tiles) {
+                                                void *__restrict__ Cout, int M, int N, int K, int m_tiles, int n_tiles,
+                                                GemmLn ln) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -459,9 +553,17 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wc * 64 + j * 16 + fq * 4;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_F32) bv = *reinterpret_cast<const f32x4 *>(bias + col);
+        if (EPI != EPI_F32 && !epi_ln(EPI)) bv = *reinterpret_cast<const f32x4 *>(bias + col);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i][j] = bv;
+    }
+    float *const ln_lds = reinterpret_cast<float *>(smem + 2 * T256_STAGE);  // [256][2] row statistics
+    constexpr int LN_NP = 8;  // as in gemm_glds: requested now, first touched behind the K loop
+    float2 ln_part[LN_NP];
+    if constexpr (epi_ln(EPI)) {
+        const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < 256 ? t : 0), M - 1) * ln.np_in;
+#pragma unroll
+        for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];
     }
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
     const int a_frag = wr * T256_HALF + frag0;                                        // + i * 2048, i = 0..7
@@ -493,6 +595,8 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     T256_ISSUE_A0(0, 0) T256_ISSUE_A1(0, 0) T256_ISSUE_W0(0, 0) T256_ISSUE_W1(0, 0)
     if (nk > 1) {
         T256_ISSUE_W0(1, 1) T256_ISSUE_W1(1, 1) T256_ISSUE_A0(1, 1)
+    }
+    if (nk > 1) {
         wait_vmcnt<6>();
     } else {
         wait_vmcnt<0>();
@@ -542,38 +646,46 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
 #undef T256_LGKM0_BARRIER
 
     // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
+    static_assert(EPI != EPI_F32_BIAS_RESIDUAL_STATS, "the statistics epilogue lives in gemm_glds (N = hidden width shapes)");
+    if constexpr (epi_ln(EPI)) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int p = 0; p < LN_NP; ++p) {
+            asm volatile("" : "+v"(ln_part[p].x), "+v"(ln_part[p].y));
+            sm += p < ln.np_in ? ln_part[p].x : 0.f;
+            sq += p < ln.np_in ? ln_part[p].y : 0.f;
+        }
+        if (t < 256) {
+            const float mean = sm * ln.inv_dim;
+            const float var = fmaxf(sq * ln.inv_dim - mean * mean, 0.f);
+            ln_lds[2 * t] = mean;
+            ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int row = m0 + wr * 128 + i * 16 + fr;
+        const int lrow = wr * 128 + i * 16 + fr;
+        const int row = m0 + lrow;
+        float mean = 0.f, rstd = 1.f, ssum = 0.f, ssq = 0.f;
+        if constexpr (epi_ln(EPI)) {
+            mean = ln_lds[2 * lrow];
+            rstd = ln_lds[2 * lrow + 1];
+        }
         if (row >= M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wc * 64 + j * 16 + fq * 4;
-            const int64_t o = (int64_t)row * N + col;
-            f32x4 v = acc[i][j];
-            if (EPI == EPI_BF16_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
-            }
-            if (EPI == EPI_F32_BIAS_RESIDUAL) v += *reinterpret_cast<const f32x4 *>(residual + o);
-            if (EPI == EPI_BF16_BIAS || EPI == EPI_BF16_BIAS_GELU) {
-                bf16x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
-                *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16 *>(Cout) + o) = h;
-            } else {
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
-            }
+            epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq);
         }
     }
 }
 
 template <int EPI>
 ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
-                      int N, int K) {
+                      int N, int K, const GemmLn &ln) {
     static bool attr_set = false;
-    constexpr int lds = 2 * T256_STAGE;
+    constexpr int lds = 2 * T256_STAGE + 2048;  // + the rows' LayerNorm statistics (EPI 4 / 5)
     if (!attr_set) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_256<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -581,7 +693,7 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
     }
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
-    hipLaunchKernelGGL((gemm_256<EPI>), dim3(grid), dim3(512), lds, s, A, W, bias, res, C, M, N, K, m_tiles, n_tiles);
+    hipLaunchKernelGGL((gemm_256<EPI>), dim3(grid), dim3(512), lds, s, A, W, bias, res, C, M, N, K, m_tiles, n_tiles, ln);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -609,9 +721,9 @@ int g_gemm_variant = 14;
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
-                       int M, int N, int K) {
+                       int M, int N, int K, const GemmLn &ln) {
     static bool attr_set = false;
-    constexpr int lds = DEPTH * (TM * 128 + G_WIMG);
+    constexpr int lds = DEPTH * (TM * 128 + G_WIMG) + WN * TM * 8;  // + row statistics / their per-wave partials
     if (!attr_set) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE, WN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -620,7 +732,7 @@ ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float 
     const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
     hipLaunchKernelGGL((gemm_glds<EPI, DEPTH, TM, PIPE, WN>), dim3(grid), dim3(TM * WN), lds, s, A, W, bias, res, C, M, N, K,
-                       m_tiles, n_tiles);
+                       m_tiles, n_tiles, ln);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -628,17 +740,18 @@ ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float 
 template <int EPI>
 ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                       int N, int K) {
+    const GemmLn none;
     switch (g_gemm_variant) {
         case 0:
             hipLaunchKernelGGL(gemm_bf16_nt<EPI>, dim3(N / BN, (M + BM - 1) / BM), dim3(256), 0, s, A, W, bias, res, C,
                                M, N, K);
             SSW_HIP_TRY(hipGetLastError());
             return SSW_OK;
-        case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K);
+        case 7: return launch_glds<EPI, 2, 256, true>(s, A, W, bias, res, C, M, N, K, none);
         case 9:
-            if (N % 256 == 0) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K);
-            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
-        case 2: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K);
+            if (N % 256 == 0) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, none);
+            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, none);
+        case 2: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K, none);
         default: {
             // the 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills the chip
             // about twice or more: measured at M = 10 000 (profiles/r02_gemm_ab.txt) it wins on fc1 (480 tiles,
@@ -647,10 +760,24 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
             (void)hipGetDevice(&dev);
             const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
             if (g_gemm_variant == 14 && N % 256 == 0 && 10 * tiles256 >= 18 * (int64_t)num_cus(dev))
-                return launch_256<EPI>(s, A, W, bias, res, C, M, N, K);
-            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K);
+                return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, none);
+            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, none);
         }
     }
+}
+
+// the LayerNorm-folded / statistics-emitting epilogues exist on the default kernels only
+template <int EPI>
+ssw_status launch_epi_ln(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
+                         int N, int K, const GemmLn &ln) {
+    if constexpr (EPI != EPI_F32_BIAS_RESIDUAL_STATS) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
+        if (g_gemm_variant != 15 && N % 256 == 0 && 10 * tiles256 >= 18 * (int64_t)num_cus(dev))
+            return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
+    }
+    return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
 }
 
 }  // namespace
@@ -677,6 +804,33 @@ ssw_status launch_gemm_bf16_nt(int epi, hipStream_t s, const void *A_, const voi
         case EPI_F32_BIAS_RESIDUAL: return launch_epi<EPI_F32_BIAS_RESIDUAL>(s, A, W, bias, res, C, M, N, K);
     }
     set_error("gemm_bf16_nt: unknown epilogue %d", epi);
+    return SSW_ERR_INVALID;
+}
+
+ssw_status launch_gemm_bf16_ln(int epi, hipStream_t s, const void *A_, const void *W_, const float *bias,
+                               const float *res, void *C, int M, int N, int K, const GemmLn &ln) {
+    if (N % BN != 0 || K % BK != 0 || M <= 0) {
+        set_error("gemm_bf16_ln: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    const bf16 *A = static_cast<const bf16 *>(A_), *W = static_cast<const bf16 *>(W_);
+    switch (epi) {
+        case EPI_BF16_LN:
+        case EPI_BF16_LN_GELU:
+            if (!ln.stats_in || !ln.c1 || !bias || ln.np_in <= 0 || ln.np_in > 8) {
+                set_error("gemm_bf16_ln: the LayerNorm-folded product needs statistics, c1 and c2");
+                return SSW_ERR_INVALID;
+            }
+            return epi == EPI_BF16_LN ? launch_epi_ln<EPI_BF16_LN>(s, A, W, bias, res, C, M, N, K, ln)
+                                      : launch_epi_ln<EPI_BF16_LN_GELU>(s, A, W, bias, res, C, M, N, K, ln);
+        case EPI_F32_BIAS_RESIDUAL_STATS:
+            if (!ln.xcopy || !ln.stats_out || !res || !bias) {
+                set_error("gemm_bf16_ln: the statistics epilogue needs the bf16 copy, the partial-sum buffer, bias and residual");
+                return SSW_ERR_INVALID;
+            }
+            return launch_epi_ln<EPI_F32_BIAS_RESIDUAL_STATS>(s, A, W, bias, res, C, M, N, K, ln);
+    }
+    set_error("gemm_bf16_ln: epilogue %d is not a LayerNorm-folded one", epi);
     return SSW_ERR_INVALID;
 }
 

@@ -125,6 +125,21 @@ ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, 
 ssw_status launch_gemm_bf16_nt(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K);
 void tune_gemm(int variant);
+// LayerNorm folded into a product (tile path of the CLIP towers; gemm_bf16.hip explains the algebra):
+//   epi 4 / 5 (consumer):  C = rstd * (A W'^T - mean * c1) + c2 [quick-GELU] -> bf16, with A = bf16(x), W' = gamma (.) W,
+//                          c2 passed as `bias`, the rows' statistics as np_in partial (sum, sum of squares) pairs
+//   epi 6 (producer):      C = A W^T + bias + residual -> f32, plus its bf16 copy and the partial statistics of the
+//                          128-column tile, for the next consumer
+struct GemmLn {
+    const float *stats_in = nullptr;  // [M][np_in][2]
+    int np_in = 0;
+    float inv_dim = 0.f, eps = 0.f;   // 1 / (row length of the normalised vector), LayerNorm epsilon
+    const float *c1 = nullptr;        // [N]
+    __bf16 *xcopy = nullptr;          // producer: [M][N] bf16 copy of the f32 output
+    float *stats_out = nullptr;       // producer: [M][N / 128][2]
+};
+ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
+                               const float *residual, void *C, int M, int N, int K, const GemmLn &ln);
 // gemm_pw4.hip: the persistent four-wave kernel (256 x bn tiles, bn = 256 / 192 / 128, 0 = choose); N % 128, K % 128
 bool gemm_pw4_supports(int M, int N, int K);
 void gemm_pw4_set_mode(int mode);  // diagnostics of tools/perf_gemm.py (0 = the kernel)

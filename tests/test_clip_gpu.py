@@ -273,4 +273,6 @@ def test_single_query_path_agrees_with_tile_path_over_random_shapes(models):
         tiled = ours.embed_text(np.tile(ids, (reps + 1, 1)), normalize=True)[:B]
         assert np.isfinite(got).all()
         assert (got * tiled).sum(1).min() >= 0.99995, (B, L)
-        assert np.abs(got - tiled).max() <= 1e-3, (B, L, np.abs(got - tiled).max())
+        # (1.5e-3: the tile path folds its LayerNorms into the products since round 3 -- bf16(x) times gamma (.) W instead
+        #  of bf16(LN(x)) times W -- so the two paths round differently; both are held to the HF bar above)
+        assert np.abs(got - tiled).max() <= 1.5e-3, (B, L, np.abs(got - tiled).max())
