@@ -198,6 +198,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                     ret = make_session(gdm, p, b=b)
                     np.random.seed(0)
                     g = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+                hip_shown = [int(v) for a in ret["session"].acc_indices for v in np.asarray(a).reshape(-1)]
                 res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
                              "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])), "iters": len(g["latencies"]),
                              "hip_nfound": g["nfound"]}
@@ -218,9 +219,19 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 cpu_rounds = 4 if (full and name in ("knn_prop2", "pseudo_lr")) else 30
                 c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=cpu_rounds,
                                          max_results=10 ** 6, knn_df=ds.knn_graph().restrict_k(k=10).knn_df if knn_k else None)
+            # the two legs' image sequences, round by round (not only nfound): the CPU leg restates the reference's
+            # expressions, so this is the C5 parity check at the stated size.  The L-BFGS loops may part where the
+            # reference itself does not reproduce its fits; the agreement is reported, not assumed.
+            cpu_shown = [int(v) for v in c["shown"]]
+            m_cmp = min(len(cpu_shown), len(hip_shown))
+            prefix = 0
+            while prefix < m_cmp and cpu_shown[prefix] == hip_shown[prefix]:
+                prefix += 1
             res[name].update({"cpu_iters_per_s": 1.0 / float(np.mean(c["latencies"])),
                               "cpu_ms_per_iter": 1e3 * float(np.mean(c["latencies"])),
-                              "cpu_iters_timed": len(c["latencies"]), "cpu_nfound": c["nfound"]})
+                              "cpu_iters_timed": len(c["latencies"]), "cpu_nfound": c["nfound"],
+                              "sequence_check": {"rounds_compared": m_cmp, "identical_prefix": prefix,
+                                                 "same_images": sorted(cpu_shown[:m_cmp]) == sorted(hip_shown[:m_cmp])}})
         if full and with_cpu:  # one label-propagation sweep against its HBM/L2 stream (12 B per non-zero + 40 B per node)
             from seesaw_amd.knn_graph import get_weight_matrix, rbf_kernel
             from seesaw_amd.label_propagation import LabelPropagation

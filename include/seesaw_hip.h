@@ -177,6 +177,30 @@ ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *
                               int32_t n_lists, int32_t list_stride, const int32_t *dev_counts,
                               int32_t k, uint64_t *dev_keys_out, int32_t *dev_count_out);
 
+/* The sharded query as ONE device pipeline: scan -> select -> all-gather -> merge, with no elementwise kernels around
+ * the collective.  ssw_index_set_exchange_target makes the selection's last kernel also write this rank's MESSAGE into
+ * dev_msg [msg_len = (with_best ? 2 : 1) * k_max + 1 words]: keys - image_offset (the low word then holds
+ * 0xFFFFFFFF - global image position) at [0, k), best rows + row_offset at [k_max, k_max + k) when with_best, and
+ * count | overflow << 32 in the last word (NULL detaches).  ssw_topk_merge_msgs_dev merges `world` gathered messages:
+ * a list's count is the low half of its last word; the overflow flags go to dev_flags [world] (i64) and are OR-ed into
+ * dev_flags_seen [1].  No reference counterpart. */
+ssw_status ssw_index_set_exchange_target(ssw_index *idx, uint64_t *dev_msg_or_null, int32_t k_max, int32_t with_best,
+                                         int64_t image_offset, int64_t row_offset);
+ssw_status ssw_topk_merge_msgs_dev(int32_t device, void *hip_stream, const uint64_t *dev_msgs, int32_t world,
+                                   int32_t k_max, int32_t with_best, int32_t k, uint64_t *dev_keys_out,
+                                   int32_t *dev_count_out, int64_t *dev_flags_or_null, int64_t *dev_flags_seen_or_null);
+
+/* The collective itself (`ssw_topk_allgather(ssw_comm *, ...)`): RCCL bound at run time (dlopen; the
+ * copy torch mapped, if any).  ssw_comm_unique_id on one rank -> 128 bytes handed to every rank by the caller's own
+ * means -> ssw_comm_create on every rank (collective).  ssw_topk_allgather enqueues ncclAllGather of msg_len u64 words
+ * per rank on hip_stream; dev_recv [world * msg_len] is in rank order. */
+typedef struct ssw_comm ssw_comm;
+ssw_status ssw_comm_unique_id(void *out_id128);
+ssw_status ssw_comm_create(int32_t device, const void *unique_id128, int32_t rank, int32_t world, ssw_comm **out);
+ssw_status ssw_comm_destroy(ssw_comm *comm);
+ssw_status ssw_topk_allgather(ssw_comm *comm, void *hip_stream, const uint64_t *dev_send, uint64_t *dev_recv,
+                              int32_t msg_len);
+
 /* tuning hook (tools/sweep_scan.py): pick the scan kernel's schedule variant for dim=512
  * (0 u4, 1 u4+nt, 2 u8, 3 u8+nt, 4 u2+nt; -1 = default) and cap its resident blocks per CU
  * (0 = no cap, -1 = default).  All variants produce identical bits. */

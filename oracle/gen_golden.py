@@ -983,9 +983,175 @@ def gen_contweighted():
     save("contweighted", **out)
 
 
+def gen_c5_sequence():
+    """(vii-b) BASELINE config C5 at its stated small size: the reference's own Session + benchmark_loop over the
+    LVIS-shape synthetic dataset bench.py uses (1 109 images x 13 tiles = 14 417 vectors, mediocre text query), 30 rounds,
+    batch 1, shortlist 50, for plain / knn_prop2 / multi_reg (ce_loss) / pseudo_lr; the k-NN graph is the reference's
+    compute_exact_knn.  Captured: the image returned in every round (fitting loops under three torch seeds).  Takes a
+    few minutes (a dense 14 417 x 14 417 distance matrix and ~90 L-BFGS fits): `--check` covers it only when asked for
+    by name or with SSW_GOLDEN_ALL=1."""
+    import contextlib
+    import io
+    import torch
+    from seesaw_amd.synthetic import make_dataset
+    msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+    sess = R.ref("seesaw.seesaw_session")
+    bench = R.ref("seesaw.seesaw_bench")
+    bt = R.ref("seesaw.basic_types")
+    kg = R.ref("seesaw.knn_graph")
+    mreg = R.ref("seesaw.loops.multi_reg")
+    gb = R.ref("seesaw.loops.graph_based")
+    pr = sys.modules["pyroaring"]
+
+    class FakeDataset:
+        def __init__(self, d):
+            self.d = d
+            self.file_meta = d.file_meta
+            self.paths = d.paths
+
+        def load_ground_truth(self):
+            return self.d.load_ground_truth()
+
+        def get_urls(self, idxbatch):
+            return self.d.get_urls(idxbatch)
+
+    make = dict(n_images=1109, tiles_per_image=13, n_categories=2, positive_frac=0.05, seed=11)
+    ds = make_dataset("lvis", knn_k=0, **make)
+    ds.embedding.noise = 1.2
+    boxes, _ = ds.load_ground_truth()
+    knn_df = kg.KNNGraph(kg.compute_exact_knn(ds.vectors, n_neighbors=11)).restrict_k(k=10).knn_df
+    W = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
+    L = kg.get_weight_matrix(knn_df, kfun=kg.rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True, laplacian=True)
+    xlx = np.asarray(ds.vectors.T @ ((L / L.diagonal().sum()) @ ds.vectors))
+    fake_wm = lambda idx, options, xlx_matrix=False: xlx if xlx_matrix else W
+    mreg.get_weight_matrix_from_index = fake_wm
+    gb.get_weight_matrix_from_index = fake_wm
+    matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    lp_opts = dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                   calib_b=-0.4, prior_weight=1.0)
+    logreg_opts = dict(class_weights=1.0, scale="centered", reg_lambda=1.0, max_iter=200.0, lr=1, fit_intercept=False)
+    variants = {
+        "plain": None,
+        "knn_prop2": lp_opts,
+        "multi_reg": dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
+                          reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200,
+                          pos_weight="balanced", lr=1.0, matrix_options=matrix),
+        "pseudo_lr": dict(switch_over=True, real_sample_weight=1.0, sample_size=10000, log_reg_params=logreg_opts,
+                          label_prop_params=lp_opts),
+    }
+    import json
+    out = {"make": np.asarray(json.dumps(make)), "noise": np.asarray(1.2), "names": np.array(list(variants)),
+           "seeds": np.asarray(BENCH_LOOP_SEEDS[:3]), "knn_rows": np.asarray(knn_df.shape[0])}
+    for name, opts in variants.items():
+        fits = name in ("multi_reg", "pseudo_lr")
+        for seed in (BENCH_LOOP_SEEDS[:3] if fits else BENCH_LOOP_SEEDS[:1]):
+            index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+            p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="multiscale", c_name=None), interactive=name,
+                                 interactive_options=opts, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                                 batch_size=1, start_policy="from_start" if name == "knn_prop2" else "after_first_batch",
+                                 index_options={"use_vec_index": False})
+            b = bt.BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
+            np.random.seed(0)
+            torch.manual_seed(seed)
+            with contextlib.redirect_stdout(io.StringIO()):
+                session = sess.Session(None, FakeDataset(ds), index, p)
+                res = bench.benchmark_loop(session=session, subset=pr.BitMap(ds.file_meta.index.values), box_data=boxes, b=b, p=p)
+            shown = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in session.acc_indices])
+            suffix = "" if seed == BENCH_LOOP_SEEDS[0] else f"_seed{seed}"
+            out[f"{name}_shown{suffix}"] = shown
+            out[f"{name}_nfound{suffix}"] = np.asarray(res["nfound"])
+            print(name, seed, res["nfound"], res["nseen"], shown[:12])
+    save("c5_sequence", **out)
+
+
+def gen_multireg_det():
+    """(iv-c) the RegModule fits of the `multireg` family and the `multi_reg` session of `bench_loop` once more with the
+    reference's DataLoader shuffle switched off (rows in storage order): ONE deterministic end point per case, no torch
+    seed involved -- what the non-reproducing cases are held to.  The only change to the reference is
+    the `shuffle` flag its fit passes to torch's DataLoader."""
+    import contextlib
+    import io
+    import json
+    import pandas as pd
+    import torch
+    from seesaw_amd.synthetic import make_dataset
+    mr = R.ref("seesaw.loops.multi_reg")
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    xlx = torch.from_numpy(g["xlx"]).float()
+    orig_dl = mr.DataLoader
+    mr.DataLoader = lambda ds, batch_size, shuffle=True: orig_dl(ds, batch_size=batch_size, shuffle=False)
+    out = {}
+    try:
+        i = 0
+        configs = [(lt, n, n_pos, dl, ql, 0.8) for lt in ["ce_loss", "pairwise_rank_loss", "pairwise_logistic_loss"]
+                   for (n, n_pos, dl, ql) in [(60, 8, 0.0, 0.0), (150, 20, 1000.0, 10.0)]]
+        configs += [(lt, 100, 12, 0.0, 1.0, 3.0) for lt in ["pairwise_rank_loss", "pairwise_logistic_loss", "ce_loss"]]
+        for (loss_type, n, n_pos, data_lam, query_lam, q_noise) in configs:
+            X, y, q = _labelled_set(700 + i, n, n_pos, q_noise=q_noise)
+            rng = np.random.default_rng(i)
+            img = np.sort(rng.integers(0, max(2, n // 3), n))
+            matchdf = pd.DataFrame({"dbidx": img, "ys": y, "max_iou": y * 0.5})
+            model = mr.RegModule(dim=512, xlx_matrix=xlx, qvec=torch.from_numpy(q).float(), label_loss_type=loss_type,
+                                 rank_loss_margin=0.2, reg_data_lambda=data_lam, reg_norm_lambda=100.0, use_qvec_norm=None,
+                                 reg_query_lambda=query_lam, verbose=False, max_iter=200, pos_weight="balanced", lr=1.0)
+            traj = _Trajectory(model, model.weight)
+            model.fit(X, y, matchdf)
+            out[f"c{i}_coeff"] = model.get_coeff().copy()
+            out[f"c{i}_final_loss"] = np.asarray(traj.arrays()[1][-1])
+            out[f"c{i}_evals"] = np.asarray(len(traj.loss))
+            i += 1
+        out["n_cases"] = np.asarray(i)
+        # the multi_reg session of bench_loop (dataset A), shuffle off
+        msi = R.ref("seesaw.indices.multiscale.multiscale_index")
+        sess = R.ref("seesaw.seesaw_session")
+        bench = R.ref("seesaw.seesaw_bench")
+        bt = R.ref("seesaw.basic_types")
+        pr = sys.modules["pyroaring"]
+
+        class FakeDataset:
+            def __init__(self, d):
+                self.d = d
+                self.file_meta = d.file_meta
+                self.paths = d.paths
+
+            def load_ground_truth(self):
+                return self.d.load_ground_truth()
+
+            def get_urls(self, idxbatch):
+                return self.d.get_urls(idxbatch)
+
+        spec = BENCH_LOOP_DATASETS["A"]
+        ds = make_dataset("lvis", knn_k=0, **spec["make"])
+        ds.embedding.noise = spec["noise"]
+        boxes, _ = ds.load_ground_truth()
+        matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+        opts = dict(label_loss_type="ce_loss", rank_loss_margin=0.2, use_qvec_norm=None, reg_data_lambda=0.0,
+                    reg_norm_lambda=100.0, reg_query_lambda=0.0, verbose=False, max_iter=200, pos_weight="balanced", lr=1.0,
+                    matrix_options=matrix)
+        mr.get_weight_matrix_from_index = lambda idx, options, xlx_matrix=False: np.zeros((512, 512), np.float32)  # unused: reg_data_lambda = 0
+        index = msi.MultiscaleIndex(embedding=ds.embedding, vectors=ds.vectors, vector_meta=ds.vector_meta, vec_index=None)
+        p = bt.SessionParams(index_spec=bt.IndexSpec(d_name="lvis", i_name="multiscale", c_name=None), interactive="multi_reg",
+                             interactive_options=opts, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                             batch_size=1, start_policy="after_first_batch", index_options={"use_vec_index": False})
+        b = bt.BenchParams(name="multi_reg", ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            session = sess.Session(None, FakeDataset(ds), index, p)
+            res = bench.benchmark_loop(session=session, subset=pr.BitMap(ds.file_meta.index.values), box_data=boxes, b=b, p=p)
+        out["multi_reg_shown"] = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in session.acc_indices])
+        out["multi_reg_nfound"] = np.asarray(res["nfound"])
+        print("multi_reg session, shuffle off:", res["nfound"], res["nseen"], out["multi_reg_shown"])
+    finally:
+        mr.DataLoader = orig_dl
+    save("multireg_det", **out)
+
+
 FAMILIES = {"lknn": gen_lknn, "scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
             "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop,
-            "multiregneg": gen_multiregneg, "contweighted": gen_contweighted}
+            "multiregneg": gen_multiregneg, "contweighted": gen_contweighted,
+            "c5_sequence": gen_c5_sequence, "multireg_det": gen_multireg_det}
+HEAVY = {"c5_sequence"}  # minutes each: regenerated only when named or with SSW_GOLDEN_ALL=1
 
 def main(argv):
     """python oracle/gen_golden.py [--check] [family ...]
@@ -993,7 +1159,8 @@ def main(argv):
     committed tests/golden/*.npz (run by tests/test_golden_regen_cpu.py where /root/reference exists)."""
     global OUT_DIR
     check = "--check" in argv
-    names = [a for a in argv if not a.startswith("--")] or list(FAMILIES)
+    names = [a for a in argv if not a.startswith("--")] or [f for f in FAMILIES
+                                                           if f not in HEAVY or os.environ.get("SSW_GOLDEN_ALL")]
     if not check:
         for nm in names:
             print(f"== {nm}")

@@ -549,7 +549,11 @@ ssw_status ssw_index_topk_dev(ssw_index *idx, const float *q_dev, int32_t k) {
     SSW_REQUIRE(idx != nullptr, "idx is NULL");
     DeviceGuard guard(idx->device);
     if (q_dev) SSW_TRY(do_scan(idx, q_dev));
-    if (idx->n_images == 0) return SSW_OK;
+    if (idx->n_images == 0) {  // an empty shard still takes part in the exchange: its message says "0 keys"
+        if (idx->ws.xchg.msg_out)
+            SSW_HIP_TRY(hipMemsetAsync(idx->ws.xchg.msg_out + (idx->ws.xchg.msg_len - 1), 0, sizeof(uint64_t), idx->stream));
+        return SSW_OK;
+    }
     return do_select(idx, k);
 }
 
@@ -708,6 +712,35 @@ ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *
     DeviceGuard guard(device);
     return launch_merge_topk(dev_keys_in, n_lists, list_stride, dev_counts, k, dev_keys_out,
                              dev_count_out, (hipStream_t)hip_stream);
+}
+
+// the sharded exchange without elementwise kernels around the collective: the selection's last kernel also writes
+// this rank's message (globalised keys, optional best rows, count | overflow << 32) into dev_msg
+ssw_status ssw_index_set_exchange_target(ssw_index *idx, uint64_t *dev_msg_or_null, int32_t k_max, int32_t with_best,
+                                         int64_t image_offset, int64_t row_offset) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    FinalExchange x;
+    if (dev_msg_or_null) {
+        SSW_REQUIRE(k_max >= 1 && k_max <= SSW_MAX_TOPK && image_offset >= 0, "bad message geometry");
+        x.msg_out = dev_msg_or_null;
+        x.image_offset = (uint64_t)image_offset;
+        x.row_offset = row_offset;
+        x.k_max = k_max;
+        x.with_best = with_best ? 1 : 0;
+        x.msg_len = (with_best ? 2 : 1) * k_max + 1;
+    }
+    idx->ws.xchg = x;
+    return SSW_OK;
+}
+
+ssw_status ssw_topk_merge_msgs_dev(int32_t device, void *hip_stream, const uint64_t *dev_msgs, int32_t world,
+                                   int32_t k_max, int32_t with_best, int32_t k, uint64_t *dev_keys_out,
+                                   int32_t *dev_count_out, int64_t *dev_flags_or_null, int64_t *dev_flags_seen_or_null) {
+    SSW_REQUIRE(dev_msgs && dev_keys_out && dev_count_out, "NULL argument");
+    DeviceGuard guard(device);
+    return launch_merge_msgs(dev_msgs, world, k_max, with_best, k, dev_keys_out, dev_count_out,
+                             reinterpret_cast<long long *>(dev_flags_or_null),
+                             reinterpret_cast<long long *>(dev_flags_seen_or_null), (hipStream_t)hip_stream);
 }
 
 ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu) {

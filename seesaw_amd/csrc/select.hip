@@ -258,6 +258,12 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t *s, int p, int t) {
 
 // candidates (n_lists lists of counts[l] keys at keys_in + l*stride; or one list whose
 // length is *ncand_ptr) -> k largest, sorted descending.
+// `x` (sharded exchange, no extra launch on either side of the all-gather):
+//   selection: msg_out = this rank's message -- keys made global (key - image_offset: the low word is
+//     0xFFFFFFFF - id) at [0, k), best rows + row_offset at [k_max, k_max + k) when with_best, and the word
+//     count | overflow << 32 at [msg_len - 1];
+//   merge (from_msgs): the lists ARE such messages (stride msg_len): a list's count is the low word of its last entry,
+//     its overflow flag goes to flags_out[l] and is OR-ed into flags_seen.
 __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ keys_in, int n_lists,
                                                 int list_stride, const int32_t *__restrict__ counts,
                                                 const uint32_t *__restrict__ ncand_ptr,
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
                                                 uint64_t *__restrict__ keys_out,
                                                 int32_t *__restrict__ count_out,
                                                 uint32_t *__restrict__ best_out,
-                                                unsigned char *__restrict__ packed_or_null) {
+                                                unsigned char *__restrict__ packed_or_null, FinalExchange x) {
     extern __shared__ uint64_t s[];  // FINAL_CAP entries
     const int t = threadIdx.x;
     int n = 0;
@@ -276,7 +282,9 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
     } else {
         for (int l = 0; l < n_lists; ++l) {
             // lists arrive sorted (descending): only a list's first k keys can reach the global top-k
-            const int c = max(0, min(min(counts[l], list_stride), k));
+            const int have = x.from_msgs ? (int)(keys_in[(int64_t)l * list_stride + list_stride - 1] & 0xffffffffull)
+                                         : counts[l];
+            const int c = max(0, min(min(have, x.from_msgs ? x.k_max : list_stride), k));
             if (n + c > FINAL_CAP) break;  // launcher guarantees n_lists * min(stride, k) <= FINAL_CAP
             for (int i = t; i < c; i += 1024) s[n + i] = keys_in[(int64_t)l * list_stride + i];
             n += c;
@@ -295,11 +303,16 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
         const uint64_t key = s[i];
         keys_out[i] = key;
         if (pk_keys) pk_keys[i] = key;
+        uint32_t br = 0;
         if (best_out != nullptr) {
             const uint32_t id = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
-            const uint32_t br = best_src ? best_src[id] : id;
+            br = best_src ? best_src[id] : id;
             best_out[i] = br;
             if (pk_best) pk_best[i] = br;
+        }
+        if (x.msg_out) {
+            x.msg_out[i] = key - x.image_offset;
+            if (x.with_best) x.msg_out[x.k_max + i] = (uint64_t)((int64_t)br + x.row_offset);
         }
     }
     if (t == 0) {
@@ -308,6 +321,16 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
                                            state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
         count_out[0] = out;
         if (state_or_null) count_out[1] = ovf;
+        if (x.msg_out) x.msg_out[x.msg_len - 1] = (uint64_t)(uint32_t)out | ((uint64_t)(uint32_t)ovf << 32);
+        if (x.from_msgs) {
+            long long any = 0;
+            for (int l = 0; l < n_lists; ++l) {
+                const long long f = (long long)(keys_in[(int64_t)l * list_stride + list_stride - 1] >> 32);
+                if (x.flags_out) x.flags_out[l] = f;
+                any |= f;
+            }
+            if (x.flags_seen) *x.flags_seen |= any;
+        }
         if (packed_or_null) {
             int32_t *hdr = reinterpret_cast<int32_t *>(packed_or_null);
             hdr[0] = out;
@@ -440,7 +463,7 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -481,7 +504,7 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
                        ws.cand, threshold);
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -501,7 +524,34 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,
                        (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr, (int)k, (const uint32_t *)nullptr, keys_out, count_out,
-                       (uint32_t *)nullptr, (unsigned char *)nullptr);
+                       (uint32_t *)nullptr, (unsigned char *)nullptr, FinalExchange());
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+// the merge side of the sharded exchange: the gathered messages themselves are the lists
+ssw_status launch_merge_msgs(const uint64_t *msgs, int32_t world, int32_t k_max, int32_t with_best, int32_t k,
+                             uint64_t *keys_out, int32_t *count_out, long long *flags_out, long long *flags_seen,
+                             hipStream_t stream) {
+    if (k < 1 || k > SSW_MAX_TOPK || k_max < k) {
+        set_error("merge: k=%d outside [1, min(%d, k_max = %d)]", k, SSW_MAX_TOPK, k_max);
+        return SSW_ERR_INVALID;
+    }
+    if (world < 1 || (int64_t)world * k > FINAL_CAP) {
+        set_error("merge: %d lists x %d keys exceed %d candidates", world, k, FINAL_CAP);
+        return SSW_ERR_INVALID;
+    }
+    FinalExchange x;
+    x.from_msgs = 1;
+    x.k_max = k_max;
+    x.with_best = with_best;
+    x.msg_len = (with_best ? 2 : 1) * k_max + 1;
+    x.flags_out = flags_out;
+    x.flags_seen = flags_seen;
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, msgs, (int)world,
+                       (int)x.msg_len, (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                       (int)k, (const uint32_t *)nullptr, keys_out, count_out, (uint32_t *)nullptr,
+                       (unsigned char *)nullptr, x);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

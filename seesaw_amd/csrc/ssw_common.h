@@ -151,8 +151,19 @@ ssw_status launch_gemm_pw4(int epi, hipStream_t stream, const void *A, const voi
 ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
                               hipStream_t stream);
 
+// side outputs / inputs of the selection's last kernel for the row-sharded exchange (select.hip, k_final)
+struct FinalExchange {
+    uint64_t *msg_out = nullptr;   // selection: this rank's message
+    uint64_t image_offset = 0;     // subtracted from the keys (globalises the image position in the low word)
+    int64_t row_offset = 0;        // added to the best rows
+    int32_t k_max = 0, with_best = 0, msg_len = 0;
+    int32_t from_msgs = 0;         // merge: the input lists are messages
+    long long *flags_out = nullptr, *flags_seen = nullptr;
+};
+
 // select.hip: exact top-k of per-image best scores.
 struct SelectWorkspace {
+    FinalExchange xchg;             // set by ssw_index_set_exchange_target
     // all device pointers
     uint32_t *hist1 = nullptr;      // [4096]
     uint32_t *hist2 = nullptr;      // [4096]
@@ -192,6 +203,9 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
 ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t list_stride,
                              const int32_t *counts, int32_t k, uint64_t *keys_out,
                              int32_t *count_out, hipStream_t stream);
+ssw_status launch_merge_msgs(const uint64_t *msgs, int32_t world, int32_t k_max, int32_t with_best, int32_t k,
+                             uint64_t *keys_out, int32_t *count_out, long long *flags_out, long long *flags_seen,
+                             hipStream_t stream);
 ssw_status launch_gather_f32(const float *src, const int64_t *idx_dev, int64_t n, float *dst,
                              hipStream_t stream);
 

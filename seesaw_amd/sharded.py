@@ -14,6 +14,7 @@ collective is latency-bound: one fused all_gather_into_tensor, never a ring of s
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -94,6 +95,60 @@ class ShardedTopK:
         self.flags_seen = torch.zeros(1, dtype=torch.int64, device=dev)    # OR over all exchanges since reset
         self.out_keys = torch.zeros(self.k_max, dtype=torch.int64, device=dev)
         self.out_count = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    # ---- fused form: no elementwise kernels around the collective ---------------------------------------
+    def attach(self, dev_index, row_offset: int = 0):
+        """have the index's selection write this rank's message itself (ssw_index_set_exchange_target): its last kernel
+        then leaves keys - image_offset, best rows + row_offset and count | overflow << 32 in send_buf"""
+        assert self.send_buf.is_cuda
+        _lib.call("ssw_index_set_exchange_target", dev_index._h, ctypes.c_void_p(self.send_buf.data_ptr()), self.k_max,
+                  int(self.with_best), self.image_offset, int(row_offset))
+        self._attached = dev_index
+        return self
+
+    def use_c_comm(self, unique_id: Optional[bytes] = None):
+        """route the all-gather through the library's own entry point (ssw_topk_allgather: ncclAllGather on the current
+        stream) instead of torch.distributed.  The 128-byte id comes from rank 0 (ssw_comm_unique_id) and is handed
+        to the other ranks through the default process group when there is one."""
+        torch = self.torch
+        if unique_id is None:
+            buf = (ctypes.c_char * 128)()
+            if self.rank == 0:
+                _lib.call("ssw_comm_unique_id", buf)
+            uid = bytes(buf)
+            if self.world > 1:
+                import torch.distributed as dist
+                t = torch.tensor(list(uid), dtype=torch.uint8, device=self.send_buf.device if dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.broadcast(t, src=0, group=self.group)
+                uid = bytes(t.cpu().tolist())
+        else:
+            uid = unique_id
+        self._comm = ctypes.c_void_p()
+        dev_index = self.send_buf.device.index if self.send_buf.is_cuda else 0
+        _lib.call("ssw_comm_create", int(dev_index), uid, self.rank, self.world, ctypes.byref(self._comm))
+        return self
+
+    def close_c_comm(self):
+        if getattr(self, "_comm", None):
+            _lib.call("ssw_comm_destroy", self._comm)
+            self._comm = None
+
+    def exchange_fused(self, k: int):
+        """the attached index has just run topk_dev(q, k): all-gather its message, merge (counts and overflow flags are
+        unpacked by the merge kernel) -> (out_keys, out_count).  Two launches + one collective, nothing else."""
+        torch = self.torch
+        assert getattr(self, "_attached", None) is not None, "attach(dev_index) first"
+        stream_ptr = torch.cuda.current_stream().cuda_stream
+        if getattr(self, "_comm", None):
+            _lib.call("ssw_topk_allgather", self._comm, ctypes.c_void_p(stream_ptr), ctypes.c_void_p(self.send_buf.data_ptr()),
+                      ctypes.c_void_p(self.all_buf.data_ptr()), self.msg_len)
+        else:
+            self.gather()
+        _lib.call("ssw_topk_merge_msgs_dev", int(self.all_buf.device.index), ctypes.c_void_p(stream_ptr),
+                  ctypes.c_void_p(self.all_buf.data_ptr()), self.world, self.k_max, int(self.with_best), int(k),
+                  ctypes.c_void_p(self.out_keys.data_ptr()), ctypes.c_void_p(self.out_count.data_ptr()),
+                  ctypes.c_void_p(self.flags.data_ptr()), ctypes.c_void_p(self.flags_seen.data_ptr()))
+        return self.out_keys, self.out_count
 
     def pack(self, local_keys, local_count, k: int, image_offset: Optional[int] = None, best_rows=None):
         """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys, local image positions);
@@ -203,12 +258,16 @@ class ShardedSyntheticIndex:
         self.xchg = ShardedTopK(rank=rank, world=world, device=self.device,
                                 image_offset=self.row_lo, k_max=k_max, group=group,
                                 force_collective=force_collective)
+        # the selection writes the message itself, the merge unpacks it: scan -> select -> all-gather -> merge
+        self.xchg.attach(self.local)
+        if os.environ.get("SSW_C_COMM"):  # the collective through the library's own RCCL entry point
+            self.xchg.use_c_comm()
 
     def topk_async(self, q_dev_ptr: int, k: int):
         """scan + local select + all-gather + merge, all enqueued on the current stream.  The overflow flags
         travel with the message; check `xchg.assert_no_overflow_seen()` after synchronising."""
         self.local.topk_dev(q_dev_ptr, k)
-        return self.xchg.exchange(self.local_keys, self.local_count, k)
+        return self.xchg.exchange_fused(k)
 
     def topk(self, q_dev_ptr: int, k: int):
         from .device_index import decode_keys
@@ -218,7 +277,9 @@ class ShardedSyntheticIndex:
         if over:  # the same list on every rank: the overflowing ones redo their selection exactly, all re-exchange
             if self.rank in over:
                 self.local.select_deep_dev(k)
-            keys, count = self.xchg.exchange(self.local_keys, self.local_count, k)
+            if self.rank not in over:  # (a repaired shard's deep selection rewrote its message; the others re-send theirs)
+                pass
+            keys, count = self.xchg.exchange_fused(k)
             self.torch.cuda.synchronize(self.device)
             assert not self.xchg.overflowed()
             self.xchg.reset_overflow_seen()
@@ -227,4 +288,5 @@ class ShardedSyntheticIndex:
         return imgs, scores
 
     def close(self):
+        self.xchg.close_c_comm()
         self.local.close()

@@ -30,6 +30,13 @@ def main():
     p_imgs, p_scores, _ = plain.topk(q, k)
     assert np.array_equal(imgs, p_imgs), "RCCL path differs from the plain index"
     assert np.array_equal(scores.view(np.uint32), p_scores.view(np.uint32))
+    # the same query with the collective issued by the library itself (ssw_comm_create / ssw_topk_allgather: RCCL bound
+    # by dlopen, ncclAllGather on the current stream) instead of torch.distributed
+    index.xchg.use_c_comm()
+    imgs2, scores2 = index.topk(q_dev.data_ptr(), k)
+    assert np.array_equal(imgs2, p_imgs) and np.array_equal(scores2.view(np.uint32), p_scores.view(np.uint32)), \
+        "ssw_topk_allgather path differs from the plain index"
+    index.xchg.close_c_comm()
     # a bare collective on device tensors too, so a failure points at RCCL rather than at the index
     t = torch.arange(8, dtype=torch.int64, device="cuda")
     out = torch.empty(8 * real_world, dtype=torch.int64, device="cuda")

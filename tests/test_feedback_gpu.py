@@ -109,16 +109,20 @@ def test_logreg_lossgrad_along_the_reference_trajectory():
 
 def test_multireg_fit_vs_reference_golden():
     """Fitted coefficients against the reference's (seeded) fits, in rank scores of the labelled rows.
-    The fixture holds the reference's result for 3 shuffle seeds: where the reference reproduces itself
-    (spread <= 3e-5) ours is held to 1e-4 of it; where it does not -- its L-BFGS stops on an f32-noisy
-    loss, so the stopping point moves with the summation order -- ours must lie within 1e-4 of the
-    reference's own cloud (distance to the nearest seed <= spread + 1e-4).  The HIP path rounds the
-    regulariser values to f32 exactly where torch does, so it walks the reference's path rather than
-    running on to the f64 minimiser (which the reference misses by up to 7e-4)."""
+    The fixture holds the reference's result for 3 shuffle seeds, and (multireg_det.npz) ONE deterministic end point
+    per case from the reference with its DataLoader shuffle switched off.  Where the reference reproduces itself
+    (spread <= 3e-5) ours is held to 1e-4 of it.  Where it does not -- its L-BFGS stops on an f32-noisy loss, so the
+    stopping point moves with the summation order -- the distance to the nearest of its runs is held to 1e-4 too, with
+    ONE exception that carries an explicit numeric ceiling: c6 (pairwise hinge on a poor query: a piecewise-linear
+    objective whose active set of pairs flips along the path; the reference's own runs are 6e-3 apart).  The HIP path
+    rounds the regulariser values to f32 exactly where torch does, so it walks the reference's path rather than running
+    on to the f64 minimiser (which the reference misses by up to 7e-4)."""
     import pandas as pd
     from oracle import feedback_oracle as fo
     from seesaw_amd.loops.multi_reg import RegModule
     g = np.load(os.path.join(GOLDEN, "multireg.npz"))
+    gd = np.load(os.path.join(GOLDEN, "multireg_det.npz"))
+    NEAREST_CEILING = {6: 3e-3}   # measured 1.4e-3 (round 3); every other case: TOL = 1e-4
     held_directly = 0
     for c in range(int(g["n_cases"])):
         X, y, img, q = g[f"c{c}_X"], g[f"c{c}_y"], g[f"c{c}_img"], g[f"c{c}_q"]
@@ -135,13 +139,14 @@ def test_multireg_fit_vs_reference_golden():
         spread = _seed_spread(Xc, seeds)
         nearest = min(_rank_scores(Xc, coeff, s_) for s_ in seeds)
         to_ref = _rank_scores(Xc, coeff, g[f"c{c}_coeff"])
-        print(f"multireg c{c} {lt}: |ours - reference| = {to_ref:.2e} (nearest seed {nearest:.2e}), "
-              f"reference's own seed spread {spread:.2e}")
+        to_det = _rank_scores(Xc, coeff, gd[f"c{c}_coeff"])
+        nearest = min(nearest, to_det)  # the shuffle-free run is one more run of the reference
+        print(f"multireg c{c} {lt}: |ours - reference| = {to_ref:.2e} (nearest of its runs {nearest:.2e}; its shuffle-free "
+              f"end point {to_det:.2e}), reference's own seed spread {spread:.2e}")
         if spread <= REPRODUCIBLE:
             held_directly += 1
             assert to_ref <= TOL, (c, to_ref)
-        else:
-            assert nearest <= spread + TOL, (c, nearest, spread)
+        assert nearest <= NEAREST_CEILING.get(c, TOL), (c, nearest, spread)
         if lt != "pairwise_rank_loss":  # smooth objectives: distance to the f64 minimiser, for the record
             opt = fo.multireg_optimum(X, y, img, q, g["xlx"], loss_type=lt, l_data=float(g[f"c{c}_data_lam"]),
                                       l_query=float(g[f"c{c}_query_lam"]))

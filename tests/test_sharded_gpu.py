@@ -7,6 +7,7 @@
   and repaired by the deep selection;
 * ShardedTopK.exchange over RCCL itself: a world-size-1 `nccl` process group launched through
   torch.distributed.run runs all_gather_into_tensor on device tensors on real hardware."""
+import ctypes
 import os
 import subprocess
 import sys
@@ -44,6 +45,62 @@ def _merge_shards(shards, offsets, q_dev, k, torch, k_max):
     out_keys, out_count = x.merge_gathered(k)
     torch.cuda.synchronize()
     return x, out_keys[: int(out_count.item())].cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("k,k_max", [(100, 128), (1024, 1024)])
+@pytest.mark.parametrize("sizes", [[25000] * 8, [1, 40000, 0, 700, 99999, 13, 30000, 29287]])
+def test_fused_message_path_equals_pack_and_merge(k, k_max, sizes):
+    """round 3: the selection's last kernel writes the rank's message itself (ssw_index_set_exchange_target) and the
+    merge kernel unpacks counts / overflow flags (ssw_topk_merge_msgs_dev) -- no torch elementwise kernels around the
+    collective.  Message by message and merged key by key identical to pack() + merge_gathered(); best rows too."""
+    import torch
+    from oracle import seesaw_oracle as orc
+    from seesaw_amd import _lib
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.sharded import ShardedTopK, _DevArray
+    seed = 91
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(int)
+    q_dev = torch.from_numpy(orc.synth_query(6)).cuda()
+    dev = torch.device("cuda", 0)
+    world = len(sizes)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = ShardedTopK(rank=0, world=world, device=dev, image_offset=0, k_max=k_max, with_best=True)
+    fused = ShardedTopK(rank=0, world=world, device=dev, image_offset=0, k_max=k_max, with_best=True)
+    ref.world = fused.world = 1
+    shards = []
+    for r, (n, off) in enumerate(zip(sizes, offsets)):
+        idx = DeviceIndex.synthetic(n, 512, seed=seed, first_row=int(off))
+        shards.append(idx)
+        idx.set_stream(stream)
+        one = ShardedTopK(rank=r, world=world, device=dev, image_offset=int(off), k_max=k_max, with_best=True)
+        one.attach(idx, row_offset=int(off))
+        idx.topk_dev(q_dev.data_ptr(), min(k, max(n, 1)) if n else k)
+        keys, count = _views(idx, torch)
+        _, _, best_ptr = idx.result_ptrs()
+        best = torch.as_tensor(_DevArray(best_ptr, (_lib.SSW_MAX_TOPK,), "<u4"), device=dev).to(torch.int64)
+        torch.cuda.synchronize()
+        if n == 0:  # an empty shard launches no selection: ssw_index_topk_dev zeroes its message's count word
+            assert int(one.send_buf[-1].item()) == 0
+            ref.all_buf[r] = ref.pack_empty()
+        else:
+            kk = min(k, n)
+            ref.all_buf[r] = ref.pack(keys, count, kk, image_offset=int(off), best_rows=best + int(off))
+            c = int(count[0].item())
+            assert torch.equal(one.send_buf[:c], ref.all_buf[r, :c])                       # keys
+            assert torch.equal(one.send_buf[k_max:k_max + c], ref.all_buf[r, k_max:k_max + c])  # best rows
+            assert int(one.send_buf[-1].item()) == int(ref.all_buf[r, -1].item())          # count | overflow << 32
+        fused.all_buf[r] = one.send_buf
+    want_keys, want_count = ref.merge_gathered(k)
+    _lib.call("ssw_topk_merge_msgs_dev", 0, ctypes.c_void_p(stream), ctypes.c_void_p(fused.all_buf.data_ptr()), world, k_max, 1, k,
+              ctypes.c_void_p(fused.out_keys.data_ptr()), ctypes.c_void_p(fused.out_count.data_ptr()),
+              ctypes.c_void_p(fused.flags.data_ptr()), ctypes.c_void_p(fused.flags_seen.data_ptr()))
+    torch.cuda.synchronize()
+    c = int(want_count.item())
+    assert int(fused.out_count.item()) == c == min(k, int(np.sum(sizes)))
+    assert torch.equal(fused.out_keys[:c], want_keys[:c])
+    assert int(fused.flags_seen.item()) == 0 and not fused.overflowed()
+    for s_ in shards:
+        s_.close()
 
 
 @pytest.mark.parametrize("k", [100, 1024])
