@@ -137,6 +137,10 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
 ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int64_t n,
                                    float *out_scores_host);
 
+/* the vectors of arbitrary rows, [n, dim] f32 (`index.vectors[rows]`: the labelled tiles the fitting loops read,
+ * seesaw/loops/multi_reg.py:204, loops/util.py:6,11), out of the resident matrix. */
+ssw_status ssw_index_gather_rows(ssw_index *idx, const int64_t *rows_host, int64_t n, float *out_host);
+
 /* scores of arbitrary rows against another vector, in the scan's summation order
  * (`vectors[ilocs] @ vector2`, multiscale_index.py:347-349). */
 ssw_status ssw_index_score_rows(ssw_index *idx, const float *q_host, const int64_t *rows_host,

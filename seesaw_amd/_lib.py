@@ -113,6 +113,7 @@ _SIGNATURES = {
     "ssw_clip_sync": (c_i32, [c_void_p]),
     "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "ssw_tune_gemm": (c_i32, [c_i32]),
+    "ssw_index_gather_rows": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ssw_index_set_exchange_target": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_i64, c_i64]),
     "ssw_topk_merge_msgs_dev": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_comm_unique_id": (c_i32, [c_void_p]),

@@ -705,6 +705,44 @@ ssw_status ssw_index_gather_scores(ssw_index *idx, const int64_t *rows_host, int
     return SSW_OK;
 }
 
+namespace {
+__global__ void k_gather_rows_f32(const float *__restrict__ X, const int64_t *__restrict__ rows, int64_t n, int dim,
+                                  float *__restrict__ out) {
+    const int64_t r = blockIdx.x;
+    const float4 *src = reinterpret_cast<const float4 *>(X + rows[r] * dim);
+    float4 *dst = reinterpret_cast<float4 *>(out + r * dim);
+    for (int c = threadIdx.x; c < dim / 4; c += blockDim.x) dst[c] = src[c];
+}
+}  // namespace
+
+// the vectors of arbitrary rows (`index.vectors[rows]`: what the fitting loops read of the labelled tiles,
+// multi_reg.py:204, loops/util.py:6,11) out of the resident matrix -- for callers that do not hold a host copy of it
+// (a rank of the row-sharded index serves its own rows this way)
+ssw_status ssw_index_gather_rows(ssw_index *idx, const int64_t *rows_host, int64_t n, float *out_host) {
+    SSW_REQUIRE(idx != nullptr, "idx is NULL");
+    if (n <= 0) return SSW_OK;
+    SSW_REQUIRE(rows_host != nullptr && out_host != nullptr, "NULL argument");
+    for (int64_t i = 0; i < n; ++i)
+        SSW_REQUIRE(rows_host[i] >= 0 && rows_host[i] < idx->n, "row %lld outside [0, %lld)", (long long)rows_host[i],
+                    (long long)idx->n);
+    DeviceGuard guard(idx->device);
+    SSW_TRY(stage_rows(idx, rows_host, n));
+    float *buf = nullptr;
+    SSW_HIP_TRY(hipMalloc((void **)&buf, (size_t)n * idx->dim * sizeof(float)));
+    hipLaunchKernelGGL(k_gather_rows_f32, dim3((unsigned)n), dim3(128), 0, idx->stream, idx->X, idx->gather_idx, n,
+                       (int)idx->dim, buf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out_host, buf, (size_t)n * idx->dim * sizeof(float), hipMemcpyDeviceToHost, idx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(idx->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) {
+        set_error("ssw_index_gather_rows: %s", hipGetErrorString(e));
+        return SSW_ERR_HIP;
+    }
+    return SSW_OK;
+}
+
 ssw_status ssw_topk_merge_dev(int32_t device, void *hip_stream, const uint64_t *dev_keys_in,
                               int32_t n_lists, int32_t list_stride, const int32_t *dev_counts,
                               int32_t k, uint64_t *dev_keys_out, int32_t *dev_count_out) {

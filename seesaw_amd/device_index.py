@@ -151,6 +151,13 @@ class DeviceIndex:
         _lib.call("ssw_index_gather_scores", self._h, _ptr(rows), rows.shape[0], _ptr(out))
         return out
 
+    def gather_rows(self, rows: np.ndarray) -> np.ndarray:
+        """`vectors[rows]` [n, dim] f32 out of the resident matrix"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((rows.shape[0], self.dim), dtype=np.float32)
+        _lib.call("ssw_index_gather_rows", self._h, _ptr(rows), rows.shape[0], _ptr(out))
+        return out
+
     def score_rows(self, q: np.ndarray, rows: np.ndarray) -> np.ndarray:
         """`vectors[rows] @ q` on the device, same summation order as the scan."""
         q = self._query(q)

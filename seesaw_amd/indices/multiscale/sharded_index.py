@@ -73,8 +73,18 @@ class DeviceShard:
         self.index.select_deep_dev(k)
         return self.keys, self.count, self.best.to(self.torch.int64) & 0xFFFFFFFF
 
-    def rescore_avg(self, local_positions, aug_larger, minus):
-        return self.index.rescore_avg(local_positions, aug_larger, minus)
+    def select_scores(self, row_scores: np.ndarray, k: int, excluded_local: np.ndarray):
+        """top-k of the slice by caller-supplied per-row scores (f32, -inf = skip): the label-propagation ranking"""
+        self.index.set_excluded(excluded_local)
+        self.index.load_scores(row_scores)
+        self.index.topk_dev(0, k)
+        return self.keys, self.count, self.best.to(self.torch.int64) & 0xFFFFFFFF
+
+    def rows(self, rows_local):
+        return self.index.gather_rows(rows_local)
+
+    def rescore_avg(self, local_positions, aug_larger, minus, aug_weight="level_max"):
+        return self.index.rescore_avg(local_positions, aug_larger, minus, aug_weight=aug_weight)
 
     def tile_scores(self, rows_local):
         return self.index.gather_scores(rows_local)
@@ -89,6 +99,36 @@ class DeviceShard:
         self.index.close()
 
 
+class _ShardedRows:
+    """`index.vectors` of a sharded index built without the full host array: what the loops read of it --
+    `.shape`, `vectors[rows]` (multi_reg.py:204, loops/util.py:6,11, rocchio_update.py:24) -- served from the shards.
+    `vectors[rows]` is a COLLECTIVE (every rank runs the same session and asks for the same rows)."""
+
+    def __init__(self, index, dim):
+        self._index, self.shape, self.dtype, self.ndim = index, (index.vector_meta.shape[0], dim), np.dtype(np.float32), 2
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        """the whole matrix on this rank (COLLECTIVE; N x 2 KB): only the one-off X'LX of the data regulariser asks
+        for it (loops/graph_based.py compute_xlx), which every rank then forms redundantly on its own GPU"""
+        out = self._index.gather_rows(np.arange(self.shape[0], dtype=np.int64))
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+    def __getitem__(self, rows):
+        if isinstance(rows, tuple):
+            raise TypeError("a sharded index serves whole rows: vectors[rows]")
+        if isinstance(rows, slice):
+            rows = np.arange(*rows.indices(self.shape[0]))
+        rows = np.asarray(rows)
+        if rows.dtype == bool:
+            rows = np.flatnonzero(rows)
+        one = rows.ndim == 0
+        out = self._index.gather_rows(rows.reshape(-1).astype(np.int64))
+        return out[0] if one else out
+
+
 class ShardedMultiscaleIndex(MultiscaleIndex):
     def __init__(self, *, embedding, vectors: Optional[np.ndarray], vector_meta: pd.DataFrame, rank: int, world: int,
                  local_vectors: Optional[np.ndarray] = None, device: int = 0, group=None, k_max: int = 1024,
@@ -99,11 +139,14 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         self.rank, self.world, self.group = int(rank), int(world), group
         self._k_max, self._comm_device, self._shard_factory, self._merge = int(k_max), comm_device, shard_factory, merge
         self._local_vectors = local_vectors
+        serve_rows = vectors is None
         if vectors is None:
             assert local_vectors is not None
             vectors = np.zeros((vector_meta.shape[0], 0), dtype=np.float32)  # placeholder: meta only
         super().__init__(embedding=embedding, vectors=vectors, vector_meta=vector_meta, vec_index=None, path=path,
                          excluded=excluded, device=device)
+        if serve_rows:  # no rank holds the matrix: `index.vectors[rows]` gathers from the owning shards
+            self.vectors = _ShardedRows(self, int(local_vectors.shape[1]))
 
     @staticmethod
     def row_range(vector_meta: pd.DataFrame, world: int, rank: int):
@@ -134,7 +177,15 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
 
     # ---- stage 1 ------------------------------------------------------------------------
     def _prelim(self, *, vector, topk_dbidx, exclude_dbidx=None, force_exact=False):
-        import torch
+        cand = self._select_and_exchange(lambda shard, k_local, mine: shard.select(vector, k_local, mine), topk_dbidx,
+                                         exclude_dbidx)
+        if not isinstance(cand, tuple):
+            self._resident_q = np.asarray(vector, dtype=np.float32).reshape(-1).copy()
+        return cand
+
+    def _select_and_exchange(self, select, topk_dbidx, exclude_dbidx, keep_finite=False):
+        """local selection (select(shard, k_local, excluded_local) -> keys, (count, overflow), best local rows),
+        one all-gather of the messages, merge on every rank -> _Candidates (or the empty triple)"""
         excl_pos = self._excluded_positions(exclude_dbidx)
         n_included = self._dbidx.shape[0] - excl_pos.shape[0]
         k = min(int(topk_dbidx), n_included)
@@ -146,7 +197,7 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         x = self._xchg
         if self._shard is not None:
             k_local = min(k, self.n_local_images)
-            keys, count, best = self._shard.select(vector, k_local, mine)
+            keys, count, best = select(self._shard, k_local, mine)
             x.pack(keys, count, k_local, best_rows=best + self.row_lo)
         else:
             x.pack_empty()
@@ -166,20 +217,66 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         merged = out_keys[:c].cpu().numpy().view(np.uint64)
         pos, scores = decode_keys(merged)
         best_rows = x.best_rows_of(merged)
-        self._resident_q = np.asarray(vector, dtype=np.float32).reshape(-1).copy()
+        if keep_finite:  # images whose every row was skipped (score -inf) do not take part
+            keep = np.isfinite(scores)
+            pos, scores, best_rows = pos[keep], scores[keep], best_rows[keep]
         return _Candidates(self._dbidx[pos], scores, pos, best_rows)
+
+    def topk_from_scores(self, row_scores, *, topk_dbidx, exclude_dbidx=None, skip_rows=None):
+        """the selection by caller-supplied per-row scores (the label-propagation ranking, graph_based.py:88-98): every rank
+        holds the whole score vector (the propagation is replicated), loads its slice and takes part in the usual exchange"""
+        s = np.asarray(row_scores, dtype=np.float32).copy()
+        if skip_rows is not None:
+            s[skip_rows] = -np.inf
+        local = s[self.row_lo:self.row_hi]
+        self._resident_q = None
+        cand = self._select_and_exchange(lambda shard, k_local, mine: shard.select_scores(local, k_local, mine), topk_dbidx,
+                                         exclude_dbidx, keep_finite=True)
+        if isinstance(cand, tuple):
+            return _Candidates(np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.int64), np.zeros(0, np.int64))
+        return cand
+
+    topk_from_device_scores = None  # (the propagated scores of a graph loop reach a sharded index through the host)
 
     # ---- stage 2 ------------------------------------------------------------------------
     def _owned(self, positions: np.ndarray) -> np.ndarray:
         return positions[(positions >= self.img_lo) & (positions < self.img_hi)]
 
+    def _comm_tensor_device(self):
+        import torch
+        if self._comm_device is not None:
+            return torch.device(self._comm_device)
+        return torch.device("cuda", self.device) if self._shard_factory is DeviceShard else torch.device("cpu")
+
+    def _all_gather_f64(self, vec: np.ndarray, cap: int):
+        """fixed-size tensor collective: every rank contributes <= cap float64 values -> list of per-rank arrays.
+        (One all_gather_into_tensor of world x (cap + 1) doubles; under RCCL an object collective would pickle, stage
+        through byte tensors and run two collectives.)"""
+        import torch
+        import torch.distributed as dist
+        n = int(vec.shape[0])
+        assert n <= cap, (n, cap)
+        msg = np.zeros(cap + 1, dtype=np.float64)
+        msg[0] = n
+        msg[1:1 + n] = vec
+        dev = self._comm_tensor_device()
+        send = torch.from_numpy(msg).to(dev)
+        recv = torch.empty(self.world * (cap + 1), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        out = recv.cpu().numpy().reshape(self.world, cap + 1)
+        return [out[r, 1:1 + int(out[r, 0])] for r in range(self.world)]
+
     def _gather_stage2(self, own_pos, own_scores, own_rows, all_positions):
         """(score, tile row) of every candidate image, computed on its owner, known to every rank afterwards"""
         mine = (np.asarray(own_pos, np.int64), np.asarray(own_scores, np.float32), np.asarray(own_rows, np.int64))
         if self.world > 1:
-            import torch.distributed as dist
-            parts = [None] * self.world
-            dist.all_gather_object(parts, mine, group=self.group)
+            # positions, scores (f32) and rows (< 2^53) are exact in float64: one fixed-size message per rank
+            cap = int(all_positions.shape[0])
+            flat = np.concatenate([mine[0].astype(np.float64), mine[1].astype(np.float64), mine[2].astype(np.float64)])
+            parts = []
+            for v in self._all_gather_f64(flat, 3 * cap):
+                m = v.shape[0] // 3
+                parts.append((v[:m].astype(np.int64), v[m:2 * m].astype(np.float32), v[2 * m:].astype(np.int64)))
         else:
             parts = [mine]
         pos = np.concatenate([p[0] for p in parts])
@@ -187,7 +284,7 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         assert np.array_equal(pos[order], all_positions), "every candidate image has exactly one owner"
         return np.concatenate([p[1] for p in parts])[order], np.concatenate([p[2] for p in parts])[order]
 
-    def _rescore_avg_on_device(self, candidate_df, topk, aug_larger, vector2=None):
+    def _rescore_avg_on_device(self, candidate_df, topk, aug_larger, vector2=None, aug_weight="level_max"):
         positions = np.sort(np.asarray(candidate_df.attrs["positions"], dtype=np.int64))
         own = self._owned(positions)
         scores, rows = np.zeros(0, np.float32), np.zeros(0, np.int64)
@@ -195,7 +292,7 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
             minus = None
             if vector2 is not None:
                 minus = self._shard.score_rows(vector2, self._candidate_rows(own) - self.row_lo)
-            scores, rows = self._shard.rescore_avg(own - self.img_lo, aug_larger, minus)
+            scores, rows = self._shard.rescore_avg(own - self.img_lo, aug_larger, minus, aug_weight)
             rows = rows + self.row_lo
         scores, rows = self._gather_stage2(own, scores, rows, positions)
         top = np.argsort(-scores.astype(np.float64))[:topk]
@@ -234,9 +331,10 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
             if vector2 is None:
                 return self._activations_from_best(candidate_df, topk)
             return self._plain_vector2(candidate_df, topk, vector2)
-        if kwargs.get("aug_weight", "level_max") != "level_max" or not self._has_tile_meta:
-            raise NotImplementedError("the sharded index aggregates with aug_weight='level_max' over float32 tile boxes")
-        return self._rescore_avg_on_device(candidate_df, topk, kwargs["aug_larger"], vector2)
+        if not self._has_tile_meta:
+            raise NotImplementedError("the sharded index aggregates over float32 tile boxes with zoom levels <= 31")
+        return self._rescore_avg_on_device(candidate_df, topk, kwargs["aug_larger"], vector2,
+                                           aug_weight=kwargs.get("aug_weight", "level_max"))
 
     # ---- the rest of the interface --------------------------------------------------------
     def score(self, vec):
@@ -245,15 +343,36 @@ class ShardedMultiscaleIndex(MultiscaleIndex):
         mine = self._shard.scores(vec) if self._shard is not None else np.zeros(0, np.float32)
         if self.world == 1:
             return mine
+        import torch
         import torch.distributed as dist
-        parts = [None] * self.world
-        dist.all_gather_object(parts, mine, group=self.group)
-        return np.concatenate(parts)
+        # every rank's row range is known everywhere (shard_bounds_by_image): one padded tensor collective
+        bounds = [shard_bounds_by_image(self._row_start, self.world, r) for r in range(self.world)]
+        cap = max(b[3] - b[2] for b in bounds)
+        dev = self._comm_tensor_device()
+        send = torch.zeros(cap, dtype=torch.float32, device=dev)
+        send[:mine.shape[0]] = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.float32)).to(dev)
+        recv = torch.empty(self.world * cap, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        out = recv.cpu().numpy().reshape(self.world, cap)
+        return np.concatenate([out[r, :bounds[r][3] - bounds[r][2]] for r in range(self.world)])
 
-    def topk_from_scores(self, *a, **k):
-        raise NotImplementedError("ranking by caller-supplied scores (label propagation) runs on the unsharded index")
-
-    topk_from_device_scores = topk_from_scores
+    def gather_rows(self, rows) -> np.ndarray:
+        """`vectors[rows]` [m, dim] on every rank without a host copy of the matrix anywhere: each rank reads the rows it
+        owns out of its shard (ssw_index_gather_rows), the others' places stay zero, one all-reduce(sum) fills them in
+        (x + 0 + ... + 0 is exact).  COLLECTIVE: every rank calls it with the same rows."""
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        dim = self.vectors.shape[1]
+        out = np.zeros((rows.shape[0], dim), dtype=np.float32)
+        own = (rows >= self.row_lo) & (rows < self.row_hi)
+        if own.any() and self._shard is not None:
+            out[own] = self._shard.rows(rows[own] - self.row_lo)
+        if self.world > 1 and rows.shape[0]:
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(out).to(self._comm_tensor_device())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            out = t.cpu().numpy()
+        return out
 
     def subset(self, indices):
         raise NotImplementedError("subset of a sharded index")

@@ -106,7 +106,8 @@ class KnnProp2(LoopBase):
         """next images by propagated score: unlabelled vectors only, distinct non-returned
         images, then the usual per-image aggregation (graph_based.py:88-109)."""
         model, p, q = self.state.knn_model, self.params, self.q
-        resident = getattr(model, "scores_on_device", lambda: False)() and hasattr(q.index, "topk_from_device_scores")
+        resident = getattr(model, "scores_on_device", lambda: False)() and \
+            callable(getattr(q.index, "topk_from_device_scores", None))
         avg_on_device = resident and p.agg_method != "plain_score" and getattr(q.index, "_has_tile_meta", False) \
             and getattr(p, "aug_weight", None) in (None, "level_max") and hasattr(q.index, "rescore_avg_from_device_scores")
         on_device = resident and (p.agg_method == "plain_score" or avg_on_device)

@@ -36,7 +36,20 @@ class OracleShard:
 
     select_deep = None
 
-    def rescore_avg(self, local_positions, aug_larger, minus):
+    def select_scores(self, row_scores, k, excluded_local):
+        self._scores = np.asarray(row_scores, dtype=np.float32)
+        ids, sc, rows = orc.topk_images_tiebreak(self._scores, self.r2i, self.n_images, list(excluded_local), k)
+        keys = torch.zeros(K_BUF, dtype=torch.int64)
+        keys[: ids.shape[0]] = torch.from_numpy(encode_keys(sc, ids).view(np.int64).copy())
+        best = torch.zeros(K_BUF, dtype=torch.int64)
+        best[: ids.shape[0]] = torch.from_numpy(np.asarray(rows, dtype=np.int64))
+        return keys, torch.tensor([ids.shape[0], 0], dtype=torch.int32), best
+
+    def rows(self, rows_local):
+        return self.X[np.asarray(rows_local, dtype=np.int64)]
+
+    def rescore_avg(self, local_positions, aug_larger, minus, aug_weight="level_max"):
+        assert aug_weight == "level_max"
         scores, rows, off = [], [], 0
         for p in local_positions:
             a, b = self.row_start[p], self.row_start[p + 1]

@@ -70,6 +70,16 @@ def _worker(rank, world, port, tmpdir):
     res = pindex.query(vector=pq, vector2=orc.synth_query(pseed + 1), topk=10, shortlist_size=50, exclude=BitMap(),
                        force_exact=True, agg_method="avg_score", aug_larger="greater", rescore_method=None)
     out["avg_v2_dbidxs"], out["avg_v2_acts"] = np.asarray(res["dbidxs"]), _acts(res)
+    # round 3: rows served from the owning shards (no rank holds the matrix), ranking by caller-supplied scores
+    cut = ShardedMultiscaleIndex.row_range(pmeta, world, 0)[1]  # the same rows on every rank: gather_rows is a collective
+    rows = np.array([0, 5, cut - 1, cut, PX.shape[0] - 1, 17, 17])
+    out["rows_ok"] = np.asarray(np.array_equal(pindex.vectors[rows], PX[rows]) and pindex.vectors.shape == PX.shape
+                                and np.array_equal(np.asarray(pindex.vectors), PX))
+    fake = np.sin(np.arange(PX.shape[0], dtype=np.float64) * 0.37)  # any per-row score every rank agrees on
+    skip = np.zeros(PX.shape[0], dtype=bool)
+    skip[::7] = True
+    cand = pindex.topk_from_scores(fake, topk_dbidx=20, exclude_dbidx=BitMap(pmeta.dbidx.values[:40]), skip_rows=skip)
+    out["tfs_pos"], out["tfs_scores"], out["tfs_rows"] = cand.attrs["positions"], np.asarray(cand.max_score), cand.attrs["best_rows"]
     # the full score vector, assembled from the slices
     out["score_head"] = pindex.score(pq)[:64]
     out["score_len"] = np.asarray(pindex.score(pq).shape[0])
@@ -101,7 +111,18 @@ def test_two_rank_sharded_index_matches_reference(tmp_path, oracle):
             assert np.array_equal(r[k][f"{tag}_acts"][:, :5], ref[:, :5]), (k, tag)
             assert np.abs(r[k][f"{tag}_acts"][:, 5] - ref[:, 5]).max() <= 1e-6
         assert int(r[k]["score_len"]) == g["pyr_meta"].shape[0]
+        assert bool(r[k]["rows_ok"])
     assert np.array_equal(r[0]["score_head"], r[1]["score_head"])
+    # topk_from_scores: both ranks agree, and agree with the selection on the unsharded arrays
+    pm = g["pyr_meta"]
+    fake = np.sin(np.arange(pm.shape[0], dtype=np.float64) * 0.37).astype(np.float32)
+    fake[::7] = -np.inf
+    dbidx, r2i = np.unique(pm[:, 0].astype(np.int64), return_inverse=True)
+    excl = np.searchsorted(dbidx, np.unique(pm[:40, 0].astype(np.int64)))
+    ids, sc, rows = oracle.topk_images_tiebreak(fake, r2i, dbidx.shape[0], list(excl), 20)
+    for k in range(2):
+        assert np.array_equal(r[k]["tfs_pos"], ids) and np.array_equal(r[k]["tfs_rows"], rows)
+        assert np.array_equal(r[k]["tfs_scores"].astype(np.float32), sc)
 
 
 def test_shard_bounds_by_image_cover_and_balance():

@@ -116,3 +116,82 @@ def test_world_size_1_equals_unsharded(oracle):
             assert np.array_equal(ra["dbidxs"], rb["dbidxs"])
             assert np.array_equal(_acts(ra), _acts(rb))
     b.close()
+
+
+def _session_worker(rank, world, port, tmpdir):
+    """whole feedback sessions over the sharded index: no rank holds the matrix (vectors=None), the fitting loops read
+    the labelled rows through index.vectors[rows] = gather_rows (owning shard + all-reduce), the graph loop ranks
+    through topk_from_scores on the shards"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    import io
+    import json
+    import torch
+    torch.cuda.set_device(0)
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.indices.multiscale.sharded_index import ShardedMultiscaleIndex
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import Session
+    from seesaw_amd.synthetic import GlobalDataManager, make_dataset
+    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
+    spec = json.loads(str(g["datasets"]))["A"]
+    ds = make_dataset("lvis", knn_k=10, **spec["make"])
+    ds.embedding.noise = spec["noise"]
+    gdm = GlobalDataManager().add(ds)
+    boxes, _ = ds.load_ground_truth()
+    graph = ds.knn_graph()
+    matrix = dict(knn_path="nndescent60", symmetric=True, self_edges=False, normalized_weights=False, knn_k=10, edist=0.05)
+    options = {
+        "plain": None,
+        "multi_reg_data": dict(label_loss_type="pairwise_rank_loss", rank_loss_margin=0.2, use_qvec_norm=None,
+                               reg_data_lambda=1000.0, reg_norm_lambda=100.0, reg_query_lambda=10.0, verbose=False,
+                               max_iter=100, pos_weight="balanced", lr=1.0, matrix_options=matrix),
+        "knn_prop2": dict(matrix_options=matrix, normalize_scores=False, sigmoid_before_propagate=True, calib_a=10.0,
+                          calib_b=-0.4, prior_weight=1.0),
+    }
+    lo, hi = ShardedMultiscaleIndex.row_range(ds.vector_meta, world, rank)
+    out = {}
+    for name, opts in options.items():
+        index = ShardedMultiscaleIndex(embedding=ds.embedding, vectors=None, local_vectors=ds.vectors[lo:hi],
+                                       vector_meta=ds.vector_meta, rank=rank, world=world, device=0, comm_device="cpu",
+                                       k_max=128)
+        index.knng = {n_: graph for n_ in ("exact", "nndescent60", "")}
+        # gather_rows against the host array (which this rank would not have in production)
+        cut = ShardedMultiscaleIndex.row_range(ds.vector_meta, world, 0)[1]  # the same rows on every rank (a collective)
+        rows = np.array([0, 7, cut - 1, cut, ds.vectors.shape[0] - 1, 7])
+        assert np.array_equal(index.vectors[rows], ds.vectors[rows]) and index.vectors.shape == ds.vectors.shape
+        interactive = "multi_reg" if name.startswith("multi_reg") else name
+        p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale", c_name=None), interactive=interactive,
+                          interactive_options=opts, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                          batch_size=1, start_policy="from_start" if name == "knn_prop2" else "after_first_batch",
+                          index_options={"use_vec_index": False})
+        b = BenchParams(name=name, ground_truth_category="c1", qstr="a c1", n_batches=25, max_results=10)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            session = Session(gdm, ds, index, p)
+            res = benchmark_loop(session=session, box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+        out[f"{name}_shown"] = np.concatenate([np.asarray(a, dtype=np.int64).reshape(-1) for a in session.acc_indices])
+        out[f"{name}_nfound"] = np.asarray(res["nfound"])
+        index.close()
+    np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sessions_over_the_sharded_index_match_reference(tmp_path):
+    """plain / multi_reg (data + query regularisers) / knn_prop2 sessions over a two-rank sharded index built WITHOUT a
+    host copy of the matrix return, on every rank, the reference's own sessions (tests/golden/bench_loop.npz)"""
+    port = 29950 + os.getpid() % 1000
+    mp.spawn(_session_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
+    for k in range(2):
+        r = np.load(tmp_path / f"rank{k}.npz")
+        for name in ("plain", "multi_reg_data", "knn_prop2"):
+            assert np.array_equal(r[f"{name}_shown"], g[f"{name}_shown"]), (k, name, r[f"{name}_shown"].tolist(),
+                                                                            g[f"{name}_shown"].tolist())
+            assert int(r[f"{name}_nfound"]) == int(g[f"{name}_nfound"])
