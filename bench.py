@@ -236,8 +236,23 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
             from seesaw_amd.knn_graph import get_weight_matrix, rbf_kernel
             from seesaw_amd.label_propagation import LabelPropagation
             with contextlib.redirect_stdout(io.StringIO()):
-                W = get_weight_matrix(ds.knn_graph().restrict_k(k=10).knn_df, kfun=rbf_kernel(0.05), self_edges=False,
-                                      normalized=False, symmetric=True)
+                knn_df = ds.knn_graph().restrict_k(k=10).knn_df
+                # get_weight_matrix (knn_graph.py:31-104), the one-off O(nnz) pass between the graph and the sweeps:
+                # assembled on the device (csrc/wmatrix.hip) next to the reference's scipy form on the host cores
+                get_weight_matrix(knn_df, kfun=rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True, device=device)
+                tw = time.perf_counter()
+                W = get_weight_matrix(knn_df, kfun=rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True,
+                                      device=device)
+                t_wm_dev = time.perf_counter() - tw
+                tw = time.perf_counter()
+                W_host = get_weight_matrix(knn_df, kfun=rbf_kernel(0.05), self_edges=False, normalized=False, symmetric=True)
+                t_wm_host = time.perf_counter() - tw
+                res["weight_matrix"] = {"nodes": int(W.shape[0]), "nnz": int(W.nnz), "device_s": t_wm_dev, "host_scipy_s": t_wm_host,
+                                        "identical_arrays": bool(np.array_equal(W.indptr, W_host.indptr) and
+                                                                 np.array_equal(W.indices, W_host.indices) and
+                                                                 np.array_equal(W.data, W_host.data)),
+                                        "note": "device_s includes the host-side exp(), the uploads and the copy back"}
+                del W_host
                 lp = LabelPropagation(W, reg_lambda=1.0, max_iter=1, epsilon=-1.0, device=device)
                 prior = np.full(W.shape[0], 0.5)
                 ids, vals = np.arange(0, 1000, dtype=np.int64), (np.arange(1000) % 2).astype(np.float64)

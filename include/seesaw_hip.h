@@ -263,6 +263,19 @@ ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t m
 /* device address of the [n] f64 result of the last propagation (valid until the next run on this handle). */
 ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores);
 
+/* The symmetric k-NN weight matrix on the device: get_weight_matrix(symmetric=True) (seesaw/knn_graph.py:31-104) from
+ * the directed edge list src / dst [n_edges] i32 and w [n_edges] f64 = kfun(distance) (formed by the caller on the host:
+ * exp() rounds as numpy's) -> CSR with sorted indices, W_ij = (sum over the directions present) / (their number), the
+ * diagonal stored as 0.  Bit-identical to the reference's arrays (one commutative addition, one division per entry).
+ * SSW_ERR_UNSUPPORTED: a vertex with more than 4096 incident edges, or a vertex pair with more than two edges (repeated
+ * edges: the host path then decides the sum order).  ssw_wm_fetch copies indptr [n + 1] i64, indices [nnz] i32, data [nnz]
+ * f64 to the host. */
+typedef struct ssw_wm ssw_wm;
+ssw_status ssw_wm_build_symmetric(int32_t device, int64_t n, int64_t n_edges, const int32_t *src_host,
+                                  const int32_t *dst_host, const double *w_host, ssw_wm **out, int64_t *out_nnz);
+ssw_status ssw_wm_fetch(ssw_wm *m, int64_t *indptr_host, int32_t *indices_host, double *data_host);
+ssw_status ssw_wm_destroy(ssw_wm *m);
+
 /* Exact k-NN graph over the resident matrix (rows as vertices, cosine / dot similarity):
  * replaces compute_exact_knn, seesaw/knn_graph.py:170-191 (`1 - X @ X.T`, argsort, first k+1).
  * out_dst / out_score are [n_rows, k+1]: per row the k+1 best rows INCLUDING the row itself,

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libseesaw_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip.h")
 
 SSW_OK = 0
+SSW_ERR_INVALID, SSW_ERR_HIP, SSW_ERR_NOMEM, SSW_ERR_UNSUPPORTED, SSW_ERR_NUMERIC = -1, -2, -3, -4, -5
 SSW_MAX_TOPK = 4096
 
 
@@ -113,6 +114,9 @@ _SIGNATURES = {
     "ssw_clip_sync": (c_i32, [c_void_p]),
     "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "ssw_tune_gemm": (c_i32, [c_i32]),
+    "ssw_wm_build_symmetric": (c_i32, [c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
+    "ssw_wm_fetch": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ssw_wm_destroy": (c_i32, [c_void_p]),
     "ssw_index_gather_rows": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ssw_index_set_exchange_target": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_i64, c_i64]),
     "ssw_topk_merge_msgs_dev": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -52,7 +52,7 @@ def compute_xlx(laplacian, X_vectors: np.ndarray, device_index=None) -> np.ndarr
 
 
 def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vectors=None, knng: KNNGraph = None,
-                         device_index=None):
+                         device_index=None, device=None):
     key = opts.model_dump_json()
     if opts.xlx_matrix:
         assert opts.symmetric and not opts.self_edges
@@ -61,7 +61,8 @@ def lookup_weight_matrix(opts: WeightMatrixOptions, *, use_cache: bool, X_vector
     print(f"init weight matrix {opts=}")
     graph = (knng if knng is not None else KNNGraph.from_file(opts.knn_path)).restrict_k(k=opts.knn_k)
     wm = get_weight_matrix(graph.knn_df, kfun=rbf_kernel(opts.edist), self_edges=opts.self_edges,
-                           normalized=opts.normalized_weights, symmetric=opts.symmetric, laplacian=opts.xlx_matrix)
+                           normalized=opts.normalized_weights, symmetric=opts.symmetric, laplacian=opts.xlx_matrix,
+                           device=device)  # the symmetric assembly runs on the index's GPU (csrc/wmatrix.hip)
     if opts.xlx_matrix:
         assert X_vectors is not None
         wm = compute_xlx(wm, X_vectors, device_index=device_index)
@@ -80,7 +81,9 @@ def get_weight_matrix_from_index(idx, weight_matrix_options, xlx_matrix=False):
         opts.knn_path = f"mem:{id(idx)}:{opts.knn_path}"
     use_cache = opts.knn_path.find("subset") == -1
     return lookup_weight_matrix(opts, use_cache=use_cache, X_vectors=idx.vectors, knng=knng,
-                                device_index=getattr(idx, "_dev", None) if xlx_matrix else None)
+                                device_index=getattr(idx, "_dev", None) if xlx_matrix else None,
+                                device=getattr(idx, "device", None) if (getattr(idx, "_dev", None) is not None or
+                                                                        getattr(idx, "_shard", None) is not None) else None)
 
 
 def get_label_prop(q, label_prop_params):

@@ -118,11 +118,17 @@ def benchmark_loop(*, session: Session, subset: FrozenBitMap, box_data: pd.DataF
             break
         # get_state() builds fresh Imdata records every call and fill_imdata works on a copy,
         # so the reference's deepcopy of the whole state (seesaw_bench.py:325) is not needed
-        s = session.get_state()
-        last_batch = s.gdata[-1]
-        for j, imdata in enumerate(last_batch):
-            last_batch[j] = fill_imdata(imdata, box_data, b, _groups=groups)
-        session.update_state(s)
+        if hasattr(session, "update_last_batch") and not os.environ.get("SSW_BENCH_FULL_STATE"):
+            # only the batch just shown changes: same bookkeeping as get_state() + update_state() below, without
+            # rebuilding every earlier batch on every round (seesaw_session.py)
+            last_batch = [fill_imdata(imdata, box_data, b, _groups=groups) for imdata in session.last_batch()]
+            session.update_last_batch(last_batch)
+        else:
+            s = session.get_state()
+            last_batch = s.gdata[-1]
+            for j, imdata in enumerate(last_batch):
+                last_batch[j] = fill_imdata(imdata, box_data, b, _groups=groups)
+            session.update_state(s)
         total_results += int(sum(is_image_accepted(im) for im in last_batch))
         total_seen += len(idxbatch)
         if total_results >= max_results:

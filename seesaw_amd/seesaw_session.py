@@ -86,6 +86,44 @@ class Session:
         if self._check_reversals():
             self.loop.set_reversals()
 
+    # ---- the last batch only ---------------------------------------------------------------------------------
+    # benchmark_loop's simulated user labels the batch it was just shown and never revisits an earlier one, yet
+    # get_state() / update_state() (the web client's protocol, kept above) rebuild every batch so far on every round:
+    # O(rounds) records, bitmap copies and label-db writes per round.  These two do the same bookkeeping for the
+    # last batch alone; every set / label / change list ends up identical (tests: the reference's session sequences).
+    def last_batch(self):
+        """the Imdata records of the batch next() just returned (what get_state().gdata[-1] holds)"""
+        prefill = self.params.annotation_category is not None
+        return self.get_panel_data(idxbatch=self.acc_indices[-1], activation_batch=self.acc_activations[-1], prefill=prefill)
+
+    def update_last_batch(self, batch):
+        """update_state() for a state in which only the last batch changed"""
+        seen, accepted, put = self.seen, self.accepted, self.q.label_db.put
+        change = []
+        for imdata in batch:
+            dbidx = imdata.dbidx
+            self.image_timing[dbidx] = imdata.timing
+            new_seen = dbidx not in seen
+            if new_seen:
+                seen.add(dbidx)
+            acc = is_image_accepted(imdata)
+            new_acc = acc and dbidx not in accepted
+            if new_acc:
+                accepted.add(dbidx)
+            put(dbidx, imdata.boxes)
+            if new_seen or new_acc:
+                change.append((dbidx, 1 if new_acc else 0))
+            # reversal = an accepted image shown after a rejected one (sticky: earlier verdicts do not change here)
+            rev = self.__dict__.setdefault("_rev", [False, False])  # [a rejected image was shown, reversal seen]
+            if acc and rev[0]:
+                rev[1] = True
+            elif not acc:
+                rev[0] = True
+        self._last_change = sorted(change)  # ascending dbidx, as the bitmap union of update_state() lists them
+        self._log("update_state.end")
+        if self.__dict__.get("_rev", [False, False])[1] and len(accepted) != 0 and len(accepted) != len(seen):
+            self.loop.set_reversals()
+
     def _check_reversals(self):
         """a reversal = some rejected image shown before an accepted one."""
         if len(self.accepted) == 0 or len(self.accepted) == len(self.seen):
