@@ -143,6 +143,43 @@ class LKNNModel(ProbabilityModel):
         assert (deltas == deltas[0]).all(), "the vectorised look-ahead needs the same number of neighbours for every node"
         return int(deltas[0])
 
+    # what ssw_lknn_top_sum keeps per thread (csrc/lknn.hip): K picks, D neighbours, a K + D list with a 192-bit mask
+    KERNEL_MAX_K, KERNEL_MAX_D, KERNEL_MAX_LIST = 128, 32, 192
+
+    @staticmethod
+    def _top_sum_host(numer, denom, scores, nbr_sorted, K, top, block=4096):
+        """the look-ahead values on the host, for horizons / degrees beyond the kernel's registers (reward_horizon > 129,
+        more than 32 neighbours): same quantities, rows in blocks.  For node i the pool is the global list `top` without i
+        and without i's neighbours, plus the neighbours at their conditioned scores; value = sum of its K best."""
+        N, D = nbr_sorted.shape
+        t_sorted_pos = np.argsort(top, kind="stable")
+        t_ids = top[t_sorted_pos].astype(np.int64)
+        t_scores = scores[t_ids]
+        given0 = numer / (denom + 1)
+        given1 = (numer + 1) / (denom + 1)
+        out = np.empty(N, dtype=np.float64)
+        for a in range(0, N, block):
+            b = min(N, a + block)
+            rows = np.arange(a, b, dtype=np.int64)[:, None]
+            nb = nbr_sorted[a:b].astype(np.int64)
+            base = np.broadcast_to(t_scores, (b - a, t_ids.shape[0])).copy()
+            base[t_ids[None, :] == rows] = -np.inf                      # the node itself leaves the list
+            pos = np.searchsorted(t_ids, nb)                            # neighbours that sit in the list are replaced
+            hit = np.take(np.append(t_ids, N), pos) == nb
+            rr, cc = np.nonzero(hit)
+            base[rr, pos[rr, cc]] = -np.inf
+            vals = []
+            for cond in (given1, given0):
+                ns = np.take(cond, nb)
+                ns[nb == rows] = -np.inf
+                pool = np.concatenate([base, ns], axis=1)
+                best = -np.sort(-pool, axis=1)[:, :K]                   # descending: the order the reference adds them in
+                assert (best > -np.inf).all(), "fewer than K candidates left for some node"
+                vals.append(best.sum(axis=1))
+            s = scores[a:b]
+            out[a:b] = s * (1 + vals[0]) + (1 - s) * vals[1]
+        return out
+
     def top_sum(self, K: int, return_values: bool = False):
         """_top_sum (efficient_nonmyopic_search.py:94-169) for the current state: value of labelling every node next,
         K further picks into the future.  -> (best index, best value[, all values])"""
@@ -162,8 +199,15 @@ class LKNNModel(ProbabilityModel):
         assert (numer <= denom).all()
         scores = numer / denom
         L = K + D
+        assert N - seen.shape[0] >= L, f"{N - seen.shape[0]} unseen nodes cannot fill a look-ahead list of K + D = {L}"
         part = np.argpartition(-scores, L - 1)[:L]          # the K + D best, then ordered: O(N) instead of a full sort
         top = part[np.argsort(-scores[part], kind="stable")].astype(np.int32)
+        assert np.isfinite(scores[top]).all()               # (the reference's `top_k_scores > -inf`)
+        if K > self.KERNEL_MAX_K or D > self.KERNEL_MAX_D or L > self.KERNEL_MAX_LIST:
+            with np.errstate(invalid="ignore"):
+                values = self._top_sum_host(numer, denom, scores, np.sort(self.matrix.indices.reshape(-1, D)), K, top)
+            best = int(np.nanargmax(values))
+            return (best, float(values[best]), values) if return_values else (best, float(values[best]))
         numer, denom = np.ascontiguousarray(numer), np.ascontiguousarray(denom)
         values = np.empty(N, dtype=np.float64) if return_values else None
         best_i, best_v = ctypes.c_int64(-1), ctypes.c_double(0.0)

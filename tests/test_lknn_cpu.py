@@ -70,3 +70,30 @@ def test_oracle_top_sum_bit_exact_over_the_reference_session(oracle, horizon):
             assert np.array_equal(vals[ok].view(np.uint64), ref[ok].view(np.uint64)), (horizon, rnd)
             assert int(np.nanargmax(vals)) == int(picks[rnd]) and np.nanmax(vals) == g[f"h{horizon}_values"][rnd]
         model.condition_(int(picks[rnd]), int(truth[int(picks[rnd])]))
+
+
+@pytest.mark.parametrize("horizon", [9, 101])
+def test_host_fallback_of_the_look_ahead_equals_reference_values(horizon):
+    """LKNNModel._top_sum_host -- what top_sum runs for horizons / degrees beyond the kernel's registers (K > 128, more
+    than 32 neighbours: ADVICE r2) -- against the reference's value vectors of the planning session, bit for bit"""
+    from seesaw_amd.loops.LKNN_model import LKNNModel, initial_gamma_array
+    from seesaw_amd.research.active_search.common import Dataset
+    g = np.load(os.path.join(GOLDEN, "lknn.npz"))
+    N, D, nbr, W, truth = session_graph(g)
+    model = LKNNModel.from_dataset(Dataset.from_vectors(np.zeros((N, 1))), weight_matrix=W, gamma=initial_gamma_array(0.1, N))
+    picks = g[f"h{horizon}_picks"]
+    K = horizon - 1
+    for rnd in range(12):
+        if rnd in (0, 5, 11):
+            numer = model.numerators + model.gamma
+            denom = model.denominators + 1
+            numer[np.asarray(model.dataset.seen_indices, dtype=np.int64)] = -np.inf
+            scores = numer / denom
+            top = np.argsort(-scores, kind="stable")[:K + D].astype(np.int32)
+            with np.errstate(invalid="ignore"):
+                vals = LKNNModel._top_sum_host(numer, denom, scores, np.sort(nbr), K, top, block=700)
+            ref = g[f"h{horizon}_values_r{rnd}"]
+            assert np.array_equal(np.isnan(vals), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            assert np.array_equal(vals[ok].view(np.uint64), ref[ok].view(np.uint64)), (horizon, rnd)
+        model.condition_(int(picks[rnd]), int(truth[int(picks[rnd])]))
