@@ -140,6 +140,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
     with_cpu=False (ranks of an N > 1 run: every GPU runs its own replica of the sessions, the way
     seesaw_bench's parallel_run spreads sessions over actors) skips the CPU side and the sweep timing."""
     import numpy as np
+    import torch
     from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
     from seesaw_amd.bitmap import BitMap
     from seesaw_amd.seesaw_bench import benchmark_loop
@@ -197,6 +198,7 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 for _ in range(2):  # first session warms kernels / allocations, second is reported
                     ret = make_session(gdm, p, b=b)
                     np.random.seed(0)
+                    torch.manual_seed(0)
                     g = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
                 hip_shown = [int(v) for a in ret["session"].acc_indices for v in np.asarray(a).reshape(-1)]
                 res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
@@ -217,6 +219,8 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 qvec = ds.load_index().string2vec("a c1")
                 # bounded CPU sample: scipy label propagation over 1.56 M nodes takes seconds per round
                 cpu_rounds = 4 if (full and name in ("knn_prop2", "pseudo_lr")) else 30
+                np.random.seed(0)      # both legs draw from numpy's / torch's global streams (box-drop draws, PseudoLR's
+                torch.manual_seed(0)   # sample, nn.Linear start weights): same seeds, same draws
                 c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=cpu_rounds,
                                          max_results=10 ** 6, knn_df=ds.knn_graph().restrict_k(k=10).knn_df if knn_k else None)
             # the two legs' image sequences, round by round (not only nfound): the CPU leg restates the reference's

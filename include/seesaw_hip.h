@@ -207,8 +207,14 @@ ssw_status ssw_topk_allgather(ssw_comm *comm, void *hip_stream, const uint64_t *
 
 /* tuning hook (tools/sweep_scan.py): pick the scan kernel's schedule variant for dim=512
  * (0 u4, 1 u4+nt, 2 u8, 3 u8+nt, 4 u2+nt; -1 = default) and cap its resident blocks per CU
- * (0 = no cap, -1 = default).  All variants produce identical bits. */
+ * (0 = no cap, -1 = default).  Indexes under 65 536 rows run a latency-shaped kernel (8 rows in flight per wave, query
+ * through LDS) unless a variant is named; -2 = the default streaming variant at every size.  All produce identical bits. */
 ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu);
+
+/* ssw_index_topk on an index of <= 8192 images / 65536 rows and <= 8192 excluded ids runs as two launches (scan;
+ * per-image max + exclusion + sort in one workgroup) with the query, the ids and the result in pinned memory the device
+ * maps -- no copies, no stream wait.  0 switches that form off (tests compare it with the general path; same results). */
+ssw_status ssw_tune_topk(int32_t small_path);
 
 /* per-launch device time of the dominant (scan) kernel, measured with HIP events
  * on the handle's stream.  enable=1 starts recording one event pair per scan

@@ -72,8 +72,12 @@ def run_session(vectors, vector_meta, box_data, category, qvec, *, loop="multi_r
         img = int(d[0])  # batch_size 1: the best image of the shortlist (plain_score aggregation)
         returned.append(img)
         shown.append(img)
-        # ---- simulated user
+        # ---- simulated user (fill_imdata, seesaw_bench.py:237-273: one np.random.rand per ground-truth box of the image,
+        # the box_drop_prob draw -- drawn even at probability 0, so it moves numpy's global stream, which
+        # pseudo_lr's np.random.permutation reads later)
         hit = img in positives
+        if hit:
+            np.random.rand(int((boxes.dbidx.values == img).sum()))
         nfound += int(hit)
         img_rows = np.nonzero(row_dbidx == img)[0]
         if hit and meta_xyxy is not None:

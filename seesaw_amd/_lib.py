@@ -127,6 +127,7 @@ _SIGNATURES = {
     "ssw_debug_gemm_pw4_mode": (c_i32, [c_i32, c_void_p]),
     "ssw_debug_gemm_pw4_wg": (c_i32, [c_void_p]),
     "ssw_tune_scan": (c_i32, [c_i32, c_i32]),
+    "ssw_tune_topk": (c_i32, [c_i32]),
     "ssw_index_profile": (c_i32, [c_void_p, c_i32]),
     "ssw_index_profile_read": (c_i32, [c_void_p, c_void_p, c_i32, c_i32_p]),
 }

@@ -1,6 +1,7 @@
 // capi_index.hip -- C-ABI of the resident vector index (see include/seesaw_hip.h).
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <vector>
 
 #include "ssw_common.h"
@@ -90,6 +91,10 @@ struct ssw_index {
     int64_t gather_cap = 0;
     PinnedStage rows_stage;
     void *res_host = nullptr;  // pinned result mirror
+    // small index (one scan launch + one selection launch, no copies, no stream wait): pinned, device-visible block
+    // [query dim f32][excluded ids SMALL_EXCL_CAP i64][packed result], and the sequence number the host spins on
+    unsigned char *small_host = nullptr;
+    unsigned small_seq = 0;
     float *q2_dev = nullptr;  // second query vector (score_rows)
     PinnedStage q2_stage;
     // tile geometry + staging of the avg_score aggregation (rescore.hip)
@@ -252,6 +257,7 @@ ssw_status ssw_index_destroy(ssw_index *idx) {
     (void)hipFree(idx->q2_dev);
     idx->rows_stage.release();
     if (idx->res_host) (void)hipHostFree(idx->res_host);
+    if (idx->small_host) (void)hipHostFree(idx->small_host);
     idx->q2_stage.release();
     if (idx->own_stream) (void)hipStreamDestroy(idx->own_stream);
     delete idx;
@@ -633,13 +639,95 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
     return SSW_OK;
 }
 
+// An index of a few thousand images (an LVIS-category subset: 1 109 images x 13 tiles) spends its round in fixed
+// costs, not in the scan: three copies, five launches and a stream wait were ~95 us around ~10 us of kernels.  This form
+// is two launches and no copy: the scan reads the query and the selection reads the excluded ids from pinned memory the
+// device maps, the selection (per-image max + exclusion + sort in one workgroup) writes the packed result into the same
+// block and releases a sequence word the host spins on.
+constexpr int64_t SMALL_EXCL_CAP = 8192;
+constexpr int64_t SMALL_ROWS = 65536;  // <= 256 scan workgroups read the query over the host link
+
+static bool g_small_path = true;  // ssw_tune_topk
+
+static bool small_path_ok(const ssw_index *idx, int64_t n_excluded) {
+    return g_small_path && idx->n_images >= 1 && idx->n_images <= SELECT_SMALL_IMAGES && idx->n <= SMALL_ROWS &&
+           n_excluded <= SMALL_EXCL_CAP;
+}
+
+static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t *excluded_images, int64_t n_excluded,
+                             int32_t k, int64_t *out_images, float *out_scores, int64_t *out_best_rows,
+                             int32_t *out_count) {
+    const size_t q_bytes = (size_t)idx->dim * sizeof(float), ex_bytes = (size_t)SMALL_EXCL_CAP * sizeof(int64_t);
+    const size_t res_bytes = 16 + (size_t)SSW_MAX_TOPK * 12;
+    if (!idx->small_host) {
+        SSW_HIP_TRY(hipHostMalloc((void **)&idx->small_host, q_bytes + ex_bytes + res_bytes,
+                                  hipHostMallocMapped | hipHostMallocCoherent));
+        memset(idx->small_host, 0, q_bytes + ex_bytes + res_bytes);
+    }
+    unsigned char *dev_view = nullptr;
+    SSW_HIP_TRY(hipHostGetDevicePointer((void **)&dev_view, idx->small_host, 0));
+    for (int64_t i = 0; i < n_excluded; ++i) {
+        SSW_REQUIRE(excluded_images[i] >= 0 && excluded_images[i] < idx->n_images,
+                    "excluded image %lld outside [0, %lld)", (long long)excluded_images[i], (long long)idx->n_images);
+    }
+    SSW_TRY(ensure_ws(idx));
+    if (idx->ws.excl_dirty)  // a list installed by ssw_index_set_excluded does not apply to this call
+        SSW_TRY(select_set_excluded(idx->ws, idx->n_images, nullptr, 0, idx->stream));
+    if (q_host) {
+        memcpy(idx->small_host, q_host, q_bytes);
+        SSW_TRY(do_scan(idx, reinterpret_cast<const float *>(dev_view)));
+    }
+    if (n_excluded > 0) memcpy(idx->small_host + q_bytes, excluded_images, (size_t)n_excluded * sizeof(int64_t));
+    unsigned seq = ++idx->small_seq;
+    if (seq == 0) seq = ++idx->small_seq;
+    unsigned char *res = idx->small_host + q_bytes + ex_bytes;
+    SSW_TRY(launch_select_small(idx->ws, idx->scores, idx->has_map ? idx->row_start : nullptr, idx->n_images,
+                                reinterpret_cast<const int64_t *>(dev_view + q_bytes), n_excluded, k,
+                                dev_view + q_bytes + ex_bytes, seq, idx->stream));
+    const unsigned *flag = reinterpret_cast<const unsigned *>(res) + 3;
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
+            seen = true;
+            break;
+        }
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    if (!seen) {
+        SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            set_error("topk: the selection kernel finished without publishing its result");
+            return SSW_ERR_HIP;
+        }
+    }
+    const int32_t *hdr = reinterpret_cast<const int32_t *>(res);
+    int32_t count = hdr[0];
+    if (count > k) count = k;
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(res + 16);
+    const uint32_t *best = reinterpret_cast<const uint32_t *>(res + 16 + (size_t)k * sizeof(uint64_t));
+    for (int32_t i = 0; i < count; ++i) {
+        const uint64_t key = keys[i];
+        if (out_images) out_images[i] = (int64_t)(0xffffffffu - (uint32_t)(key & 0xffffffffull));
+        if (out_scores) out_scores[i] = ord_to_f32((uint32_t)(key >> 32));
+        if (out_best_rows) out_best_rows[i] = (int64_t)best[i];
+    }
+    *out_count = count;
+    return SSW_OK;
+}
+
 ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *excluded_images,
                           int64_t n_excluded, int32_t k, int64_t *out_images, float *out_scores,
                           int64_t *out_best_rows, int32_t *out_count) {
     SSW_REQUIRE(idx != nullptr && out_count != nullptr, "NULL argument");
     SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    SSW_REQUIRE(n_excluded == 0 || excluded_images != nullptr, "excluded_images is NULL");
     *out_count = 0;
     DeviceGuard guard(idx->device);
+    if (small_path_ok(idx, n_excluded)) {
+        if (q_host) SSW_TRY(check_query(idx, q_host));
+        return topk_small(idx, q_host, excluded_images, n_excluded, k, out_images, out_scores, out_best_rows, out_count);
+    }
     if (q_host) {
         SSW_TRY(check_query(idx, q_host));
         SSW_TRY(idx->q_stage.push(idx->q_dev, q_host, (size_t)idx->dim * sizeof(float),
@@ -779,6 +867,11 @@ ssw_status ssw_topk_merge_msgs_dev(int32_t device, void *hip_stream, const uint6
     return launch_merge_msgs(dev_msgs, world, k_max, with_best, k, dev_keys_out, dev_count_out,
                              reinterpret_cast<long long *>(dev_flags_or_null),
                              reinterpret_cast<long long *>(dev_flags_seen_or_null), (hipStream_t)hip_stream);
+}
+
+ssw_status ssw_tune_topk(int32_t small_path) {
+    g_small_path = small_path != 0;
+    return SSW_OK;
 }
 
 ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu) {

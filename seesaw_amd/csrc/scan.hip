@@ -162,6 +162,41 @@ __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restric
     }
 }
 
+// Small index (fewer rows than the streaming kernel needs to fill the chip: an LVIS-subset index has 14 417): the
+// streaming kernel gives each wave 64 rows, fetched two at a time -- 32 dependent round trips to HBM, ~12 us for 29 MB.
+// Here a wave takes U rows per step (all in flight at once), 16 waves a workgroup, at most 128 workgroups, and the query
+// comes through LDS: one wave's read per workgroup, so q may live in pinned host memory (ssw_index_topk's small-index
+// form) and its fetch overlaps the first rows'.  Same dot_frag / group_reduce order: identical bits.  Plain loads: an
+// index this size stays in the Infinity Cache between rounds.
+template <int C, int U>
+__global__ __launch_bounds__(1024) void scan_small_kernel(const float *__restrict__ X, const float *__restrict__ q,
+                                                          float *__restrict__ scores, int n, int steps) {
+    __shared__ float4 ql[C * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int last = n - 1;
+    const float4 *X4 = reinterpret_cast<const float4 *>(X);
+    const int row_base = (blockIdx.x * 16 + wave) * U * steps;
+    Group<C, U> cur, nxt;
+    load_group<C, U, false>(cur, X4, row_base, last, lane);
+    if (threadIdx.x < C * 64) ql[threadIdx.x] = reinterpret_cast<const float4 *>(q)[threadIdx.x];
+    __syncthreads();
+    RowFrag<C> qf;
+#pragma unroll
+    for (int c = 0; c < C; ++c) qf.v[c] = ql[c * 64 + lane];
+    for (int g = 0; g < steps; ++g) {
+        const int row0 = row_base + g * U;
+        if (row0 >= n) break;
+        if (g + 1 < steps) load_group<C, U, false>(nxt, X4, row0 + U, last, lane);
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = dot_frag<C>(cur.r[u], qf);
+        const float v = group_reduce<U>(acc, lane);
+        if (lane < U && row0 + lane < n) scores[row0 + lane] = v;
+        cur = nxt;
+    }
+}
+
 // scores of an explicit list of rows, same summation order as the full scan (one wave per
 // row, plain butterfly) -- stage-2 rescoring against a second vector
 // (multiscale_index.py:347-349).
@@ -249,6 +284,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
 // non-temporal loads are worth +4...7 %, and with them FEWER resident waves stream faster --
 // at 100 M rows u2+nt with one block per CU reads 6.70 TB/s, u4 (default policy, 8 waves/SIMD)
 // 6.17 TB/s; 1 M rows: 6.66 vs 5.65 TB/s.  All variants produce identical bits.
+constexpr int64_t SCAN_SMALL_ROWS = 65536;  // below: the streaming kernel has under one 4-wave workgroup per CU
+bool g_scan_small = true;       // tuning hook (ssw_tune_scan variant -2: streaming kernel at every size)
 int g_scan_variant = -1;        // tuning hook (ssw_tune_scan): -1 = default (u2 + nt)
 int g_scan_blocks_per_cu = -1;  // -1 = default (1 per CU for dim 512), 0 = as many as fit
 
@@ -272,6 +309,16 @@ ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t 
     if (n >= (int64_t)0x7fff0000) {
         set_error("scan: n=%lld rows exceeds the 2^31 row limit of one index shard", (long long)n);
         return SSW_ERR_UNSUPPORTED;
+    }
+    if (n < SCAN_SMALL_ROWS && g_scan_small) {
+        constexpr int SU = C <= 2 ? 8 : 4;
+        const int64_t per_step = 16 * SU;  // rows a workgroup takes per step
+        const int steps = (int)((n + 128 * per_step - 1) / (128 * per_step));
+        const int64_t sgrid = (n + per_step * steps - 1) / (per_step * steps);
+        hipLaunchKernelGGL((scan_small_kernel<C, SU>), dim3((unsigned)sgrid), dim3(1024), 0, stream, X, q, scores, (int)n,
+                           steps);
+        SSW_HIP_TRY(hipGetLastError());
+        return SSW_OK;
     }
     const int64_t nbatches = (n + 63) >> 6;
     int64_t grid = (int64_t)num_cus(device) * blocks_per_cu[dev_slot];
@@ -352,6 +399,8 @@ ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, 
 }
 
 void tune_scan(int variant, int blocks_per_cu) {
+    g_scan_small = variant == -1;  // an explicit variant (or -2) means the streaming kernel at every size
+    if (variant < -1) variant = -1;
     g_scan_variant = variant;
     g_scan_blocks_per_cu = blocks_per_cu;
 }

@@ -32,6 +32,7 @@ namespace {
 
 constexpr int NBINS = 4096;
 constexpr int FINAL_CAP = 8192;  // candidates the final sort can take (64 KiB of LDS)
+constexpr size_t FINAL_LDS_BYTES = (size_t)(FINAL_CAP + FINAL_CAP / 2) * sizeof(uint64_t);  // + the halvings' second buffer
 // The second histogram level is taken as soon as the first leaves more than this many candidates: collecting them is
 // one global atomic each and the final sort is a one-workgroup bitonic network, so 8192 candidates cost 17 + 30 us
 // where the 9 us of a second level leave a few hundred (1.56 M rows / 120 000 images: 99 -> 60 us of selection).
@@ -236,24 +237,150 @@ __global__ __launch_bounds__(256) void k_collect_deep(const float *__restrict__ 
     }
 }
 
-// descending bitonic sort of p (power of two) u64 keys in LDS, 1024 threads
-__device__ __forceinline__ void bitonic_sort_desc(uint64_t *s, int p, int t) {
-    for (int k2 = 2; k2 <= p; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = t; i < p; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool desc = ((i & k2) == 0);
-                    const uint64_t a = s[i], b = s[ixj];
-                    if ((a < b) == desc) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
-                }
-            }
-            __syncthreads();
+// ---- the final selection: the c largest of p keys in LDS, sorted descending, 1024 threads ------------------------------
+// A full bitonic sort of the candidates in LDS cost a barrier per stage -- 66 stages for 2048 keys, ~30 us of a ~35 us
+// kernel for an LVIS-subset index, where the selection is most of a feedback round.  This form:
+//   * a compare-exchange at distance j < 64 stays in registers: the partner's key comes through DPP (j = 1, 2, 4, 8) or
+//     v_permlane16_swap / v_permlane32_swap (j = 16, 32) -- VALU latency, no LDS queue, no barrier; only j >= 64 goes
+//     through LDS;
+//   * only the c = max(64, 2^ceil(log2 k)) largest are wanted: blocks of c keys are sorted (alternating direction, the
+//     ordinary network up to k2 = c), then pairs of blocks are merged by keeping the element-wise maximum of a descending
+//     and an ascending block -- the c largest of both, as a bitonic sequence -- and running the half-cleaners on it,
+//     until one block is left.  For k = 60 of 2048 keys: 21 stages over 2048 keys, then 7 over 1024, 512, ... 64,
+//     one barrier per halving (the halves ping-pong between two LDS buffers).
+// Keys are unique (score, position) apart from the 0 padding, so the order of equal keys does not matter.
+
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
+    if constexpr (J == 1) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        // lanes 0-3, 8-11 of a row read lane + 4 (row_shl:4, banks 0 and 2), the others lane - 4 (row_shr:4)
+        int r = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xF, 0xA, false);
+        return (uint32_t)r;
+    } else if constexpr (J == 8) {
+        return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true);  // row_ror:8
+    } else if constexpr (J == 16) {
+        // (a, b) = (x, x): the swap exchanges a's odd rows with b's even rows -> a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
+        const auto ab = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? ab[0] : ab[1];
+    } else {
+        // a's upper half <-> b's lower half -> a = [lo lo], b = [hi hi]
+        const auto ab = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32) ? ab[0] : ab[1];
+    }
+}
+
+// one compare-exchange stage at lane distance J of the merge with direction bit k2, key of element index i
+template <int J>
+__device__ __forceinline__ uint64_t lane_stage(uint64_t v, int i, int k2, int lane) {
+    const uint32_t lo = lane_xor_u32<J>((uint32_t)v, lane), hi = lane_xor_u32<J>((uint32_t)(v >> 32), lane);
+    const uint64_t o = ((uint64_t)hi << 32) | lo;
+    const bool lower = (lane & J) == 0, desc = (i & k2) == 0;
+    return ((lower == desc) == (o > v)) ? o : v;  // the larger key to the descending side's lower lane
+}
+
+// stages j = min(jstart, 32) .. 1 on NE register-resident keys, key e being element e * 1024 + t (live when < pcur)
+template <int NE>
+__device__ __forceinline__ void lane_stages(uint64_t (&v)[NE], int pcur, int k2, int jstart, int t) {
+    const int lane = t & 63;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int i = e * 1024 + t;
+        if (e * 1024 < pcur && i < pcur) {  // uniform per wave: pcur is a multiple of 64
+            if (jstart >= 32) v[e] = lane_stage<32>(v[e], i, k2, lane);
+            if (jstart >= 16) v[e] = lane_stage<16>(v[e], i, k2, lane);
+            if (jstart >= 8) v[e] = lane_stage<8>(v[e], i, k2, lane);
+            if (jstart >= 4) v[e] = lane_stage<4>(v[e], i, k2, lane);
+            if (jstart >= 2) v[e] = lane_stage<2>(v[e], i, k2, lane);
+            v[e] = lane_stage<1>(v[e], i, k2, lane);
         }
     }
+}
+
+// stages j = jstart .. 1 of the merge whose direction bit is k2, over pcur keys (a multiple of 64) in LDS
+__device__ __forceinline__ void bitonic_stages(uint64_t *s, int pcur, int k2, int jstart, int t) {
+    int j = jstart;
+    for (; j >= 64; j >>= 1) {
+        for (int pr = t; pr < (pcur >> 1); pr += 1024) {
+            const int i = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));  // pair number -> lower index (a 0 at bit log2 j)
+            const int ixj = i | j;
+            const bool desc = ((i & k2) == 0);
+            const uint64_t a = s[i], b = s[ixj];
+            if ((a < b) == desc) {
+                s[i] = b;
+                s[ixj] = a;
+            }
+        }
+        __syncthreads();
+    }
+    uint64_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e * 1024 < pcur && e * 1024 + t < pcur) v[e] = s[e * 1024 + t];
+    lane_stages<8>(v, pcur, k2, j, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e * 1024 < pcur && e * 1024 + t < pcur) s[e * 1024 + t] = v[e];
+    __syncthreads();
+}
+
+// s: p keys (p a power of two in [64, FINAL_CAP]) followed by a second buffer of FINAL_CAP / 2 keys at s + FINAL_CAP;
+// c: power of two in [64, p].  Returns where the c largest keys lie, descending (s or the second buffer).
+__device__ __forceinline__ uint64_t *select_sorted_desc(uint64_t *s, int p, int c, int t) {
+    {   // k2 = 2 .. 64 without leaving the registers
+        uint64_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e * 1024 < p && e * 1024 + t < p) v[e] = s[e * 1024 + t];
+        lane_stages<8>(v, p, 2, 1, t);
+        lane_stages<8>(v, p, 4, 2, t);
+        lane_stages<8>(v, p, 8, 4, t);
+        lane_stages<8>(v, p, 16, 8, t);
+        lane_stages<8>(v, p, 32, 16, t);
+        lane_stages<8>(v, p, 64, 32, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e * 1024 < p && e * 1024 + t < p) s[e * 1024 + t] = v[e];
+        __syncthreads();
+    }
+    for (int k2 = 128; k2 <= c; k2 <<= 1) bitonic_stages(s, p, k2, k2 >> 1, t);
+    const int cshift = __builtin_ctz(c);
+    uint64_t *src = s, *dst = s + FINAL_CAP;
+    for (int pcur = p; pcur > c;) {
+        const int half = pcur >> 1;
+        uint64_t r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = e * 1024 + t;
+            if (e * 1024 < half && o < half) {
+                const int m = o >> cshift, i = o & (c - 1);
+                const uint64_t a = src[((2 * m) << cshift) + i], b = src[((2 * m + 1) << cshift) + i];
+                r[e] = a > b ? a : b;
+            }
+        }
+        pcur = half;
+        if (c == 64) {  // the half-cleaners are lane stages: straight on the registers, one barrier per halving
+            lane_stages<4>(r, pcur, c, 32, t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e * 1024 < half && e * 1024 + t < half) dst[e * 1024 + t] = r[e];
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e * 1024 < half && e * 1024 + t < half) dst[e * 1024 + t] = r[e];
+            __syncthreads();
+            bitonic_stages(dst, pcur, c, c >> 1, t);
+        }
+        uint64_t *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    return src;
 }
 
 // candidates (n_lists lists of counts[l] keys at keys_in + l*stride; or one list whose
@@ -273,10 +400,45 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
                                                 int32_t *__restrict__ count_out,
                                                 uint32_t *__restrict__ best_out,
                                                 unsigned char *__restrict__ packed_or_null, FinalExchange x) {
-    extern __shared__ uint64_t s[];  // FINAL_CAP entries
+    extern __shared__ uint64_t s[];  // FINAL_CAP entries + FINAL_CAP / 2 for the halvings
     const int t = threadIdx.x;
     int n = 0;
-    if (ncand_ptr != nullptr) {
+    if (x.values_all != nullptr) {
+        // few images (m <= FINAL_CAP: an LVIS-category subset has ~1 100): no histograms, no candidate pass -- every
+        // image's composite key goes straight into the selection, excluded ones as 0 (below every real key)
+        n = (int)x.m_all;
+        // the id list lives in host memory: ask for it first, use it once the keys are in LDS
+        const int64_t ex0 = (t < x.n_excl) ? x.excl_ids[t] : -1;
+        for (int i = t; i < n; i += 1024) {
+            float v;
+            if (x.row_start != nullptr) {  // k_image_max, here; eight rows in flight
+                const int64_t r0 = x.row_start[i], r1 = x.row_start[i + 1];
+                float best = -INFINITY;
+                int64_t br = r0;
+                for (int64_t r = r0; r < r1; r += 8) {
+                    float sc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sc[u] = x.values_all[min(r + u, r1 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (r + u < r1 && sc[u] > best) {  // strict: lowest row wins ties
+                            best = sc[u];
+                            br = r + u;
+                        }
+                    }
+                }
+                x.img_score[i] = best;
+                x.img_best[i] = (uint32_t)br;
+                v = best;
+            } else {
+                v = x.values_all[i];
+            }
+            s[i] = is_excluded(x.excl, i) ? 0ull : composite_key(v, i);
+        }
+        __syncthreads();
+        if (ex0 >= 0) s[ex0] = 0ull;  // ids range-checked by the host
+        for (int64_t j = t + 1024; j < x.n_excl; j += 1024) s[x.excl_ids[j]] = 0ull;
+    } else if (ncand_ptr != nullptr) {
         n = (int)min(*ncand_ptr, (uint32_t)FINAL_CAP);
         for (int i = t; i < n; i += 1024) s[i] = keys_in[i];
     } else {
@@ -290,17 +452,40 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
             n += c;
         }
     }
-    int p = 1;
+    int p = 64;
     while (p < n) p <<= 1;
+    int c = 64;  // keys wanted, rounded up to a block of the selection
+    while (c < k) c <<= 1;
+    c = min(c, p);
     for (int i = n + t; i < p; i += 1024) s[i] = 0ull;  // below every real key
     __syncthreads();
-    bitonic_sort_desc(s, p, t);
-    const int out = min(k, n);
+    const uint64_t *res = select_sorted_desc(s, p, c, t);
+    // res[0, c): descending, real keys (never 0) first.  The thread that sees the end of the real keys among the first
+    // min(k, c) reports the count; every entry before it goes out.
+    const int kk = min(k, c);
     // packed mirror for the host: [count, overflow, k, 0][keys x k][best x k], one D2H copy
     uint64_t *pk_keys = packed_or_null ? reinterpret_cast<uint64_t *>(packed_or_null + 16) : nullptr;
     uint32_t *pk_best = packed_or_null ? reinterpret_cast<uint32_t *>(packed_or_null + 16 + (size_t)k * 8) : nullptr;
-    for (int i = t; i < out; i += 1024) {
-        const uint64_t key = s[i];
+    for (int i = t; i < kk; i += 1024) {
+        const uint64_t key = res[i];
+        const bool last = key != 0ull && (i + 1 == kk || res[i + 1] == 0ull);
+        if (last || (i == 0 && key == 0ull)) {
+            const int out = key != 0ull ? i + 1 : 0;
+            // overflow of the fast path (more candidates than the final sort takes), for the host
+            const int ovf = (state_or_null && (state_or_null[ST_OVERFLOW] != 0 ||
+                                               state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
+            count_out[0] = out;
+            if (state_or_null || x.values_all) count_out[1] = ovf;
+            if (x.msg_out) x.msg_out[x.msg_len - 1] = (uint64_t)(uint32_t)out | ((uint64_t)(uint32_t)ovf << 32);
+            if (packed_or_null) {
+                int32_t *hdr = reinterpret_cast<int32_t *>(packed_or_null);
+                hdr[0] = out;
+                hdr[1] = ovf;
+                hdr[2] = k;
+                if (x.host_seq == 0) hdr[3] = 0;
+            }
+        }
+        if (key == 0ull) continue;
         keys_out[i] = key;
         if (pk_keys) pk_keys[i] = key;
         uint32_t br = 0;
@@ -315,29 +500,21 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
             if (x.with_best) x.msg_out[x.k_max + i] = (uint64_t)((int64_t)br + x.row_offset);
         }
     }
-    if (t == 0) {
-        // overflow of the fast path (more candidates than the final sort takes), for the host
-        const int ovf = (state_or_null && (state_or_null[ST_OVERFLOW] != 0 ||
-                                           state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
-        count_out[0] = out;
-        if (state_or_null) count_out[1] = ovf;
-        if (x.msg_out) x.msg_out[x.msg_len - 1] = (uint64_t)(uint32_t)out | ((uint64_t)(uint32_t)ovf << 32);
-        if (x.from_msgs) {
-            long long any = 0;
-            for (int l = 0; l < n_lists; ++l) {
-                const long long f = (long long)(keys_in[(int64_t)l * list_stride + list_stride - 1] >> 32);
-                if (x.flags_out) x.flags_out[l] = f;
-                any |= f;
-            }
-            if (x.flags_seen) *x.flags_seen |= any;
+    if (t == 0 && x.from_msgs) {
+        long long any = 0;
+        for (int l = 0; l < n_lists; ++l) {
+            const long long f = (long long)(keys_in[(int64_t)l * list_stride + list_stride - 1] >> 32);
+            if (x.flags_out) x.flags_out[l] = f;
+            any |= f;
         }
-        if (packed_or_null) {
-            int32_t *hdr = reinterpret_cast<int32_t *>(packed_or_null);
-            hdr[0] = out;
-            hdr[1] = ovf;
-            hdr[2] = k;
-            hdr[3] = 0;
-        }
+        if (x.flags_seen) *x.flags_seen |= any;
+    }
+    if (x.host_seq != 0) {  // the packed block is host memory: release everything, then the word the host spins on
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned *>(packed_or_null) + 3, x.host_seq, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -442,6 +619,44 @@ ssw_status launch_image_max(const float *scores, const int64_t *row_start, int64
     return SSW_OK;
 }
 
+// k_final's LDS (96 KiB) is above the 64 KiB a kernel gets by default: raise the limit once per device
+static ssw_status final_lds_ready() {
+    static bool done[64] = {false};
+    int dev = 0;
+    SSW_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_final), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)FINAL_LDS_BYTES));
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return SSW_OK;
+}
+
+ssw_status launch_select_small(SelectWorkspace &ws, const float *row_scores, const int64_t *row_start_or_null,
+                               int64_t n_images, const int64_t *excl_ids_mapped, int64_t n_excl, int32_t k,
+                               unsigned char *packed_mapped, unsigned seq, hipStream_t stream) {
+    if (n_images < 1 || n_images > SELECT_SMALL_IMAGES || n_images > FINAL_CAP || k < 1 || k > SSW_MAX_TOPK || seq == 0) {
+        set_error("select_small: n_images=%lld k=%d outside the one-launch path", (long long)n_images, k);
+        return SSW_ERR_INVALID;
+    }
+    FinalExchange x = ws.xchg;
+    x.values_all = row_scores;
+    x.m_all = n_images;
+    x.row_start = row_start_or_null;
+    x.img_score = ws.img_score;
+    x.img_best = ws.img_best;
+    x.excl_ids = excl_ids_mapped;
+    x.n_excl = n_excl;
+    x.host_seq = seq;
+    SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, (const uint64_t *)nullptr, 0, 0,
+                       (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (int)k,
+                       row_start_or_null ? (const uint32_t *)ws.img_best : (const uint32_t *)nullptr, ws.out_keys,
+                       ws.out_count, ws.out_best, packed_mapped, x);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
 ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t m,
                               const uint32_t *best_rows_or_null, int32_t k, int device,
                               hipStream_t stream) {
@@ -454,6 +669,18 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
         return SSW_ERR_UNSUPPORTED;
     }
     const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
+    if (m <= FINAL_CAP) {  // one launch: the sort takes every image
+        FinalExchange x = ws.xchg;
+        x.values_all = values;
+        x.m_all = m;
+        x.excl = excl;
+        SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, (const uint64_t *)nullptr,
+                           0, 0, (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (int)k,
+                           best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, x);
+        SSW_HIP_TRY(hipGetLastError());
+        return SSW_OK;
+    }
     SSW_HIP_TRY(hipMemsetAsync(ws.hist1, 0, (2 * NBINS + ST_WORDS) * sizeof(uint32_t), stream));
     const int g = grid_for(m, device);
     hipLaunchKernelGGL(k_hist<1>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist1, ws.state);
@@ -461,7 +688,8 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     hipLaunchKernelGGL(k_hist<2>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist2, ws.state);
     hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, (int)k);
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
+    SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
                        best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
     SSW_HIP_TRY(hipGetLastError());
@@ -502,7 +730,8 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
     SSW_HIP_TRY(hipMemsetAsync(ws.state, 0, ST_WORDS * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(k_collect_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state,
                        ws.cand, threshold);
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, ws.cand,
+    SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
                        best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
     SSW_HIP_TRY(hipGetLastError());
@@ -521,7 +750,8 @@ ssw_status launch_merge_topk(const uint64_t *keys_in, int32_t n_lists, int32_t l
         set_error("merge: %d lists x %d keys exceed %d candidates", n_lists, std::min(list_stride, k), FINAL_CAP);
         return SSW_ERR_INVALID;
     }
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, keys_in,
+    SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, keys_in,
                        (int)n_lists, (int)list_stride, counts, (const uint32_t *)nullptr,
                        (const uint32_t *)nullptr, (int)k, (const uint32_t *)nullptr, keys_out, count_out,
                        (uint32_t *)nullptr, (unsigned char *)nullptr, FinalExchange());
@@ -548,7 +778,8 @@ ssw_status launch_merge_msgs(const uint64_t *msgs, int32_t world, int32_t k_max,
     x.msg_len = (with_best ? 2 : 1) * k_max + 1;
     x.flags_out = flags_out;
     x.flags_seen = flags_seen;
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_CAP * sizeof(uint64_t), stream, msgs, (int)world,
+    SSW_TRY(final_lds_ready());
+    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, msgs, (int)world,
                        (int)x.msg_len, (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                        (int)k, (const uint32_t *)nullptr, keys_out, count_out, (uint32_t *)nullptr,
                        (unsigned char *)nullptr, x);

@@ -159,6 +159,19 @@ struct FinalExchange {
     int32_t k_max = 0, with_best = 0, msg_len = 0;
     int32_t from_msgs = 0;         // merge: the input lists are messages
     long long *flags_out = nullptr, *flags_seen = nullptr;
+    // few images (<= the sort's capacity): the selection is this one kernel over all of them
+    const float *values_all = nullptr;
+    int64_t m_all = 0;
+    const uint32_t *excl = nullptr;
+    // ... which can also take the per-image maximum (values_all = row scores, row_start set; fills img_score / img_best),
+    // the excluded ids as a list (device-visible pinned memory) and write the packed result into pinned host memory,
+    // ending with the release of host_seq into its header word 3 (the host spins on it)
+    const int64_t *row_start = nullptr;
+    float *img_score = nullptr;
+    uint32_t *img_best = nullptr;
+    const int64_t *excl_ids = nullptr;
+    int64_t n_excl = 0;
+    unsigned host_seq = 0;
 };
 
 // select.hip: exact top-k of per-image best scores.
@@ -195,6 +208,12 @@ ssw_status launch_image_max(const float *scores, const int64_t *row_start, int64
 ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t m,
                               const uint32_t *best_rows_or_null, int32_t k, int device,
                               hipStream_t stream);
+// small index (n_images <= SELECT_SMALL_IMAGES): per-image max, exclusion by id list, selection and the packed result
+// into pinned host memory in ONE launch; the host waits for header word 3 == seq (see FinalExchange)
+constexpr int64_t SELECT_SMALL_IMAGES = 8192;
+ssw_status launch_select_small(SelectWorkspace &ws, const float *row_scores, const int64_t *row_start_or_null,
+                               int64_t n_images, const int64_t *excl_ids_mapped, int64_t n_excl, int32_t k,
+                               unsigned char *packed_mapped, unsigned seq, hipStream_t stream);
 // the fast path flags (out_count[1]) a 24-bit prefix bin with more candidates than the final
 // sort can take (massive exact ties); the caller then reruns the selection on the deep path.
 ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,

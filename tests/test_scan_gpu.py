@@ -25,7 +25,7 @@ def test_synth_rows_bit_exact(DeviceIndex, oracle, n):
 
 
 @pytest.mark.parametrize("dim", [256, 512, 768, 1024])
-@pytest.mark.parametrize("n", [1, 64, 65, 4097, 20011])
+@pytest.mark.parametrize("n", [1, 64, 65, 127, 4097, 20011, 65535, 70001])
 def test_scores_bit_exact_vs_kernel_order_oracle(DeviceIndex, oracle, n, dim):
     X = oracle.synth_rows(3, 100, n, dim)
     q = oracle.synth_query(1, dim)
@@ -36,6 +36,25 @@ def test_scores_bit_exact_vs_kernel_order_oracle(DeviceIndex, oracle, n, dim):
     # and within f32 rounding of the reference expression `vectors @ q`
     assert np.abs(got - oracle.scores_reference(X, q)).max() <= oracle.rounding_band(X, q)
     idx.close()
+
+
+@pytest.mark.parametrize("n", [5, 129, 14417, 40000])
+def test_small_index_scan_kernel_equals_streaming_kernel(DeviceIndex, oracle, n):
+    """under 65 536 rows the scan is the latency-shaped kernel; ssw_tune_scan(-2) forces the streaming one: same bits"""
+    from seesaw_amd import _lib
+    X = oracle.synth_rows(8, 3, n, 512)
+    idx = DeviceIndex.from_numpy(X)
+    try:
+        for qs in range(3):
+            q = oracle.synth_query(qs)
+            _lib.call("ssw_tune_scan", -2, -1)
+            want = idx.scores(q)
+            _lib.call("ssw_tune_scan", -1, -1)
+            assert np.array_equal(bits(idx.scores(q)), bits(want))
+            assert np.array_equal(bits(want), bits(oracle.scores_kernel_order(X, q)))
+    finally:
+        _lib.call("ssw_tune_scan", -1, -1)
+        idx.close()
 
 
 def test_scores_general_values(DeviceIndex, oracle):
@@ -90,6 +109,43 @@ def test_topk_ragged_images_and_reuse(DeviceIndex, oracle):
         assert np.array_equal(bits(g), bits(scores))
         returned.extend(imgs[:10].tolist())
     idx.close()
+
+
+@pytest.mark.parametrize("tiles", [1, 13])
+def test_small_index_form_equals_general_path(DeviceIndex, oracle, tiles):
+    """an index of <= 8192 images runs ssw_index_topk as two launches with pinned, device-mapped query / ids / result;
+    switched off (ssw_tune_topk(0)) the same calls take the general path: identical answers, round after round, with the
+    list growing, repeated ids, q=None reuse, k beyond what is left, and everything excluded"""
+    from seesaw_amd import _lib
+    n_images = 1109
+    rng = np.random.default_rng(tiles)
+    counts = np.full(n_images, tiles) if tiles == 1 else rng.integers(1, 2 * tiles, size=n_images)
+    row2image = np.repeat(np.arange(n_images), counts).astype(np.int32)
+    X = oracle.synth_rows(21, 0, row2image.shape[0], 512)
+    ref_idx = DeviceIndex.from_numpy(X, row2image=None if tiles == 1 else row2image)
+    idx = DeviceIndex.from_numpy(X, row2image=None if tiles == 1 else row2image)
+    returned = []
+    try:
+        for rnd in range(12):
+            q = oracle.synth_query(rnd // 2)
+            k = (10, 60, 4096)[rnd % 3]
+            _lib.call("ssw_tune_topk", 0)
+            want = ref_idx.topk(q if rnd % 2 == 0 else None, k, excluded=returned)
+            _lib.call("ssw_tune_topk", 1)
+            got = idx.topk(q if rnd % 2 == 0 else None, k, excluded=returned)
+            for a, b in zip(got, want):
+                assert np.array_equal(bits(a) if a.dtype == np.float32 else a, bits(b) if b.dtype == np.float32 else b), rnd
+            o = oracle.topk_images_tiebreak(oracle.scores_kernel_order(X, q), None if tiles == 1 else row2image,
+                                            n_images, returned, k)
+            assert np.array_equal(got[0], o[0]) and np.array_equal(got[2], o[2])
+            returned.extend(got[0][:40].tolist())
+            returned.extend(got[0][:3].tolist())  # repeats
+        got = idx.topk(None, 5, excluded=range(n_images))
+        assert got[0].shape[0] == 0
+    finally:
+        _lib.call("ssw_tune_topk", 1)
+        idx.close()
+        ref_idx.close()
 
 
 def test_topk_fewer_than_k_and_all_excluded(DeviceIndex, oracle):
