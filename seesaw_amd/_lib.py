@@ -99,6 +99,7 @@ _SIGNATURES = {
     "ssw_fb_last_fit_on_device": (c_i32, [c_void_p, c_i32_p]),
     "ssw_fb_reset": (c_i32, [c_void_p]),
     "ssw_np_permutation_prefix": (c_i32, [c_void_p, c_i32_p, c_i64, c_i64, c_void_p]),
+    "ssw_np_permutation_prefix_dev": (c_i32, [c_i32, c_void_p, c_i32_p, c_i64, c_i64, c_void_p]),
     "ssw_rank_quick_gradient": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
     "ssw_rank_inversions": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_void_p]),
     "ssw_lknn_create": (c_i32, [c_i32, c_i64, c_i32, c_void_p, c_void_pp]),

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #ifndef __HIP_DEVICE_COMPILE__
 #include <immintrin.h>  // host pass only: the AVX-512 variants below
@@ -254,6 +255,89 @@ bool have_avx512() { return false; }
 void draw_targets_avx512(Mt &, int64_t, uint32_t *) {}
 #endif
 
+
+// ---- the walk on the device ------------------------------------------------------------------------------------------
+// The host walk above follows all k pointers through the 1.56 M steps in one serial pass (2 ms on the EPYC host, most
+// of a draw).  Traced one pointer at a time the walk needs no pass at all: what ends at position p came, at step p
+// (swap(a[p], a[J[p]]), the last step to touch p), from position J[p]; before that, the value at a position q below the
+// current step can only have come from a step i with J[i] == q -- the LATEST executed, i.e. the SMALLEST i above where
+// the trace stands -- and then sat at position i, and so on until no step targets it: that position is the value
+// (a starts as the identity).  So:   cur = p, t = 1;  if p >= 1: cur = J[p], t = p + 1;
+//                                    while some i >= t has J[i] == cur: take the smallest, cur = i, t = i + 1.
+// The lists {i : J[i] == q} are built with one atomic exchange per step (their order is the atomics' order; the
+// minimum over a list does not depend on it) and are short: ln(n / q) entries on average.  ~6 hops per pointer.
+__global__ void k_np_build_lists(const uint32_t *__restrict__ Jd, int64_t n, int32_t *__restrict__ head,
+                                 int32_t *__restrict__ nxt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // steps 1 .. n-1
+    if (i >= n) return;
+    const uint32_t j = Jd[n - 1 - i];
+    nxt[i] = atomicExch(&head[j], (int32_t)i);
+}
+
+__global__ void k_np_trace(const uint32_t *__restrict__ Jd, int64_t n, int64_t k, const int32_t *__restrict__ head,
+                           const int32_t *__restrict__ nxt, int64_t *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= k) return;
+    int64_t cur = p, t = 1;
+    if (p >= 1) {
+        cur = Jd[n - 1 - p];
+        t = p + 1;
+    }
+    for (;;) {
+        int32_t best = 0x7fffffff;
+        for (int32_t i = head[cur]; i >= 0; i = nxt[i])
+            if (i >= t && i < best) best = i;
+        if (best == 0x7fffffff) break;
+        cur = best;
+        t = (int64_t)best + 1;
+    }
+    out[p] = cur;
+}
+
+struct DevWalk {  // per device, kept between calls
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t *Jd_host = nullptr;  // pinned: the draws are written straight into it
+    uint32_t *Jd = nullptr;
+    int32_t *head = nullptr, *nxt = nullptr;
+    int64_t *out = nullptr, *out_host = nullptr;
+    int64_t cap_n = 0, cap_k = 0;
+};
+
+ssw_status dev_walk_reserve(DevWalk &w, int device, int64_t n, int64_t k) {
+    if (w.device != device) {
+        if (w.device >= 0) {
+            ssw::set_error("np_permutation_prefix: one device per thread (was %d, now %d)", w.device, device);
+            return SSW_ERR_INVALID;
+        }
+        w.device = device;
+        SSW_HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    }
+    if (n + 16 > w.cap_n) {
+        if (w.Jd_host) (void)hipHostFree(w.Jd_host);
+        (void)hipFree(w.Jd);
+        (void)hipFree(w.head);
+        (void)hipFree(w.nxt);
+        w.Jd_host = nullptr; w.Jd = nullptr; w.head = nullptr; w.nxt = nullptr; w.cap_n = 0;
+        const int64_t cap = n + n / 8 + 64;
+        SSW_HIP_TRY(hipHostMalloc((void **)&w.Jd_host, (size_t)cap * sizeof(uint32_t), hipHostMallocDefault));
+        SSW_HIP_TRY(hipMalloc((void **)&w.Jd, (size_t)cap * sizeof(uint32_t)));
+        SSW_HIP_TRY(hipMalloc((void **)&w.head, (size_t)cap * sizeof(int32_t)));
+        SSW_HIP_TRY(hipMalloc((void **)&w.nxt, (size_t)cap * sizeof(int32_t)));
+        w.cap_n = cap;
+    }
+    if (k > w.cap_k) {
+        if (w.out_host) (void)hipHostFree(w.out_host);
+        (void)hipFree(w.out);
+        w.out = nullptr; w.out_host = nullptr; w.cap_k = 0;
+        const int64_t cap = k + k / 8 + 64;
+        SSW_HIP_TRY(hipHostMalloc((void **)&w.out_host, (size_t)cap * sizeof(int64_t), hipHostMallocDefault));
+        SSW_HIP_TRY(hipMalloc((void **)&w.out, (size_t)cap * sizeof(int64_t)));
+        w.cap_k = cap;
+    }
+    return SSW_OK;
+}
+
 }  // namespace
 
 extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt_pos, int64_t n, int64_t k,
@@ -310,5 +394,38 @@ extern "C" ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt
         for (int64_t i = 0; i < k; ++i) out_prefix[i] = a[(size_t)i];
     }
     *mt_pos = mt.pos;
+    return SSW_OK;
+}
+
+// The same draw with the walk on a GPU (see k_np_trace): the draws are made on the host, into pinned memory, and cross
+// the link once (4 n bytes).  For the shapes the host walk is good at (n under 2^18, or a long prefix) this is the host
+// entry point.
+extern "C" ssw_status ssw_np_permutation_prefix_dev(int32_t device, uint32_t *mt_key624, int32_t *mt_pos, int64_t n,
+                                                    int64_t k, int64_t *out_prefix) {
+    SSW_REQUIRE(mt_key624 && mt_pos, "NULL state");
+    SSW_REQUIRE(*mt_pos >= 0 && *mt_pos <= MT_N, "MT19937 position %d outside [0, 624]", *mt_pos);
+    SSW_REQUIRE(n >= 0 && k >= 0, "negative size");
+    if (k > n) k = n;
+    if (device < 0 || n < ((int64_t)1 << 18) || n > 0x7fffffffll || k * 16 > n || k == 0)
+        return ssw_np_permutation_prefix(mt_key624, mt_pos, n, k, out_prefix);
+    SSW_REQUIRE(out_prefix, "NULL output");
+    ssw::DeviceGuard guard(device);
+    static thread_local DevWalk w;
+    SSW_TRY(dev_walk_reserve(w, device, n, k));
+    Mt mt;
+    mt.key = mt_key624;
+    mt.pos = *mt_pos;
+    mt.temper_from(mt.pos);
+    if (have_avx512()) draw_targets_avx512(mt, n, w.Jd_host);
+    else draw_targets(mt, n, w.Jd_host);
+    *mt_pos = mt.pos;
+    SSW_HIP_TRY(hipMemcpyAsync(w.Jd, w.Jd_host, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, w.stream));
+    SSW_HIP_TRY(hipMemsetAsync(w.head, 0xff, (size_t)n * sizeof(int32_t), w.stream));
+    hipLaunchKernelGGL(k_np_build_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w.stream, w.Jd, n, w.head, w.nxt);
+    hipLaunchKernelGGL(k_np_trace, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, w.stream, w.Jd, n, k, w.head, w.nxt, w.out);
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_HIP_TRY(hipMemcpyAsync(w.out_host, w.out, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, w.stream));
+    SSW_HIP_TRY(hipStreamSynchronize(w.stream));
+    memcpy(out_prefix, w.out_host, (size_t)k * sizeof(int64_t));
     return SSW_OK;
 }

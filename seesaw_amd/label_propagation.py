@@ -28,6 +28,7 @@ class LabelPropagation:
         self.verbose = verbose
         self.reg_lambda = float(reg_lambda)
         self.max_iter = int(max_iter)
+        self.device = int(device)
         self.reg_values = None
         self.weight_sum = np.asarray(W.sum(0)).reshape(-1).astype(np.float64)  # column sums, as the reference
         self.last_sweeps = 0

@@ -1,11 +1,22 @@
 """PseudoLR: propagate labels over the k-NN graph, then fit the logistic scorer on the real
 labels plus a sample of pseudo-labelled vectors (seesaw/loops/pseudo_lr.py:10-54)."""
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 
 from ..logistic_regression import LogisticRegressionPT
 from .graph_based import KnnProp2, get_label_prop
 from .point_based import PointBased
-from .util import makeXy_rows
+from .util import draw_unlabelled, makeXy_rows
+
+_SIDE = None  # one helper thread: the propagation's C call runs there (ctypes drops the GIL) beside the draw
+
+
+def _side():
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = ThreadPoolExecutor(max_workers=1, thread_name_prefix="seesaw-lp")
+    return _SIDE
 
 
 class PseudoLR(PointBased):
@@ -27,8 +38,24 @@ class PseudoLR(PointBased):
             loop.set_text_vec(tvec)
 
     def refine(self, change=None):
-        self.knn_based.refine()
-        rows, y, is_real = makeXy_rows(self.knn_based.state.knn_model, sample_size=self.options["sample_size"])
+        model = self.knn_based.state.knn_model
+        lp = getattr(model, "lp", None)
+        if lp is not None and hasattr(model, "propagate_now") and model.nvecs >= (1 << 18):
+            # KnnProp2.refine with its two halves apart: the labels are recorded, then the propagation (GPU, a few
+            # hundred us at 1.56 M vectors) runs on the helper thread while this one draws the pseudo-labelled sample
+            # -- which depends on how many vectors are labelled, not on their propagated scores (the reference draws
+            # after propagating, pseudo_lr.py:33-35; nothing else touches numpy's generator in between)
+            pos, neg = self.q.getXy(get_positions=True)
+            model.update_labels(np.concatenate([pos, neg]), np.concatenate([np.ones_like(pos), np.zeros_like(neg)]))
+            side = _side().submit(model.propagate_now)
+            try:
+                drawn = draw_unlabelled(model, self.options["sample_size"], device=lp.device)
+            finally:
+                side.result()
+            rows, y, is_real = makeXy_rows(model, sample_size=self.options["sample_size"], drawn=drawn)
+        else:
+            self.knn_based.refine()
+            rows, y, is_real = makeXy_rows(model, sample_size=self.options["sample_size"])
         params = dict(self.log_reg_params)
         params["max_iter"] = int(params.get("max_iter", 100))
         model = LogisticRegressionPT(regularizer_vector=self.state.tvec, device=getattr(self.index, "device", 0), **params)

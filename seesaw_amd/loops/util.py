@@ -28,15 +28,26 @@ def makeXy(idx, lr, sample_size, pseudoLabel=True):
     return idx.vectors[rows], y, is_real
 
 
-def makeXy_rows(lr, sample_size):
+def draw_unlabelled(lr, sample_size, device=None):
+    """np.random.permutation(#unlabelled)[:sample_size] for a ranker that keeps its labelled set as a map: depends on the
+    labels recorded so far, not on the propagation -- PseudoLR makes it while the propagation runs"""
+    return permutation_prefix(lr.is_labeled.shape[0] - len(lr._label_map), sample_size, device=device)
+
+
+def makeXy_rows(lr, sample_size, drawn=None):
     """same draw, returning row positions so the vectors can be gathered on the device.  A ranker that keeps its
     labelled set as a map (`_label_map`) spares the three passes over all vectors: the p-th unlabelled row is
-    p + #{i : labelled[i] - i <= p} over the sorted labelled rows."""
+    p + #{i : labelled[i] - i <= p} over the sorted labelled rows.  `drawn`: the permutation prefix, when the caller
+    has made the draw already (draw_unlabelled)."""
     label_map = getattr(lr, "_label_map", None)
     if label_map is not None:
         rows = np.fromiter(sorted(label_map), dtype=np.int64, count=len(label_map))  # == nonzero(is_labeled > 0)
         y = lr.labels[rows]
-        p = permutation_prefix(lr.is_labeled.shape[0] - rows.shape[0], sample_size)
+        if drawn is None:
+            # a ranker whose scores live on a GPU lends it to the draw's walk through the swaps (nprand.py)
+            dev = getattr(getattr(lr, "lp", None), "device", None) if getattr(lr, "scores_on_device", lambda: False)() else None
+            drawn = permutation_prefix(lr.is_labeled.shape[0] - rows.shape[0], sample_size, device=dev)
+        p = drawn
         pick = p + np.searchsorted(rows - np.arange(rows.shape[0]), p, side="right")  # == nonzero(~is_labeled)[0][p]
     else:
         is_labeled = lr.is_labeled > 0

@@ -9,8 +9,10 @@ import numpy as np
 from . import _lib
 
 
-def permutation_prefix(n: int, k: int) -> np.ndarray:
-    """== np.random.permutation(n)[:k] (int64), consuming the global RandomState exactly as that call does"""
+def permutation_prefix(n: int, k: int, device=None) -> np.ndarray:
+    """== np.random.permutation(n)[:k] (int64), consuming the global RandomState exactly as that call does.
+    `device`: GPU that follows the k positions through the swaps (ssw_np_permutation_prefix_dev; large n, short
+    prefixes); None keeps the whole computation on the host."""
     n, k = int(n), int(k)
     if n < 0:
         raise ValueError("negative dimensions are not allowed")  # np.arange(n) inside numpy's permutation raises too
@@ -20,7 +22,11 @@ def permutation_prefix(n: int, k: int) -> np.ndarray:
     key = np.array(state[1], dtype=np.uint32, copy=True)
     pos = ctypes.c_int32(int(state[2]))
     out = np.empty(max(0, min(n, k)), dtype=np.int64)
-    _lib.call("ssw_np_permutation_prefix", ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
-              ctypes.c_void_p(out.ctypes.data))
+    if device is None:
+        _lib.call("ssw_np_permutation_prefix", ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
+                  ctypes.c_void_p(out.ctypes.data))
+    else:
+        _lib.call("ssw_np_permutation_prefix_dev", int(device), ctypes.c_void_p(key.ctypes.data), ctypes.byref(pos), n, k,
+                  ctypes.c_void_p(out.ctypes.data))
     np.random.set_state((state[0], key, int(pos.value), state[3], state[4]))
     return out

@@ -60,6 +60,11 @@ class BaseLabelPropagationRanker:
         raise NotImplementedError("implement me")
 
     def update(self, idxs, labels):
+        self.update_labels(idxs, labels)
+        self.propagate_now()
+
+    def update_labels(self, idxs, labels):
+        """the bookkeeping half of update(): record the labels (no propagation yet)"""
         idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
         labels = np.asarray(labels, dtype=np.float64).reshape(-1)
         # np.isclose(label, 0) or np.isclose(label, 1) (atol 1e-8, rtol 1e-5) for the whole batch at once
@@ -67,6 +72,9 @@ class BaseLabelPropagationRanker:
         self.labels[idxs] = labels  # (a repeated id keeps its last label, as the per-item loop did)
         self.is_labeled[idxs] = 1
         self._label_map.update(zip(idxs.tolist(), labels.tolist()))
+
+    def propagate_now(self):
+        """the other half: propagate the recorded labels (PseudoLR runs this beside its pseudo-label draw)"""
         has_negative = any(v == 0 for v in self._label_map.values())
         if has_negative:  # the reference skips propagation until a negative label exists
             print(" propagating")
