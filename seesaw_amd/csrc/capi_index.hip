@@ -95,6 +95,7 @@ struct ssw_index {
     // [query dim f32][excluded ids SMALL_EXCL_CAP i64][packed result], and the sequence number the host spins on
     unsigned char *small_host = nullptr;
     unsigned small_seq = 0;
+    unsigned res_pending_seq = 0;  // != 0: the selection in flight publishes into res_host under this sequence number
     float *q2_dev = nullptr;  // second query vector (score_rows)
     PinnedStage q2_stage;
     // tile geometry + staging of the avg_score aggregation (rescore.hip)
@@ -126,6 +127,25 @@ static ssw_status check_query(const ssw_index *idx, const float *q_host) {
             return SSW_ERR_NUMERIC;
         }
     }
+    return SSW_OK;
+}
+
+// a host query reaches q_dev through the kernel-argument segment of a one-wave kernel (dim <= 768): a launch is a
+// third of what the 2-KB copy and its event cost on the host
+constexpr int Q_ARG_FLOATS = 768;
+struct QArg {
+    float v[Q_ARG_FLOATS];
+};
+__global__ void k_stage_query(QArg q, float *__restrict__ dst, int dim) {
+    for (int i = threadIdx.x; i < dim; i += 256) dst[i] = q.v[i];
+}
+static ssw_status stage_query(ssw_index *idx, const float *q_host) {
+    if (idx->dim > Q_ARG_FLOATS)
+        return idx->q_stage.push(idx->q_dev, q_host, (size_t)idx->dim * sizeof(float), idx->stream);
+    QArg q;
+    memcpy(q.v, q_host, (size_t)idx->dim * sizeof(float));
+    hipLaunchKernelGGL(k_stage_query, dim3(1), dim3(256), 0, idx->stream, q, idx->q_dev, idx->dim);
+    SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
 
@@ -591,12 +611,56 @@ ssw_status ssw_index_result_ptrs(ssw_index *idx, void **dev_keys, void **dev_cou
 
 // one pinned block receives the packed result [count, overflow, k, 0][keys k][best k]:
 // one async copy, one synchronisation
-static ssw_status fetch_results(ssw_index *idx, int32_t k, int32_t *count, bool *overflow) {
+static ssw_status ensure_res_host(ssw_index *idx) {
     const size_t cap = 16 + (size_t)SSW_MAX_TOPK * 12;
-    if (!idx->res_host) SSW_HIP_TRY(hipHostMalloc((void **)&idx->res_host, cap, hipHostMallocDefault));
-    SSW_HIP_TRY(hipMemcpyAsync(idx->res_host, idx->ws.packed, 16 + (size_t)k * 12, hipMemcpyDeviceToHost,
-                               idx->stream));
-    SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    if (!idx->res_host) {
+        SSW_HIP_TRY(hipHostMalloc((void **)&idx->res_host, cap, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(idx->res_host, 0, cap);
+    }
+    return SSW_OK;
+}
+
+// the next selection on this index publishes into res_host (see SelectWorkspace::host_packed)
+static ssw_status arm_host_result(ssw_index *idx) {
+    SSW_TRY(ensure_ws(idx));
+    SSW_TRY(ensure_res_host(idx));
+    unsigned char *dev_view = nullptr;
+    SSW_HIP_TRY(hipHostGetDevicePointer((void **)&dev_view, idx->res_host, 0));
+    unsigned seq = ++idx->small_seq;
+    if (seq == 0) seq = ++idx->small_seq;
+    idx->ws.host_packed = dev_view;
+    idx->ws.host_seq = seq;
+    idx->res_pending_seq = seq;
+    return SSW_OK;
+}
+
+static ssw_status wait_host_seq(hipStream_t stream, const unsigned *flag, unsigned seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return SSW_OK;
+        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    SSW_HIP_TRY(hipStreamSynchronize(stream));  // a long scan ahead of the selection: sleep in the runtime instead
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        set_error("topk: the selection kernel finished without publishing its result");
+        return SSW_ERR_HIP;
+    }
+    return SSW_OK;
+}
+
+// one pinned block receives the packed result [count, overflow, k, seq][keys k][best k]: written by the selection
+// itself when armed (arm_host_result), else one async copy + one synchronisation
+static ssw_status fetch_results(ssw_index *idx, int32_t k, int32_t *count, bool *overflow) {
+    SSW_TRY(ensure_res_host(idx));
+    if (idx->res_pending_seq != 0) {
+        const unsigned seq = idx->res_pending_seq;
+        idx->res_pending_seq = 0;
+        SSW_TRY(wait_host_seq(idx->stream, reinterpret_cast<const unsigned *>(idx->res_host) + 3, seq));
+    } else {
+        SSW_HIP_TRY(hipMemcpyAsync(idx->res_host, idx->ws.packed, 16 + (size_t)k * 12, hipMemcpyDeviceToHost,
+                                   idx->stream));
+        SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
+    }
     const int32_t *hdr = reinterpret_cast<const int32_t *>(idx->res_host);
     *count = hdr[0];
     *overflow = hdr[1] != 0;
@@ -621,6 +685,7 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
     if (overflow) {  // massive exact ties: rerun the selection on the deep path
         const float *values = idx->has_map ? idx->ws.img_score : idx->scores;
         const uint32_t *best = idx->has_map ? idx->ws.img_best : nullptr;
+        SSW_TRY(arm_host_result(idx));
         SSW_TRY(launch_select_topk_deep(idx->ws, values, idx->n_images, best, k, idx->device,
                                         idx->stream));
         SSW_TRY(fetch_results(idx, k, &count, &overflow));
@@ -730,12 +795,14 @@ ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *ex
     }
     if (q_host) {
         SSW_TRY(check_query(idx, q_host));
-        SSW_TRY(idx->q_stage.push(idx->q_dev, q_host, (size_t)idx->dim * sizeof(float),
-                                  idx->stream));
+        SSW_TRY(stage_query(idx, q_host));
         SSW_TRY(do_scan(idx, idx->q_dev));
     }
     if (idx->n_images == 0) return SSW_OK;
     SSW_TRY(ssw_index_set_excluded(idx, excluded_images, n_excluded));
+    // the selection's last kernel writes the packed result into the pinned mirror and releases a sequence word: the
+    // host spins on it (no device-to-host copy, no stream wait)
+    SSW_TRY(arm_host_result(idx));
     SSW_TRY(do_select(idx, k));
     return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
 }

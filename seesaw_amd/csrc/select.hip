@@ -23,6 +23,7 @@
 // steps 2-4 through a device bitmap.  Bound: reads 4 B/image three times -- < 0.6 % of
 // the scan's traffic at dim=512.
 #include <algorithm>
+#include <iterator>
 
 #include "ssw_common.h"
 
@@ -46,15 +47,29 @@ __device__ __forceinline__ bool is_excluded(const uint32_t *__restrict__ excl, i
     return excl != nullptr && ((excl[i >> 5] >> (i & 31)) & 1u);
 }
 
-__global__ void k_set_bits(uint32_t *bits, const int64_t *ids, int64_t n, int64_t m, int set) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t id = ids[i];
-    if (id < 0 || id >= m) return;
-    if (set)
+// a short difference between two excluded sets, in the kernel-argument segment: ids[0, n_set) gain their bit,
+// ids[n_set, n_set + n_clear) lose it
+constexpr int EXCL_ARG_IDS = 60;
+struct ExclDelta {
+    int32_t ids[EXCL_ARG_IDS];
+};
+__global__ void k_excl_delta_arg(uint32_t *bits, ExclDelta d, int n_set, int n_clear) {
+    const int i = threadIdx.x;
+    if (i >= n_set + n_clear) return;
+    const int32_t id = d.ids[i];
+    if (i < n_set)
         atomicOr(&bits[id >> 5], 1u << (id & 31));
     else
-        bits[id >> 5] = 0u;  // clearing whole words is fine: every set bit is in the old list
+        atomicAnd(&bits[id >> 5], ~(1u << (id & 31)));
+}
+__global__ void k_excl_delta(uint32_t *bits, const int64_t *ids, int64_t n_set, int64_t n_clear) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_set + n_clear) return;
+    const int64_t id = ids[i];
+    if (i < n_set)
+        atomicOr(&bits[id >> 5], 1u << (id & 31));
+    else
+        atomicAnd(&bits[id >> 5], ~(1u << (id & 31)));
 }
 
 __global__ void k_image_max(const float *__restrict__ scores, const int64_t *__restrict__ row_start,
@@ -580,33 +595,46 @@ void select_free(SelectWorkspace &ws) {
 
 ssw_status select_set_excluded(SelectWorkspace &ws, int64_t n_images, const int64_t *ids_host,
                                int64_t n, hipStream_t stream) {
-    // clear the bits of the previously installed list, then set the new one
-    if (ws.excl_dirty && ws.n_excluded_distinct > 0) {
-        const int64_t old = ws.n_excluded_distinct;
-        hipLaunchKernelGGL(k_set_bits, dim3((unsigned)((old + 255) / 256)), dim3(256), 0, stream,
-                           ws.excl_bits, ws.excl_ids, old, n_images, 0);
+    // A session's list grows by a batch per round (InteractiveQuery.returned): what reaches the device is the
+    // difference from the installed set -- a few ids in the kernel-argument segment, no copy -- not the whole list.
+    static thread_local std::vector<int64_t> neu, delta;
+    neu.assign(ids_host, ids_host + (n > 0 ? n : 0));
+    if (!std::is_sorted(neu.begin(), neu.end())) std::sort(neu.begin(), neu.end());
+    neu.erase(std::unique(neu.begin(), neu.end()), neu.end());
+    const std::vector<int64_t> &cur = ws.excl_installed;
+    delta.clear();
+    std::set_difference(neu.begin(), neu.end(), cur.begin(), cur.end(), std::back_inserter(delta));
+    const int64_t n_set = (int64_t)delta.size();
+    std::set_difference(cur.begin(), cur.end(), neu.begin(), neu.end(), std::back_inserter(delta));
+    const int64_t n_clear = (int64_t)delta.size() - n_set;
+    if (n_set + n_clear > 0) {
+        if (n_set + n_clear <= EXCL_ARG_IDS) {
+            ExclDelta d;
+            memset(&d, 0, sizeof(d));
+            for (int64_t i = 0; i < n_set + n_clear; ++i) d.ids[i] = (int32_t)delta[(size_t)i];
+            hipLaunchKernelGGL(k_excl_delta_arg, dim3(1), dim3(64), 0, stream, ws.excl_bits, d, (int)n_set, (int)n_clear);
+        } else {
+            const int64_t m = n_set + n_clear;
+            if (m > ws.excl_ids_cap) {
+                SSW_HIP_TRY(hipStreamSynchronize(stream));  // a kernel may still be reading the old buffer
+                (void)hipFree(ws.excl_ids);
+                ws.excl_ids = nullptr;
+                ws.excl_ids_cap = 0;
+                int64_t cap = 1024;
+                while (cap < m) cap <<= 1;
+                SSW_TRY(dev_alloc(&ws.excl_ids, cap));
+                ws.excl_ids_cap = cap;
+            }
+            SSW_TRY(ws.excl_stage.push(ws.excl_ids, delta.data(), (size_t)m * sizeof(int64_t), stream));
+            hipLaunchKernelGGL(k_excl_delta, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, ws.excl_bits,
+                               ws.excl_ids, n_set, n_clear);
+        }
         SSW_HIP_TRY(hipGetLastError());
     }
-    ws.excl_dirty = false;
-    ws.n_excluded_distinct = 0;
-    if (n <= 0) return SSW_OK;
-    if (n > ws.excl_ids_cap) {
-        // the old list must have been consumed by the clear kernel before its buffer goes
-        SSW_HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(ws.excl_ids);
-        ws.excl_ids = nullptr;
-        ws.excl_ids_cap = 0;
-        int64_t cap = 1024;
-        while (cap < n) cap <<= 1;
-        SSW_TRY(dev_alloc(&ws.excl_ids, cap));
-        ws.excl_ids_cap = cap;
-    }
-    SSW_TRY(ws.excl_stage.push(ws.excl_ids, ids_host, (size_t)n * sizeof(int64_t), stream));
-    hipLaunchKernelGGL(k_set_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       ws.excl_bits, ws.excl_ids, n, n_images, 1);
-    SSW_HIP_TRY(hipGetLastError());
-    ws.excl_dirty = true;
-    ws.n_excluded_distinct = n;  // length of the installed list (may contain repeats)
+    ws.excl_installed.swap(neu);
+    ws.excl_dirty = !ws.excl_installed.empty();
+    ws.n_excluded_distinct = (int64_t)ws.excl_installed.size();
+    (void)n_images;  // the ids were range-checked by the caller
     return SSW_OK;
 }
 
@@ -669,15 +697,19 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
         return SSW_ERR_UNSUPPORTED;
     }
     const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
+    unsigned char *packed = ws.host_packed ? ws.host_packed : ws.packed;
+    FinalExchange xg = ws.xchg;
+    xg.host_seq = ws.host_packed ? ws.host_seq : 0u;
+    ws.host_packed = nullptr;
     if (m <= FINAL_CAP) {  // one launch: the sort takes every image
-        FinalExchange x = ws.xchg;
+        FinalExchange x = xg;
         x.values_all = values;
         x.m_all = m;
         x.excl = excl;
         SSW_TRY(final_lds_ready());
-    hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, (const uint64_t *)nullptr,
+        hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, (const uint64_t *)nullptr,
                            0, 0, (const int32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (int)k,
-                           best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, x);
+                           best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, packed, x);
         SSW_HIP_TRY(hipGetLastError());
         return SSW_OK;
     }
@@ -691,7 +723,7 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     SSW_TRY(final_lds_ready());
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, packed, xg);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -731,9 +763,13 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
     hipLaunchKernelGGL(k_collect_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state,
                        ws.cand, threshold);
     SSW_TRY(final_lds_ready());
+    unsigned char *packed = ws.host_packed ? ws.host_packed : ws.packed;
+    FinalExchange xg = ws.xchg;
+    xg.host_seq = ws.host_packed ? ws.host_seq : 0u;
+    ws.host_packed = nullptr;
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,
                        0, 0, (const int32_t *)nullptr, ws.state + ST_NCAND, (const uint32_t *)ws.state, (int)k,
-                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, ws.packed, ws.xchg);
+                       best_rows_or_null, ws.out_keys, ws.out_count, ws.out_best, packed, xg);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/seesaw_hip.h"
 
@@ -194,6 +195,11 @@ struct SelectWorkspace {
     int64_t excl_ids_cap = 0;
     int64_t n_excluded_distinct = 0;  // distinct excluded images currently installed
     bool excl_dirty = false;          // bitmap currently has bits set
+    std::vector<int64_t> excl_installed;  // the installed set, sorted: a new list costs its difference from this one
+    // when set, the next selection writes its packed result here (pinned host memory, device view) and releases
+    // host_seq into header word 3 instead of filling `packed`; cleared by the launch
+    unsigned char *host_packed = nullptr;
+    unsigned host_seq = 0;
 };
 
 ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map);

@@ -69,7 +69,8 @@ class RegModule:
         n = len(y)
         if n > 0:
             # 1 / (vectors of the same image): matchdf.groupby('dbidx').size() merged back (multi_reg.py:163-165)
-            _, inv, cnt = np.unique(matchdf.dbidx.values, return_inverse=True, return_counts=True)
+            dbidx = matchdf if isinstance(matchdf, np.ndarray) else matchdf.dbidx.values
+            _, inv, cnt = np.unique(dbidx, return_inverse=True, return_counts=True)
             vec_weight = 1.0 / cnt[inv].astype(np.float64)
             if X is not None:
                 self._engine.set_data(X, center=True)
@@ -108,9 +109,15 @@ class MultiReg(PointBased):
             self.curr_vec = self.curr_qvec
 
     def refine(self, change=None):
-        matchdf = self.q.getXy()
-        rows = matchdf.index.values
-        y = matchdf.ys.values
+        arrays = getattr(self.q, "_matched_arrays", None)
+        if arrays is not None and hasattr(self.q.index, "_row_dbidx"):  # getXy()'s columns without the frame
+            rows, miou = arrays()
+            y = (miou > 0).astype("float")
+            matchdf = self.q.index._row_dbidx[rows]
+        else:
+            matchdf = self.q.getXy()
+            rows = matchdf.index.values
+            y = matchdf.ys.values
         assert self.curr_qvec is not None
         o = self.options
         model = RegModule(dim=self.q.index.vectors.shape[1], xlx_matrix=self.xlx_matrix, qvec=self.curr_qvec,
