@@ -936,8 +936,9 @@ ssw_status ssw_topk_merge_msgs_dev(int32_t device, void *hip_stream, const uint6
                              reinterpret_cast<long long *>(dev_flags_seen_or_null), (hipStream_t)hip_stream);
 }
 
-ssw_status ssw_tune_topk(int32_t small_path) {
-    g_small_path = small_path != 0;
+ssw_status ssw_tune_topk(int32_t flags) {
+    g_small_path = (flags & 1) != 0;
+    tune_select((flags & 2) != 0);
     return SSW_OK;
 }
 

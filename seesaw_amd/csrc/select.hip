@@ -38,6 +38,15 @@ constexpr size_t FINAL_LDS_BYTES = (size_t)(FINAL_CAP + FINAL_CAP / 2) * sizeof(
 // one global atomic each and the final sort is a one-workgroup bitonic network, so 8192 candidates cost 17 + 30 us
 // where the 9 us of a second level leave a few hundred (1.56 M rows / 120 000 images: 99 -> 60 us of selection).
 constexpr int LEVEL2_FROM = 1024;
+// sampled threshold (launch_select_topk): from this many values on, one 16-element block in SAMPLE_R, the sample's
+// rank-th largest value as threshold, rank = max(SAMPLE_RANK / 2, 3 k / SAMPLE_R) (expected candidates
+// max(1536 +- 310, 3 k); 3072 +- 450 at most: under the 4096 the final selection handles with four keys a thread), for
+// k up to SAMPLE_MAX_K
+constexpr int64_t SAMPLE_FROM = (int64_t)1 << 24;
+constexpr int64_t SAMPLE_R = 64;
+constexpr int SAMPLE_RANK = 48;
+constexpr int SAMPLE_MAX_K = 1024;
+bool g_select_sampled = true;  // ssw_tune_topk bit 1
 enum StateSlot : int {
     ST_B1 = 0, ST_ABOVE1, ST_CNT1, ST_B2, ST_ABOVE2, ST_CNT2, ST_MODE, ST_NCAND, ST_OVERFLOW, ST_K,
     ST_WORDS = 16
@@ -92,11 +101,13 @@ __global__ void k_image_max(const float *__restrict__ scores, const int64_t *__r
 }
 
 // LEVEL 1: bins = key >> 20.  LEVEL 2: bins = (key >> 8) & 0xfff for keys with key>>20 == b1.
+// sample_r > 1: the histogram of a SAMPLE -- blocks of 16 consecutive elements (one 64-byte segment), one block in
+// every sample_r (see launch_select_topk's sampled threshold)
 template <int LEVEL>
 __global__ __launch_bounds__(256) void k_hist(const float *__restrict__ values, int64_t m,
                                               const uint32_t *__restrict__ excl,
                                               uint32_t *__restrict__ hist,
-                                              const uint32_t *__restrict__ state) {
+                                              const uint32_t *__restrict__ state, int64_t sample_r) {
     __shared__ uint32_t lh[NBINS];
     uint32_t b1 = 0;
     if (LEVEL == 2) {
@@ -106,15 +117,38 @@ __global__ __launch_bounds__(256) void k_hist(const float *__restrict__ values, 
     for (int i = threadIdx.x; i < NBINS; i += 256) lh[i] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
-        if (is_excluded(excl, i)) continue;
-        const uint32_t key = f32_to_ord(values[i]);
+    const int64_t total = sample_r > 1 ? (m / (16 * sample_r)) * 16 : m;
+    auto tally = [&](float v, int64_t i) {
+        if (is_excluded(excl, i)) return;
+        const uint32_t key = f32_to_ord(v);
         if (LEVEL == 1) {
             atomicAdd(&lh[key >> 20], 1u);
         } else if ((key >> 20) == b1) {
             atomicAdd(&lh[(key >> 8) & 0xfffu], 1u);
         }
+    };
+    // 16-byte loads, two in flight per thread (the buffers are hipMalloc'ed: 16-byte aligned)
+    const float4 *v4 = reinterpret_cast<const float4 *>(values);
+    const int64_t total4 = total >> 2;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += 2 * stride) {
+        const int64_t j2 = j + stride;
+        const int64_t q0 = sample_r > 1 ? (((j >> 2) * sample_r) << 2) + (j & 3) : j;
+        const int64_t q1 = sample_r > 1 ? (((j2 >> 2) * sample_r) << 2) + (j2 & 3) : j2;
+        const float4 a = v4[q0];
+        const float4 b = j2 < total4 ? v4[q1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tally(a.x, 4 * q0);
+        tally(a.y, 4 * q0 + 1);
+        tally(a.z, 4 * q0 + 2);
+        tally(a.w, 4 * q0 + 3);
+        if (j2 < total4) {
+            tally(b.x, 4 * q1);
+            tally(b.y, 4 * q1 + 1);
+            tally(b.z, 4 * q1 + 2);
+            tally(b.w, 4 * q1 + 3);
+        }
     }
+    if (sample_r <= 1)  // the last m % 4 values
+        for (int64_t i = (total4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) tally(values[i], i);
     __syncthreads();
     for (int i = threadIdx.x; i < NBINS; i += 256) {
         const uint32_t c = lh[i];
@@ -194,15 +228,36 @@ __global__ __launch_bounds__(256) void k_collect(const float *__restrict__ value
     const uint32_t prefix = mode ? ((state[ST_B1] << 12) | state[ST_B2]) : state[ST_B1];
     const int shift = mode ? 8 : 20;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) {
-        if (is_excluded(excl, i)) continue;
-        const uint32_t key = f32_to_ord(values[i]);
-        if ((key >> shift) >= prefix) {
+    auto take = [&](float v, int64_t i) {
+        const uint32_t key = f32_to_ord(v);
+        if ((key >> shift) >= prefix && !is_excluded(excl, i)) {
             const uint32_t slot = atomicAdd(&state[ST_NCAND], 1u);
             if (slot < (uint32_t)FINAL_CAP)
                 cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
         }
+    };
+    // 16-byte loads, four in flight per thread (the buffers are hipMalloc'ed: 16-byte aligned)
+    const float4 *v4 = reinterpret_cast<const float4 *>(values);
+    const int64_t m4 = m >> 2;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < m4; j += 4 * stride) {
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ju = j + u * stride;
+            a[u] = v4[ju < m4 ? ju : j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ju = j + u * stride;
+            if (ju < m4) {
+                take(a[u].x, 4 * ju);
+                take(a[u].y, 4 * ju + 1);
+                take(a[u].z, 4 * ju + 2);
+                take(a[u].w, 4 * ju + 3);
+            }
+        }
     }
+    for (int64_t i = (m4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += stride) take(values[i], i);
 }
 
 
@@ -487,8 +542,12 @@ __global__ __launch_bounds__(1024) void k_final(const uint64_t *__restrict__ key
         if (last || (i == 0 && key == 0ull)) {
             const int out = key != 0ull ? i + 1 : 0;
             // overflow of the fast path (more candidates than the final sort takes), for the host
-            const int ovf = (state_or_null && (state_or_null[ST_OVERFLOW] != 0 ||
-                                               state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
+            // ... or of the sampled threshold: fewer candidates than asked for although the threshold left some out
+            int ovf = (state_or_null && (state_or_null[ST_OVERFLOW] != 0 ||
+                                         state_or_null[ST_NCAND] > (uint32_t)FINAL_CAP)) ? 1 : 0;
+            if (x.sampled && state_or_null && state_or_null[ST_NCAND] < (uint32_t)k &&
+                (state_or_null[ST_MODE] != 0 || state_or_null[ST_B1] != 0))
+                ovf = 1;
             count_out[0] = out;
             if (state_or_null || x.values_all) count_out[1] = ovf;
             if (x.msg_out) x.msg_out[x.msg_len - 1] = (uint64_t)(uint32_t)out | ((uint64_t)(uint32_t)ovf << 32);
@@ -556,6 +615,8 @@ int grid_for(int64_t m, int device) {
 }
 
 }  // namespace
+
+void tune_select(bool sampled) { g_select_sampled = sampled; }
 
 ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map) {
     SSW_TRY(dev_alloc(&ws.hist1, 2 * NBINS + ST_WORDS));
@@ -715,10 +776,21 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     }
     SSW_HIP_TRY(hipMemsetAsync(ws.hist1, 0, (2 * NBINS + ST_WORDS) * sizeof(uint32_t), stream));
     const int g = grid_for(m, device);
-    hipLaunchKernelGGL(k_hist<1>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist1, ws.state);
-    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, (int)k);
-    hipLaunchKernelGGL(k_hist<2>, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist2, ws.state);
-    hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, (int)k);
+    // Large m: the two histogram passes over all m values (147 us at 100 M) only serve to find a threshold that leaves
+    // a few thousand candidates.  A 1-in-64 sample finds one as well: the 24-bit prefix of the sample's 48th largest
+    // value leaves ~3072 +- 450 of the m (blocks of 16 neighbours: wider for clustered scores), always every value at
+    // or above it -- so the result is exact whenever at least k candidates came out; if fewer did (or more than the
+    // final sort takes) the overflow word is raised and the caller reruns the deep path, as for mass ties.
+    const bool sampled = g_select_sampled && m >= SAMPLE_FROM && k <= SAMPLE_MAX_K;
+    const int64_t sr = sampled ? SAMPLE_R : 1;
+    // expected candidates max(1536, 3 k): rank 24 ... 48 of the sample
+    const int rank = sampled ? std::max(SAMPLE_RANK / 2, (int)((3 * (int64_t)k + SAMPLE_R - 1) / SAMPLE_R)) : (int)k;
+    const int gs = sampled ? grid_for(m / sr, device) : g;
+    xg.sampled = sampled ? 1 : 0;
+    hipLaunchKernelGGL(k_hist<1>, dim3(gs), dim3(256), 0, stream, values, m, excl, ws.hist1, ws.state, sr);
+    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, rank);
+    hipLaunchKernelGGL(k_hist<2>, dim3(gs), dim3(256), 0, stream, values, m, excl, ws.hist2, ws.state, sr);
+    hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, rank);
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
     SSW_TRY(final_lds_ready());
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,

@@ -173,6 +173,7 @@ struct FinalExchange {
     const int64_t *excl_ids = nullptr;
     int64_t n_excl = 0;
     unsigned host_seq = 0;
+    int32_t sampled = 0;  // the threshold came from a sample: too few candidates is a failure, reported as overflow
 };
 
 // select.hip: exact top-k of per-image best scores.
@@ -202,6 +203,7 @@ struct SelectWorkspace {
     unsigned host_seq = 0;
 };
 
+void tune_select(bool sampled);
 ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map);
 void select_free(SelectWorkspace &ws);
 // install the excluded set (host ids) into ws.excl_bits; counts distinct ids.

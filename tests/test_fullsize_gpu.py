@@ -101,3 +101,46 @@ def test_c4_hundred_million_rows_properties(DeviceIndex, oracle):
         shard.close()
     m_imgs, m_scores = _merge(parts, k)
     assert np.array_equal(m_imgs, imgs) and np.array_equal(bits(m_scores), bits(scores))
+
+
+@pytest.mark.parametrize("shape", ["gaussian", "sorted", "clustered", "hidden_from_the_sample", "mostly_excluded"])
+def test_sampled_threshold_selection_is_exact(DeviceIndex, shape):
+    """from 2^24 values on the selection takes its threshold from a 1-in-16 sample (blocks of 16 neighbours); whatever
+    the sample sees, the answer is the exact top-k in (score desc, position asc) order -- a sample that misleads
+    (here: every large value sits where no sampled block looks) ends in the deep path instead"""
+    import torch
+    from seesaw_amd import _lib
+    n = (1 << 24) + 12345
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < n * 2048 + (8 << 30):
+        pytest.skip("needs 40 GB of device memory")
+    rng = np.random.default_rng(len(shape))
+    s = (rng.standard_normal(n) * 0.044).astype(np.float32)
+    excluded = rng.choice(n, 500, replace=False)
+    if shape == "sorted":
+        s.sort()
+    elif shape == "clustered":  # neighbours share most of their score, like the tiles of one image
+        s = (np.repeat(rng.standard_normal(n // 16 + 1), 16)[:n] * 0.04 + s * 0.1).astype(np.float32)
+    elif shape == "hidden_from_the_sample":
+        pos = np.arange(n)
+        s[(pos % 256) >= 16] += np.float32(1.0)  # sampled blocks are elements 0..15 of every 256
+    elif shape == "mostly_excluded":
+        excluded = np.setdiff1d(np.arange(n), rng.choice(n, 3000, replace=False))
+    idx = DeviceIndex.synthetic(n, 512, seed=1)
+    try:
+        idx.load_scores(s)
+        sx = s.astype(np.float64)
+        sx[excluded] = -np.inf
+        for k in (1, 100, 2048):
+            part = np.argpartition(-sx, k + 64)[: k + 64]
+            order = part[np.lexsort((part, -sx[part]))][:k]
+            if shape == "mostly_excluded":
+                order = order[np.isfinite(sx[order])]
+            for flags in (3, 1):
+                _lib.call("ssw_tune_topk", flags)
+                imgs, scores, rows = idx.topk(None, k, excluded=excluded)
+                assert np.array_equal(imgs, order), (shape, k, flags)
+                assert np.array_equal(bits(scores), bits(s[order]))
+    finally:
+        _lib.call("ssw_tune_topk", 3)
+        idx.close()

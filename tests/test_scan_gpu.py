@@ -131,7 +131,7 @@ def test_small_index_form_equals_general_path(DeviceIndex, oracle, tiles):
             k = (10, 60, 4096)[rnd % 3]
             _lib.call("ssw_tune_topk", 0)
             want = ref_idx.topk(q if rnd % 2 == 0 else None, k, excluded=returned)
-            _lib.call("ssw_tune_topk", 1)
+            _lib.call("ssw_tune_topk", 3)
             got = idx.topk(q if rnd % 2 == 0 else None, k, excluded=returned)
             for a, b in zip(got, want):
                 assert np.array_equal(bits(a) if a.dtype == np.float32 else a, bits(b) if b.dtype == np.float32 else b), rnd
@@ -143,7 +143,7 @@ def test_small_index_form_equals_general_path(DeviceIndex, oracle, tiles):
         got = idx.topk(None, 5, excluded=range(n_images))
         assert got[0].shape[0] == 0
     finally:
-        _lib.call("ssw_tune_topk", 1)
+        _lib.call("ssw_tune_topk", 3)
         idx.close()
         ref_idx.close()
 

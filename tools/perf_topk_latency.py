@@ -46,7 +46,7 @@ def main():
                     _lib.call("ssw_index_topk", *args)
                 dt = time.perf_counter() - t0
             print(f"{name}, C call only, {'scan + select' if with_q else 'select only'}: {1e6 * dt / reps:.1f} us")
-    _lib.call("ssw_tune_topk", 1)
+    _lib.call("ssw_tune_topk", 3)
     idx.close()
 
 
