@@ -54,9 +54,12 @@ constexpr bool epi_residual(int e) { return e == EPI_F32_BIAS_RESIDUAL || e == E
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, const float *__restrict__ bias,
                                                const float *__restrict__ residual, void *__restrict__ Cout,
-                                               const GemmLn &ln, float mean, float rstd, float *sum, float *sq) {
+                                               const GemmLn &ln, float mean, float rstd, float *sum, float *sq,
+                                               const float *c1_lds = nullptr, const float *c2_lds = nullptr) {
     if constexpr (epi_ln(EPI)) {  // (the accumulators of these variants start from zero; c2 is in `bias`)
-        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(ln.c1 + col), c2 = *reinterpret_cast<const f32x4 *>(bias + col);
+        // c1 / c2 of this tile's columns were requested before the K loop and parked in LDS: read from memory here they
+        // were a round trip to L2 in every tile's epilogue (+8.5 us on the QKV and fc1 products of the B = 200 tower)
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(c1_lds), c2 = *reinterpret_cast<const f32x4 *>(c2_lds);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * c1[r]) + c2[r];
     }
@@ -294,10 +297,13 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     // LDS-DMA piece long landed; in between they cost eight registers and no wait.
     constexpr int LN_NP = 8;  // partial pairs held in registers (hidden width <= 1024)
     float2 ln_part[LN_NP];
+    f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-31: c1 of 4 of the tile's 128 columns, 32-63: c2
+    float *const ln_c = ln_lds + 2 * TM;         // [2][128] behind the statistics
     if constexpr (epi_ln(EPI)) {
         const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < TM ? t : 0), M - 1) * ln.np_in;
 #pragma unroll
         for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];  // unconditional: no select, hence no early wait
+        ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 32) ? bias : ln.c1) + n0 + (t & 31) * 4);
     }
 
     // fragment byte offset inside an image: row (16-row block + fr), chunk (4 ks + fq) ^ (fr >> 1)
@@ -432,6 +438,8 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
             ln_lds[2 * t] = mean;
             ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
         }
+        asm volatile("" : "+v"(ln_cpre));
+        if (t < 64) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
         __syncthreads();
     }
 #pragma unroll
@@ -447,7 +455,8 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int col = n0 + wn * (128 / WN) + j * 16 + fq * 4;
-                epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq);
+                epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq,
+                                    ln_c + (col - n0), ln_c + 128 + (col - n0));
             }
         }
         if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {  // this wave's 128 / WN columns of the row: the four fq lanes
@@ -560,7 +569,10 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     float *const ln_lds = reinterpret_cast<float *>(smem + 2 * T256_STAGE);  // [256][2] row statistics
     constexpr int LN_NP = 8;  // as in gemm_glds: requested now, first touched behind the K loop
     float2 ln_part[LN_NP];
+    f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-63: c1 of 4 of the tile's 256 columns, 64-127: c2
+    float *const ln_c = ln_lds + 2 * 256;        // [2][256] behind the statistics
     if constexpr (epi_ln(EPI)) {
+        ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 64) ? bias : ln.c1) + n0 + (t & 63) * 4);
         const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < 256 ? t : 0), M - 1) * ln.np_in;
 #pragma unroll
         for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];
@@ -661,6 +673,8 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
             ln_lds[2 * t] = mean;
             ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
         }
+        asm volatile("" : "+v"(ln_cpre));
+        if (t < 128) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
         __syncthreads();
     }
 #pragma unroll
@@ -676,7 +690,8 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = n0 + wc * 64 + j * 16 + fq * 4;
-            epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq);
+            epilogue_store<EPI>(acc[i][j], (int64_t)row * N + col, col, bias, residual, Cout, ln, mean, rstd, &ssum, &ssq,
+                                ln_c + (col - n0), ln_c + 256 + (col - n0));
         }
     }
 }
@@ -685,7 +700,7 @@ template <int EPI>
 ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                       int N, int K, const GemmLn &ln) {
     static bool attr_set = false;
-    constexpr int lds = 2 * T256_STAGE + 2048;  // + the rows' LayerNorm statistics (EPI 4 / 5)
+    constexpr int lds = 2 * T256_STAGE + 2048 + 2048;  // + the rows' LayerNorm statistics and the columns' c1 / c2 (EPI 4 / 5)
     if (!attr_set) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_256<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
