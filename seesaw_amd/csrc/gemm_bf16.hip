@@ -699,12 +699,14 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
 template <int EPI>
 ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                       int N, int K, const GemmLn &ln) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {false};  // the attribute is per device
     constexpr int lds = 2 * T256_STAGE + 2048 + 2048;  // + the rows' LayerNorm statistics and the columns' c1 / c2 (EPI 4 / 5)
-    if (!attr_set) {
+    int dev_id = 0;
+    SSW_HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_256<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
@@ -737,12 +739,14 @@ int g_gemm_variant = 14;
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
                        int M, int N, int K, const GemmLn &ln) {
-    static bool attr_set = false;
-    constexpr int lds = DEPTH * (TM * 128 + G_WIMG) + WN * TM * 8;  // + row statistics / their per-wave partials
-    if (!attr_set) {
+    static bool attr_set[64] = {false};  // the attribute is per device
+    constexpr int lds = DEPTH * (TM * 128 + G_WIMG) + WN * TM * 8;  // + row statistics / their per-wave partials, c1 / c2
+    int dev_id = 0;
+    SSW_HIP_TRY(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_glds<EPI, DEPTH, TM, PIPE, WN>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     const int m_tiles = (M + TM - 1) / TM, n_tiles = N / BN;
     const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
