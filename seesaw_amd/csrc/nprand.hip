@@ -190,6 +190,30 @@ SSW_AVX512 void draw_targets_avx512(Mt &mt, int64_t n, uint32_t *Jd) {
                 mt_refill_avx512(mt.key, mt.out);
                 mt.pos = 0;
             }
+            // sixty-four words a trip while every one of them is decided by the bounds (accepted if <= i - 64,
+            // rejected if > i): the loop-carried chain (popcount -> i -> broadcast -> compares) is paid once per 64
+            while (mt.pos + 64 <= MT_N && i - 64 >= lo) {
+                const __m512i ta = _mm512_set1_epi32((int)(i - 64)), tr = _mm512_set1_epi32((int)i);
+                const __m512i v0 = _mm512_and_si512(_mm512_loadu_si512(mt.out + mt.pos), vmask);
+                const __m512i v1 = _mm512_and_si512(_mm512_loadu_si512(mt.out + mt.pos + 16), vmask);
+                const __m512i v2 = _mm512_and_si512(_mm512_loadu_si512(mt.out + mt.pos + 32), vmask);
+                const __m512i v3 = _mm512_and_si512(_mm512_loadu_si512(mt.out + mt.pos + 48), vmask);
+                const __mmask16 a0 = _mm512_cmple_epu32_mask(v0, ta), a1 = _mm512_cmple_epu32_mask(v1, ta);
+                const __mmask16 a2 = _mm512_cmple_epu32_mask(v2, ta), a3 = _mm512_cmple_epu32_mask(v3, ta);
+                const __mmask16 r0 = _mm512_cmpgt_epu32_mask(v0, tr), r1 = _mm512_cmpgt_epu32_mask(v1, tr);
+                const __mmask16 r2 = _mm512_cmpgt_epu32_mask(v2, tr), r3 = _mm512_cmpgt_epu32_mask(v3, tr);
+                if ((__mmask16)((a0 | r0) & (a1 | r1) & (a2 | r2) & (a3 | r3)) != (__mmask16)0xffff) break;
+                const int c0 = __builtin_popcount((unsigned)a0), c1 = __builtin_popcount((unsigned)a1);
+                const int c2 = __builtin_popcount((unsigned)a2), c3 = __builtin_popcount((unsigned)a3);
+                _mm512_storeu_si512(o, _mm512_maskz_compress_epi32(a0, v0));
+                _mm512_storeu_si512(o + c0, _mm512_maskz_compress_epi32(a1, v1));
+                _mm512_storeu_si512(o + c0 + c1, _mm512_maskz_compress_epi32(a2, v2));
+                _mm512_storeu_si512(o + c0 + c1 + c2, _mm512_maskz_compress_epi32(a3, v3));
+                const int c = c0 + c1 + c2 + c3;
+                o += c;
+                i -= c;
+                mt.pos += 64;
+            }
             while (mt.pos + 16 <= MT_N && i - 16 >= lo) {
                 const __m512i v = _mm512_and_si512(_mm512_loadu_si512(mt.out + mt.pos), vmask);
                 const __mmask16 acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(i - 16)));
