@@ -389,7 +389,7 @@ ssw_status ssw_np_permutation_prefix(uint32_t *mt_key624, int32_t *mt_pos, int64
                                      int64_t *out_prefix);
 /* The same draw (same values, same stream position afterwards) with the walk through the swaps on GPU `device`: the host
  * makes the n - 1 draws into pinned memory, the device links the steps by target with one atomic exchange each and traces
- * the k wanted positions independently (~6 short list walks each) -- 2.4 ms -> 0.8 ms for 10 000 of 1.56 M.  device < 0,
+ * the k wanted positions independently (~6 short list walks each) -- 2.4 ms -> 0.7 ms for 10 000 of 1.56 M.  device < 0,
  * n < 2^18 or k > n / 16: the host-only form above. */
 ssw_status ssw_np_permutation_prefix_dev(int32_t device, uint32_t *mt_key624, int32_t *mt_pos, int64_t n, int64_t k,
                                          int64_t *out_prefix);
