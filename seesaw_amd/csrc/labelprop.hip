@@ -368,6 +368,7 @@ struct ssw_lp {
     double *vals = nullptr;
     int64_t ids_cap = 0;
     int64_t n_labels_installed = 0;
+    int sweeps_hint = 0;  // sweeps the previous converged run needed (sizes the next run's first batch)
     // device-resident chaining: an installed prior (reg_values == start iterate of every call of the ranking
     // loop) and the buffer holding the last result
     bool prior_installed = false;
@@ -639,9 +640,13 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
     LpState st;
     memset(&st, 0, sizeof(st));
     int issued = 0;
-    const int batch = 8;
+    // Sweeps are enqueued in batches and the host looks at the state once per batch; sweeps enqueued past convergence
+    // are no-ops but still cost their launch and their check (~13 us a pair).  Consecutive rounds of a session converge
+    // in about the same number of sweeps, so the first batch is what the previous call needed plus one (8 at first).
+    int batch = lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 8;
     while (issued < max_iter) {
         const int upto = (issued + batch < max_iter) ? issued + batch : max_iter;
+        batch = 8;  // a second batch means the hint was too short: full size from here on
         for (; issued < upto; ++issued) {
             const int src = issued & 1;
             lp_launch_sweep(lp, src, reg_lambda, lo, hi);
@@ -658,6 +663,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
         return SSW_ERR_NUMERIC;
     }
     lp->last_result = (st.sweeps > 0) ? st.result_buf : 0;
+    lp->sweeps_hint = st.done ? (int)st.sweeps : 0;
     *st_out = st;
     return SSW_OK;
 }
