@@ -12,6 +12,13 @@ from .util import draw_unlabelled, makeXy_rows
 _SIDE = None  # one helper thread: the propagation's C call runs there (ctypes drops the GIL) beside the draw
 
 
+def _overlap_from() -> int:
+    """graphs from this many vectors on run the propagation beside the draw (below, the helper thread's hand-over costs
+    more than the propagation); SSW_PSEUDOLR_OVERLAP_FROM overrides it (tests force the path on small fixtures)"""
+    import os
+    return int(os.environ.get("SSW_PSEUDOLR_OVERLAP_FROM", 1 << 18))
+
+
 def _side():
     global _SIDE
     if _SIDE is None:
@@ -40,7 +47,7 @@ class PseudoLR(PointBased):
     def refine(self, change=None):
         model = self.knn_based.state.knn_model
         lp = getattr(model, "lp", None)
-        if lp is not None and hasattr(model, "propagate_now") and model.nvecs >= (1 << 18):
+        if lp is not None and hasattr(model, "propagate_now") and model.nvecs >= _overlap_from():
             # KnnProp2.refine with its two halves apart: the labels are recorded, then the propagation (GPU, a few
             # hundred us at 1.56 M vectors) runs on the helper thread while this one draws the pseudo-labelled sample
             # -- which depends on how many vectors are labelled, not on their propagated scores (the reference draws

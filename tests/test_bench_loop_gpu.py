@@ -195,6 +195,16 @@ def test_benchmark_loop_sequence_matches_reference(sequence_datasets, name):
         assert out["nfound"] == int(g[f"{name}_nfound"]) and out["nseen"] == int(g[f"{name}_nseen"])
 
 
+def test_pseudo_lr_with_the_propagation_beside_the_draw(sequence_datasets, monkeypatch):
+    """PseudoLR.refine on graphs of 2^18+ vectors records the labels, then runs the propagation on a helper thread
+    while the main thread makes the pseudo-label draw (loops/pseudo_lr.py).  Forced here on the fixture's dataset B:
+    the session must return the reference's images exactly as the serial order of calls does."""
+    monkeypatch.setenv("SSW_PSEUDOLR_OVERLAP_FROM", "0")
+    test_benchmark_loop_sequence_matches_reference(sequence_datasets, "pseudo_lr_b")
+    from seesaw_amd.loops import pseudo_lr
+    assert pseudo_lr._SIDE is not None, "the helper thread never ran"
+
+
 def _common_prefix(seqs):
     n = 0
     while n < min(len(x) for x in seqs) and all(x[n] == seqs[0][n] for x in seqs):
