@@ -250,6 +250,18 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
                              double reg_lambda, double eps, int32_t max_iter, double *out_f_host,
                              int32_t *out_sweeps, int32_t *out_converged);
 
+/* A graph laid out in a LOCALITY ORDER (label_propagation.py:30-43 is unchanged arithmetic): node `old`
+ * sits at position new_of_old[old]; row r of the CSR passed to create is the row of the node at position r, its columns
+ * relabelled to positions but kept in ascending ORIGINAL column id -- scipy's summation order, which the sweep follows
+ * entry by entry, so results stay bit-identical -- and weight_sum in position order.  Neighbours then sit near each other
+ * in the iterate and the sweep's gathers hit cache.  Every entry point keeps taking and returning original ids.
+ * ssw_labelprop_set_permutation must directly follow ssw_labelprop_create; ssw_labelprop_create_ordered does both and
+ * skips the column-blocked copy. */
+ssw_status ssw_labelprop_set_permutation(ssw_lp *lp, const int32_t *new_of_old_host);
+ssw_status ssw_labelprop_create_ordered(int32_t device, int64_t n, const int64_t *indptr_host, const int32_t *indices_host,
+                                        const double *data_host, const double *weight_sum_host,
+                                        const int32_t *new_of_old_host, ssw_lp **out);
+
 /* Device-resident chaining for the ranking loop (KnnProp2: the same prior is reg_values and start iterate
  * of every call, and the result only feeds a top-k): install the prior once, propagate without moving the
  * [n] f64 vectors over PCIe, hand the scores to the index's score buffer as f32 (labelled nodes at -inf

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "ssw_topk_merge_dev": (c_i32, [c_i32, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32,
                                    c_void_p, c_void_p]),
     "ssw_labelprop_create": (c_i32, [c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp]),
+    "ssw_labelprop_set_permutation": (c_i32, [c_void_p, c_void_p]),
+    "ssw_labelprop_create_ordered": (c_i32, [c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_pp]),
     "ssw_labelprop_destroy": (c_i32, [c_void_p]),
     "ssw_labelprop_run": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                                   ctypes.c_double, ctypes.c_double, c_i32, c_void_p, c_i32_p, c_i32_p]),

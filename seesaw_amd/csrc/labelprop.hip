@@ -38,6 +38,7 @@ namespace {
 
 constexpr int LP_BLOCK = 256;
 constexpr int LP_CHUNK = 4096;  // products staged in LDS per pass (32 KiB)
+constexpr int LP_INFLIGHT = 16;  // index -> gather chains per thread in flight in the plain sweep (4: 0.140 ms, 16: 0.131 ms on the re-ordered 1.56 M-node graph)
 constexpr int64_t LP_BLOCKED_ABOVE_BYTES = 5 << 20;  // iterates larger than this take the column-blocked sweep
 constexpr int64_t LP_SLICE_BYTES = 2 << 20;  // f_old bytes one pass of the column-blocked sweep gathers from (L2 = 4 MiB per XCD)
 
@@ -65,28 +66,36 @@ __global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep(
     const int64_t rend = min(row0 + LP_BLOCK, n);
     const int64_t p_begin = indptr[row0], p_end = indptr[rend];
     int64_t my_lo = 0, my_hi = 0;
+    // the row's own operands of the last step are requested now, not after the sum: one round trip less per workgroup
+    double e_prior = 0.0, e_wsum = 1.0, e_label = 0.0, e_old = 0.0;
+    unsigned char e_is_label = 0;
     if (row < n) {
         my_lo = indptr[row];
         my_hi = indptr[row + 1];
+        e_prior = prior[row];
+        e_wsum = wsum[row];
+        e_is_label = is_label[row];
+        e_label = label_val[row];
+        e_old = f_old[row];
     }
     double sum = 0.0;
     for (int64_t base = p_begin; base < p_end; base += LP_CHUNK) {
         const int64_t lim = min(base + LP_CHUNK, p_end);
-        // four independent index -> gather chains per thread in flight (the gathers of f_old are what the
+        // LP_INFLIGHT independent index -> gather chains per thread in flight (the gathers of f_old are what the
         // sweep waits for: random 8-byte reads, one cache line each)
-        for (int64_t p = base + t; p < lim; p += 4 * LP_BLOCK) {
-            int32_t col[4];
-            double w[4], f[4];
+        for (int64_t p = base + t; p < lim; p += LP_INFLIGHT * LP_BLOCK) {
+            int32_t col[LP_INFLIGHT];
+            double w[LP_INFLIGHT], f[LP_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LP_INFLIGHT; ++u) {
                 const int64_t q = p + (int64_t)u * LP_BLOCK;
                 col[u] = q < lim ? indices[q] : 0;
                 w[u] = q < lim ? data[q] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) f[u] = f_old[col[u]];
+            for (int u = 0; u < LP_INFLIGHT; ++u) f[u] = f_old[col[u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LP_INFLIGHT; ++u) {
                 const int64_t q = p + (int64_t)u * LP_BLOCK;
                 if (q < lim) prod[q - base] = __dmul_rn(w[u], f[u]);
             }
@@ -98,12 +107,12 @@ __global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep(
     }
     double d2 = 0.0;
     if (row < n) {
-        const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
-        double v = weighted / __dadd_rn(wsum[row], lambda);
+        const double weighted = __dadd_rn(sum, __dmul_rn(lambda, e_prior));
+        double v = weighted / __dadd_rn(e_wsum, lambda);
         if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
-        if (is_label[row]) v = label_val[row];
+        if (e_is_label) v = e_label;
         f_new[row] = v;
-        const double d = __dadd_rn(v, -f_old[row]);
+        const double d = __dadd_rn(v, -e_old);
         d2 = __dmul_rn(d, d);
     }
     // block max of d2 (non-negative or NaN; NaN compares false and is caught by the bounds)
@@ -346,6 +355,25 @@ __global__ void k_xlx_reduce(const double *__restrict__ P, int n_chunks, int64_t
 using namespace ssw;
 
 namespace {
+// a graph stored in a locality order (ssw_labelprop_set_permutation): perm[old id] = position in the device arrays
+__global__ void k_lp_permute_in(const double *__restrict__ src_old, const int32_t *__restrict__ perm, int64_t n,
+                                double *__restrict__ dst_new) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst_new[perm[i]] = src_old[i];
+}
+__global__ void k_lp_permute_out(const double *__restrict__ src_new, const int32_t *__restrict__ perm, int64_t n,
+                                 double *__restrict__ dst_old) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst_old[i] = src_new[perm[i]];
+}
+__global__ void k_lp_scores_f32_perm(const double *__restrict__ f, const unsigned char *__restrict__ is_label_or_null,
+                                     const int32_t *__restrict__ perm, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = perm[i];
+    out[i] = (is_label_or_null && is_label_or_null[r]) ? -INFINITY : (float)f[r];
+}
+
 __global__ void k_lp_gather(const double *__restrict__ f, const int64_t *__restrict__ rows, int64_t m,
                             double *__restrict__ out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -369,6 +397,12 @@ struct ssw_lp {
     int64_t ids_cap = 0;
     int64_t n_labels_installed = 0;
     int sweeps_hint = 0;  // sweeps the previous converged run needed (sizes the next run's first batch)
+    // locality order (ssw_labelprop_set_permutation): the device arrays are indexed by perm[original id]; every entry
+    // point keeps speaking original ids
+    int32_t *perm = nullptr;             // device [n]
+    std::vector<int32_t> perm_host;      // host copy (label ids, gather rows)
+    double *scratch = nullptr;           // [n] staging of uploads / the un-permuted result
+    std::vector<int64_t> ids_tmp;
     // device-resident chaining: an installed prior (reg_values == start iterate of every call of the ranking
     // loop) and the buffer holding the last result
     bool prior_installed = false;
@@ -391,6 +425,13 @@ struct ssw_lp {
 };
 
 extern "C" {
+
+static const int64_t *lp_map_ids(ssw_lp *lp, const int64_t *ids, int64_t m) {
+    if (!lp->perm || m <= 0) return ids;
+    lp->ids_tmp.resize((size_t)m);
+    for (int64_t i = 0; i < m; ++i) lp->ids_tmp[(size_t)i] = lp->perm_host[(size_t)ids[i]];
+    return lp->ids_tmp.data();
+}
 
 ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
     if (!lp) return SSW_OK;
@@ -416,10 +457,14 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
     (void)hipFree(lp->bl_indices);
     (void)hipFree(lp->bl_data);
     (void)hipFree(lp->bl_base_dev);
+    (void)hipFree(lp->perm);
+    (void)hipFree(lp->scratch);
     if (lp->stream) (void)hipStreamDestroy(lp->stream);
     delete lp;
     return SSW_OK;
 }
+
+static thread_local bool g_lp_skip_blocked = false;
 
 ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr_host,
                                 const int32_t *indices_host, const double *data_host,
@@ -491,6 +536,7 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
     // an iterate that (nearly) fits L2 is better served by the plain kernel (measured: 400 k nodes = 3.2 MB plain
     // 50 us vs blocked 58 us; 800 k = 6.4 MB 120 vs 112 us; 1.56 M = 12.5 MB 305 vs 161 us; 3 M 693 vs 387 us)
     if (!getenv("SSW_LP_SLICE_KB") && n * (int64_t)sizeof(double) <= LP_BLOCKED_ABOVE_BYTES) nblk = 1;
+    if (g_lp_skip_blocked) nblk = 1;  // ssw_labelprop_create_ordered: the columns do not ascend, the slices would be wrong
     if (nblk > 1 && nblk <= 4096 && nnz < (int64_t)0xffffffffll) {
         std::vector<uint32_t> bptr((size_t)nblk * (size_t)(n + 1), 0u);
         std::vector<int64_t> base((size_t)nblk + 1, 0);
@@ -597,13 +643,24 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
             if (v > hi) hi = v;
         }
         lp->prior_installed = false;
-        SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host_or_null, (size_t)n * sizeof(double),
-                                   hipMemcpyHostToDevice, s));
+        if (lp->perm) {
+            SSW_HIP_TRY(hipMemcpyAsync(lp->scratch, prior_host_or_null, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_lp_permute_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lp->scratch, lp->perm, n,
+                               lp->prior);
+            SSW_HIP_TRY(hipStreamSynchronize(s));  // scratch is reused for the start iterate below
+        } else {
+            SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host_or_null, (size_t)n * sizeof(double),
+                                       hipMemcpyHostToDevice, s));
+        }
     } else {
         lp->prior_installed = false;
         SSW_HIP_TRY(hipMemsetAsync(lp->prior, 0, (size_t)n * sizeof(double), s));
     }
-    if (start_host_or_null)
+    if (start_host_or_null && lp->perm) {
+        SSW_HIP_TRY(hipMemcpyAsync(lp->scratch, start_host_or_null, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lp_permute_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lp->scratch, lp->perm, n,
+                           lp->f[0]);
+    } else if (start_host_or_null)
         SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], start_host_or_null, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     else
         SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -627,7 +684,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
             SSW_HIP_TRY(hipMalloc((void **)&lp->vals, (size_t)cap * sizeof(double)));
             lp->ids_cap = cap;
         }
-        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, label_ids, (size_t)n_labels * sizeof(int64_t),
+        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, lp_map_ids(lp, label_ids, n_labels), (size_t)n_labels * sizeof(int64_t),
                                    hipMemcpyHostToDevice, s));
         SSW_HIP_TRY(hipMemcpyAsync(lp->vals, label_vals, (size_t)n_labels * sizeof(double),
                                    hipMemcpyHostToDevice, s));
@@ -679,12 +736,66 @@ ssw_status ssw_labelprop_run(ssw_lp *lp, const double *prior_host_or_null, const
     LpState st;
     SSW_TRY(lp_run_core(lp, prior_host_or_null, false, start_host, label_ids, label_vals, n_labels, reg_lambda, eps,
                         max_iter, &st));
-    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[lp->last_result], (size_t)lp->n * sizeof(double),
-                               hipMemcpyDeviceToHost, lp->stream));
+    const double *res = lp->f[lp->last_result];
+    if (lp->perm) {
+        hipLaunchKernelGGL(k_lp_permute_out, dim3((unsigned)((lp->n + 255) / 256)), dim3(256), 0, lp->stream, res, lp->perm,
+                           lp->n, lp->scratch);
+        res = lp->scratch;
+    }
+    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, res, (size_t)lp->n * sizeof(double), hipMemcpyDeviceToHost, lp->stream));
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     if (out_sweeps) *out_sweeps = st.sweeps;
     if (out_converged) *out_converged = st.done;
     return SSW_OK;
+}
+
+// The graph passed to ssw_labelprop_create was laid out in a locality order: node `old` sits at position
+// new_of_old[old]; row r of the CSR holds the entries of the node at position r with columns RELABELLED to positions but
+// kept in ascending ORIGINAL column id -- the order scipy adds a row's products in, which the plain sweep (each lane adds
+// its row's products in storage order) therefore still follows bit for bit.  Neighbours then sit near each other in the
+// iterate and the sweep's gathers hit lines their neighbours' rows already pulled; the column-blocked copy (whose slices
+// assume ascending columns) is dropped.  Every entry point keeps taking and returning ORIGINAL ids.
+ssw_status ssw_labelprop_set_permutation(ssw_lp *lp, const int32_t *new_of_old_host) {
+    SSW_REQUIRE(lp != nullptr && new_of_old_host != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->perm == nullptr && lp->last_result < 0 && !lp->prior_installed && lp->n_labels_installed == 0,
+                "ssw_labelprop_set_permutation: call it right after ssw_labelprop_create");
+    std::vector<unsigned char> seen((size_t)lp->n, 0);
+    for (int64_t i = 0; i < lp->n; ++i) {
+        const int32_t r = new_of_old_host[i];
+        SSW_REQUIRE(r >= 0 && r < lp->n && !seen[(size_t)r], "not a permutation of [0, %lld) at %lld", (long long)lp->n,
+                    (long long)i);
+        seen[(size_t)r] = 1;
+    }
+    DeviceGuard guard(lp->device);
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->perm, (size_t)lp->n * sizeof(int32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->scratch, (size_t)lp->n * sizeof(double) + 16));
+    SSW_HIP_TRY(hipMemcpy(lp->perm, new_of_old_host, (size_t)lp->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    lp->perm_host.assign(new_of_old_host, new_of_old_host + lp->n);
+    (void)hipFree(lp->bl_ptr);
+    (void)hipFree(lp->bl_indices);
+    (void)hipFree(lp->bl_data);
+    (void)hipFree(lp->bl_base_dev);
+    lp->bl_ptr = nullptr, lp->bl_indices = nullptr, lp->bl_data = nullptr, lp->bl_base_dev = nullptr;
+    lp->nblk = 1;
+    return SSW_OK;
+}
+
+// create + set_permutation in one call, without building a column-blocked copy that would be dropped again
+ssw_status ssw_labelprop_create_ordered(int32_t device, int64_t n, const int64_t *indptr_host, const int32_t *indices_host,
+                                        const double *data_host, const double *weight_sum_host, const int32_t *new_of_old_host,
+                                        ssw_lp **out) {
+    SSW_REQUIRE(weight_sum_host != nullptr, "create_ordered: the column sums must come from the matrix in its original order");
+    g_lp_skip_blocked = true;
+    const ssw_status st = ssw_labelprop_create(device, n, indptr_host, indices_host, data_host, weight_sum_host, out);
+    g_lp_skip_blocked = false;
+    if (st != SSW_OK) return st;
+    const ssw_status st2 = ssw_labelprop_set_permutation(*out, new_of_old_host);
+    if (st2 != SSW_OK) {
+        ssw_labelprop_destroy(*out);
+        *out = nullptr;
+    }
+    return st2;
 }
 
 ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
@@ -696,8 +807,15 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
         if (v < lo) lo = v;
         if (v > hi) hi = v;
     }
-    SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host, (size_t)lp->n * sizeof(double), hipMemcpyHostToDevice,
-                               lp->stream));
+    if (lp->perm) {
+        SSW_HIP_TRY(hipMemcpyAsync(lp->scratch, prior_host, (size_t)lp->n * sizeof(double), hipMemcpyHostToDevice, lp->stream));
+        hipLaunchKernelGGL(k_lp_permute_in, dim3((unsigned)((lp->n + 255) / 256)), dim3(256), 0, lp->stream, lp->scratch,
+                           lp->perm, lp->n, lp->prior);
+        SSW_HIP_TRY(hipGetLastError());
+    } else {
+        SSW_HIP_TRY(hipMemcpyAsync(lp->prior, prior_host, (size_t)lp->n * sizeof(double), hipMemcpyHostToDevice,
+                                   lp->stream));
+    }
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     lp->prior_lo = lo;
     lp->prior_hi = hi;
@@ -745,7 +863,8 @@ ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, i
             SSW_HIP_TRY(hipMalloc((void **)&lp->vals, (size_t)cap * sizeof(double)));
             lp->ids_cap = cap;
         }
-        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, label_ids, (size_t)n_labels * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, lp_map_ids(lp, label_ids, n_labels), (size_t)n_labels * sizeof(int64_t),
+                                   hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_lp_mark_labels, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, lp->is_label,
                            lp->ids, n_labels);
         lp->n_labels_installed = n_labels;
@@ -760,8 +879,13 @@ ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host) {
     SSW_REQUIRE(lp != nullptr && out_f_host != nullptr, "NULL argument");
     SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_fetch: nothing has been propagated yet");
     DeviceGuard guard(lp->device);
-    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, lp->f[lp->last_result], (size_t)lp->n * sizeof(double),
-                               hipMemcpyDeviceToHost, lp->stream));
+    const double *res = lp->f[lp->last_result];
+    if (lp->perm) {
+        hipLaunchKernelGGL(k_lp_permute_out, dim3((unsigned)((lp->n + 255) / 256)), dim3(256), 0, lp->stream, res, lp->perm,
+                           lp->n, lp->scratch);
+        res = lp->scratch;
+    }
+    SSW_HIP_TRY(hipMemcpyAsync(out_f_host, res, (size_t)lp->n * sizeof(double), hipMemcpyDeviceToHost, lp->stream));
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     return SSW_OK;
 }
@@ -791,7 +915,10 @@ ssw_status ssw_labelprop_gather(ssw_lp *lp, const int64_t *rows_host, int64_t m,
         SSW_HIP_TRY(hipHostMalloc((void **)&lp->g_vals_host, (size_t)cap * sizeof(double), hipHostMallocDefault));
         lp->g_cap = cap;
     }
-    memcpy(lp->g_rows_host, rows_host, (size_t)m * sizeof(int64_t));
+    if (lp->perm)
+        for (int64_t i = 0; i < m; ++i) lp->g_rows_host[i] = lp->perm_host[(size_t)rows_host[i]];
+    else
+        memcpy(lp->g_rows_host, rows_host, (size_t)m * sizeof(int64_t));
     SSW_HIP_TRY(hipMemcpyAsync(lp->g_rows, lp->g_rows_host, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, lp->stream));
     hipLaunchKernelGGL(k_lp_gather, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, lp->stream,
                        lp->f[lp->last_result], lp->g_rows, m, lp->g_vals);
@@ -805,6 +932,15 @@ ssw_status ssw_labelprop_gather(ssw_lp *lp, const int64_t *rows_host, int64_t m,
 ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores) {
     SSW_REQUIRE(lp != nullptr && out_dev_scores != nullptr, "NULL argument");
     SSW_REQUIRE(lp->last_result >= 0, "ssw_labelprop_device_scores: nothing has been propagated yet");
+    if (lp->perm) {  // callers index it by original node id: hand out an un-permuted copy (valid until the next call)
+        DeviceGuard guard(lp->device);
+        hipLaunchKernelGGL(k_lp_permute_out, dim3((unsigned)((lp->n + 255) / 256)), dim3(256), 0, lp->stream,
+                           lp->f[lp->last_result], lp->perm, lp->n, lp->scratch);
+        SSW_HIP_TRY(hipGetLastError());
+        SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+        *out_dev_scores = lp->scratch;
+        return SSW_OK;
+    }
     *out_dev_scores = lp->f[lp->last_result];
     return SSW_OK;
 }
@@ -820,8 +956,13 @@ ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t m
     SSW_REQUIRE(n == lp->n, "the index has %lld rows, the graph %lld nodes", (long long)n, (long long)lp->n);
     SSW_TRY(ssw_index_sync(index));  // nothing of the index's own stream still writes the score buffer
     DeviceGuard guard(lp->device);
-    hipLaunchKernelGGL(k_lp_scores_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lp->stream, lp->f[lp->last_result],
-                       mask_labeled ? lp->is_label : (const unsigned char *)nullptr, n, (float *)scores);
+    if (lp->perm)
+        hipLaunchKernelGGL(k_lp_scores_f32_perm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lp->stream,
+                           lp->f[lp->last_result], mask_labeled ? lp->is_label : (const unsigned char *)nullptr, lp->perm, n,
+                           (float *)scores);
+    else
+        hipLaunchKernelGGL(k_lp_scores_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lp->stream, lp->f[lp->last_result],
+                           mask_labeled ? lp->is_label : (const unsigned char *)nullptr, n, (float *)scores);
     SSW_HIP_TRY(hipGetLastError());
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
     return SSW_OK;
@@ -830,6 +971,7 @@ ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t m
 
 ssw_status ssw_xlx(ssw_index *index, ssw_lp *lap, double *out_host) {
     SSW_REQUIRE(index != nullptr && lap != nullptr && out_host != nullptr, "NULL argument");
+    SSW_REQUIRE(lap->perm == nullptr, "ssw_xlx: the Laplacian handle must be in original node order");
     int64_t n = 0, n_images = 0;
     int32_t D = 0;
     void *Xv = nullptr, *scores = nullptr;

@@ -16,8 +16,53 @@ def _p(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
+def locality_order(weight_matrix, *, window: int = 32768, min_gain: float = 2.0, min_nodes: int = 1 << 19):
+    """A node order (new_of_old, int32) that puts graph neighbours near each other -- reverse Cuthill-McKee over the
+    symmetric pattern -- or None when it would not pay: small graphs (the iterate stays in L2 anyway), or graphs where the
+    share of edges that land within `window` positions of each other does not grow `min_gain`-fold (k-NN graphs over
+    unclustered vectors have no locality to find; the column-blocked sweep serves those).  One-off per graph."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    W = weight_matrix.tocsr()
+    n = W.shape[0]
+    if n < min_nodes:
+        return None
+    pattern = sp.csr_matrix((np.ones(W.nnz, dtype=np.int8), W.indices, W.indptr), shape=W.shape)
+    pattern = (pattern + pattern.T).tocsr()
+    old_of_new = np.asarray(reverse_cuthill_mckee(pattern, symmetric_mode=True), dtype=np.int64)
+    new_of_old = np.empty(n, dtype=np.int32)
+    new_of_old[old_of_new] = np.arange(n, dtype=np.int32)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(W.indptr))
+    near_before = float((np.abs(rows - W.indices) < window).mean())
+    near_after = float((np.abs(new_of_old[rows].astype(np.int64) - new_of_old[W.indices]) < window).mean())
+    if near_after < min_gain * max(near_before, 1e-9) or near_after < 0.5:
+        return None
+    return new_of_old
+
+
+def ordered_csr(W, weight_sum, new_of_old):
+    """the CSR arrays ssw_labelprop_create_ordered takes: row r = the row of the node at position r, entries in ascending
+    ORIGINAL column id (W has sorted indices), columns relabelled to positions; weight_sum in position order"""
+    n = W.shape[0]
+    old_of_new = np.empty(n, dtype=np.int64)
+    old_of_new[new_of_old] = np.arange(n, dtype=np.int64)
+    counts = np.diff(W.indptr)[old_of_new]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    # entry positions of the old rows, concatenated in new-row order
+    starts = W.indptr[:-1][old_of_new].astype(np.int64)
+    take = np.repeat(starts - indptr[:-1], counts) + np.arange(indptr[-1], dtype=np.int64)
+    indices = np.ascontiguousarray(new_of_old[W.indices[take]], dtype=np.int32)
+    data = np.ascontiguousarray(W.data[take], dtype=np.float64)
+    wsum = np.ascontiguousarray(np.asarray(weight_sum, dtype=np.float64)[old_of_new])
+    return indptr, indices, data, wsum
+
+
 class LabelPropagation:
-    def __init__(self, weight_matrix, *, reg_lambda: float, max_iter: int, epsilon=1e-5, verbose=0, device: int = 0):
+    def __init__(self, weight_matrix, *, reg_lambda: float, max_iter: int, epsilon=1e-5, verbose=0, device: int = 0,
+                 node_order=None):
+        """node_order: optional permutation new_of_old (locality_order(weight_matrix)) -- the graph is then stored on the
+        device in that order (rows' entries still in ascending original column id, so every result stays bit-identical)
+        and the sweep's gathers of the iterate hit cache on clustered data; all ids at this interface stay original."""
         assert reg_lambda >= 0
         W = weight_matrix if sp.issparse(weight_matrix) else sp.csr_array(weight_matrix)
         W = W.tocsr()
@@ -35,6 +80,15 @@ class LabelPropagation:
         self.last_converged = False
         self._prior_installed = False
         self._h = ctypes.c_void_p()
+        self.node_order = None
+        if node_order is not None:
+            new_of_old = np.ascontiguousarray(node_order, dtype=np.int32)
+            assert new_of_old.shape == (self.n,)
+            indptr, indices, data, wsum = ordered_csr(W, self.weight_sum, new_of_old)
+            _lib.call("ssw_labelprop_create_ordered", int(device), self.n, _p(indptr), _p(indices), _p(data), _p(wsum),
+                      _p(new_of_old), ctypes.byref(self._h))
+            self.node_order = new_of_old
+            return
         indptr = np.ascontiguousarray(W.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(W.indices, dtype=np.int32)
         data = np.ascontiguousarray(W.data, dtype=np.float64)

@@ -86,10 +86,26 @@ def get_weight_matrix_from_index(idx, weight_matrix_options, xlx_matrix=False):
                                                                         getattr(idx, "_shard", None) is not None) else None)
 
 
+_ORDER = {}  # id(weight matrix) -> (the matrix, its locality order or None): one-off per graph, like the matrix itself
+
+
+def _locality_order_of(W):
+    """label_propagation.locality_order(W), remembered next to the cached weight matrix (large clustered graphs are
+    stored on the device in a neighbour-preserving node order; everything else returns None)"""
+    if os.environ.get("SSW_LP_NO_REORDER"):
+        return None
+    hit = _ORDER.get(id(W))
+    if hit is None or hit[0] is not W:
+        from ..label_propagation import locality_order
+        hit = _ORDER[id(W)] = (W, locality_order(W))
+    return hit[1]
+
+
 def get_label_prop(q, label_prop_params):
     W = get_weight_matrix_from_index(q.index, label_prop_params["matrix_options"])
     params = {k: v for k, v in label_prop_params.items() if k != "matrix_options"}
-    return LabelPropagationRanker2(weight_matrix=W, device=getattr(q.index, "device", 0), **params)
+    return LabelPropagationRanker2(weight_matrix=W, device=getattr(q.index, "device", 0), node_order=_locality_order_of(W),
+                                   **params)
 
 
 class KnnProp2(LoopBase):

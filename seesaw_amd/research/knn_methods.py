@@ -100,12 +100,12 @@ class BaseLabelPropagationRanker:
 class LabelPropagationRanker2(BaseLabelPropagationRanker):
     lp: LabelPropagation
 
-    def __init__(self, *, weight_matrix, verbose: int = 0, device: int = 0, **other):
+    def __init__(self, *, weight_matrix, verbose: int = 0, device: int = 0, node_order=None, **other):
         super().__init__(knng=None, nvecs=weight_matrix.shape[0], **other)
         self.knng_intra = None
         self.weight_matrix = weight_matrix
         self.lp = LabelPropagation(weight_matrix=weight_matrix, reg_lambda=self.prior_weight, max_iter=300,
-                                   verbose=verbose, device=device)
+                                   verbose=verbose, device=device, node_order=node_order)
 
     def set_base_scores(self, init_scores):
         super().set_base_scores(init_scores)

@@ -199,3 +199,117 @@ def test_column_blocked_equals_plain_sweep_on_a_large_graph(monkeypatch, oracle,
                                    start_value=prior, max_iter=25, epsilon=-1.0)
     ref = ref[0] if isinstance(ref, tuple) else ref
     assert np.array_equal(np.asarray(ref).view(np.uint64), got.view(np.uint64))
+
+
+def _orders(W):
+    """node orders to hold the permuted layout to: a random permutation (no structure at all), the reversal, and the
+    reverse Cuthill-McKee order locality_order() would pick on a large clustered graph"""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = W.shape[0]
+    rng = np.random.default_rng(n)
+    rcm = np.empty(n, dtype=np.int32)
+    pattern = sp.csr_matrix(W)
+    rcm[np.asarray(reverse_cuthill_mckee(((pattern + pattern.T) != 0).tocsr(), symmetric_mode=True))] = np.arange(n, dtype=np.int32)
+    return {"random": rng.permutation(n).astype(np.int32), "reversed": np.arange(n - 1, -1, -1, dtype=np.int32), "rcm": rcm}
+
+
+@pytest.mark.parametrize("order", ["random", "reversed", "rcm"])
+def test_locality_order_is_bit_exact_vs_reference_golden(order):
+    """the graph stored in a node order of its own: rows keep their entries in ascending ORIGINAL column
+    id, so every sweep adds the same products in the same order -- the reference's outputs and sweep counts, bit for bit"""
+    from seesaw_amd.label_propagation import LabelPropagation
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    W = _W(g)
+    perm = _orders(W)[order]
+    for r in range(int(g["n_runs"])):
+        lam = float(g[f"run{r}_lam"])
+        start = g[f"run{r}_start"]
+        lp = LabelPropagation(W, reg_lambda=lam, max_iter=300, node_order=perm)
+        out = lp.fit_transform(label_ids=g[f"run{r}_ids"], label_values=g[f"run{r}_vals"],
+                               reg_values=start if lam > 0 else None, start_value=start)
+        assert lp.last_sweeps == int(g[f"run{r}_steps"]), (r, lp.last_sweeps)
+        assert np.array_equal(out, g[f"run{r}_out"]), (r, np.abs(out - g[f"run{r}_out"]).max())
+        lp.close()
+
+
+@pytest.mark.parametrize("order", ["random", "rcm"])
+def test_locality_order_through_every_entry_point(order):
+    """resident chaining over a re-ordered graph: set_prior, fit_resident, fetch, gather, prior_as_result,
+    device_scores (handed to the index's f64 re-scoring in ORIGINAL order) and scores_to_index all speak original ids"""
+    import ctypes
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.label_propagation import LabelPropagation
+    g = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    W = _W(g)
+    n = W.shape[0]
+    rng = np.random.default_rng(3)
+    prior = rng.random(n)
+    ids = rng.choice(n, size=40, replace=False).astype(np.int64)
+    vals = (rng.random(40) > 0.5).astype(np.float64)
+    ref = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
+    want = ref.fit_transform(label_ids=ids, label_values=vals, reg_values=prior, start_value=prior)
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300, node_order=_orders(W)[order])
+    lp.set_prior(prior)
+    for _ in range(2):
+        lp.fit_resident(label_ids=ids, label_values=vals)
+        assert lp.last_sweeps == ref.last_sweeps
+        assert np.array_equal(lp.fetch(), want)
+    pick = rng.choice(n, size=300, replace=True).astype(np.int64)
+    assert np.array_equal(lp.gather(pick), want[pick])
+    # the device pointer other kernels index by original node id
+    import torch
+    ptr = lp.device_scores_ptr()
+    t = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    hip = None
+    for cand in (os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), "libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(cand)
+            break
+        except OSError:
+            continue
+    assert hip is not None
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(t.data_ptr(), ptr, n * 8, 3) == 0  # hipMemcpyDeviceToDevice
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), want)
+    dev = DeviceIndex.from_numpy(g["X"])
+    lp.scores_to_index(dev, mask_labeled=True)
+    s32 = want.astype(np.float32)
+    s32[ids] = -np.inf
+    rows, scores, _ = dev.topk(None, 25)
+    top = np.lexsort((np.arange(n), -s32.astype(np.float64)))[:25]
+    assert np.array_equal(rows, top) and np.array_equal(scores, s32[top])
+    # the rounds before the first negative label: the prior is the result, labelled nodes marked
+    lp.prior_as_result(ids[:5])
+    assert np.array_equal(lp.fetch(), prior)
+    lp.scores_to_index(dev, mask_labeled=True)
+    p32 = prior.astype(np.float32)
+    p32[ids[:5]] = -np.inf
+    rows, scores, _ = dev.topk(None, 25)
+    top = np.lexsort((np.arange(n), -p32.astype(np.float64)))[:25]
+    assert np.array_equal(rows, top) and np.array_equal(scores, p32[top])
+    dev.close()
+    lp.close()
+    ref.close()
+
+
+def test_locality_order_is_found_on_clustered_graphs_only():
+    """locality_order(): reverse Cuthill-McKee pays on a k-NN graph of clustered vectors (neighbours share a cluster) and
+    is declined on one of unclustered vectors (edges stay scattered whatever the order)"""
+    from seesaw_amd.label_propagation import locality_order
+    rng = np.random.default_rng(0)
+    n, k, nc = 60000, 8, 300
+    lab = rng.integers(0, nc, n)
+    members = [np.nonzero(lab == c)[0] for c in range(nc)]
+    rows = np.repeat(np.arange(n), k)
+    clustered = np.concatenate([rng.choice(members[lab[i]], k) for i in range(n)])
+    Wc = sp.csr_matrix((np.ones(n * k), (rows, clustered)), shape=(n, n))
+    Wc = (Wc + Wc.T).tocsr()
+    order = locality_order(Wc, min_nodes=1000, window=2048)
+    assert order is not None and np.array_equal(np.sort(order), np.arange(n))
+    near = np.abs(order[np.repeat(np.arange(n), np.diff(Wc.indptr))].astype(np.int64) - order[Wc.indices]) < 2048
+    assert near.mean() > 0.9
+    Wr = sp.csr_matrix((np.ones(n * k), (rows, rng.integers(0, n, n * k))), shape=(n, n))
+    Wr = (Wr + Wr.T).tocsr()
+    assert locality_order(Wr, min_nodes=1000, window=2048) is None
+    assert locality_order(Wc) is None  # under 2^19 nodes the iterate stays in L2: not worth a permutation
