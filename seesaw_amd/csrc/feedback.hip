@@ -357,6 +357,34 @@ __device__ __forceinline__ float slab_column_sum(const float *__restrict__ col, 
     return g;
 }
 
+// The same sums ahead of k_fb_final, over several workgroups, for sets of thousands of rows: one workgroup adding 322
+// slab partials of 512 columns reads 660 KB through one CU (23 us of a 48-us closure evaluation at 10 000 rows).  Here a
+// workgroup takes 64 columns; its four thread groups fetch a quarter of a 128-slab chunk each into LDS (32 loads in
+// flight per thread), then one thread per column adds the chunk in slab order -- the additions k_fb_final's own loop
+// makes, in its order; k_fb_final then finds one "slab" per column.
+__global__ __launch_bounds__(256) void k_fb_slabsum(const float *__restrict__ partial, int nslabs, int dim,
+                                                    float *__restrict__ gsum) {
+    __shared__ float buf[128][64];
+    const int t = threadIdx.x, col = t & 63, part = t >> 6;
+    const int c = blockIdx.x * 64 + col;
+    const int cc = c < dim ? c : dim - 1;
+    float g = 0.f;
+    for (int s0 = 0; s0 < nslabs; s0 += 128) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = partial[(int64_t)min(s0 + part * 32 + u, nslabs - 1) * dim + cc];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) buf[part * 32 + u][col] = v[u];
+        __syncthreads();
+        if (part == 0) {
+            const int cnt = min(128, nslabs - s0);
+            for (int i = 0; i < cnt; ++i) g += buf[i][col];
+        }
+        __syncthreads();
+    }
+    if (part == 0 && c < dim) gsum[c] = g;
+}
+
 __global__ __launch_bounds__(1024) void k_fb2_reduce(const float *__restrict__ partial /* [2][nslabs_cap][dim] */,
                                                      int64_t partial_plane, int nslabs, const float *__restrict__ item_v,
                                                      const float *__restrict__ item_h, int64_t n, int dim,
@@ -1359,6 +1387,7 @@ struct ssw_fb {
     double *loss_dev = nullptr, *loss_host = nullptr;  // total loss in f64
     int64_t *rows = nullptr;   // gather staging
     float *partial = nullptr;  // [nslabs(cap), dim]
+    float *gsum = nullptr;     // [1024] ordered column sums of the slab partials (k_fb_slabsum, sets of >= 2048 rows)
     float *rankg = nullptr;    // [cap] net position changes of the rank objective (SSW_FB_RANKREG)
     // two-output objective (ssw_fb_*2): planes of cap floats / [2][nslabs(cap)][dim] partial gradients
     float *y2 = nullptr, *sw2 = nullptr, *z2 = nullptr, *r2 = nullptr, *itemv = nullptr, *itemh = nullptr;
@@ -1589,9 +1618,17 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
         hipLaunchKernelGGL(k_fb_grad, dim3((unsigned)nslabs, (unsigned)((dim + tx - 1) / tx)), dim3(tx), 0, s, fb->X,
                            fb->r, n, dim, fb->partial);
     }
+    const float *final_partial = fb->partial;
+    int final_slabs = nslabs;
+    if (nslabs >= 64 && !getenv("SSW_FB_NO_SLABSUM")) {  // thousands of rows: the slab sums on several CUs first (same additions, same order; the variable is the tests' A/B switch)
+        if (!fb->gsum) SSW_HIP_TRY(hipMalloc((void **)&fb->gsum, 1024 * sizeof(float)));
+        hipLaunchKernelGGL(k_fb_slabsum, dim3((unsigned)((dim + 63) / 64)), dim3(256), 0, s, fb->partial, nslabs, dim, fb->gsum);
+        final_partial = fb->gsum;
+        final_slabs = 1;
+    }
     // the last kernel writes loss + gradient straight into the pinned host mirror (mapped into the
     // device's address space): no device-to-host copies are queued behind it
-    hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, fb->partial, nslabs, fb->item, fb->r, n, dim,
+    hipLaunchKernelGGL(k_fb_final, dim3(1), dim3(1024), 0, s, final_partial, final_slabs, fb->item, fb->r, n, dim,
                        by_arg ? (const float *)nullptr : (const float *)fb->w, wv,
                        fb->has_q ? fb->qhat : (const float *)nullptr, fb->has_xlx ? fb->xlx : (const float *)nullptr,
                        dev, fb->out_host_dev, fb->loss_host_dev, fb->flag_host_dev, ++fb->seqno);
@@ -2009,6 +2046,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     (void)hipFree(fb->r);
     (void)hipFree(fb->rows);
     (void)hipFree(fb->partial);
+    (void)hipFree(fb->gsum);
     (void)hipFree(fb->rankg);
     for (float *p2 : {fb->y2, fb->sw2, fb->z2, fb->r2, fb->itemv, fb->itemh, fb->partial2, fb->nw2}) (void)hipFree(p2);
     if (fb->out2_host) (void)hipHostFree(fb->out2_host);

@@ -310,6 +310,36 @@ def test_larger_labelled_sets_take_the_host_driven_fit():
     assert info["on_device"] is True
 
 
+@pytest.mark.parametrize("n,dim", [(2048, 512), (10007, 512), (4100, 192)])
+def test_slab_sums_over_several_workgroups_are_the_single_workgroup_sums(monkeypatch, n, dim):
+    """from 64 slabs (2048 rows) on, the ordered column sums of the slab partials run on several workgroups ahead of
+    k_fb_final (k_fb_slabsum): the same additions in the same order -- loss, gradient and a whole fit bit for bit"""
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    y = rng.uniform(0, 1, n)
+    obj = _lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=1, reg_kind=_lib.SSW_FB_REG_NORM,
+                           pos_weight=1.5, reg_weight=1.0 / n, margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                           reg_query_lambda=0)
+    w = (rng.standard_normal(dim + 1) * 0.05).astype(np.float32)
+    out = {}
+    for mode in ("several", "one"):
+        if mode == "one":
+            monkeypatch.setenv("SSW_FB_NO_SLABSUM", "1")
+        eng = FeedbackEngine(dim)
+        eng.set_data(X, center=True)
+        eng.set_targets(y, None)
+        loss, grad, _ = eng.lossgrad(obj, w)
+        wf, info = eng.fit(obj, w, 12)
+        out[mode] = (loss, grad.copy(), wf.copy(), info["func_evals"])
+        eng.close() if hasattr(eng, "close") else None
+    assert out["several"][0] == out["one"][0]
+    assert np.array_equal(out["several"][1].view(np.uint32), out["one"][1].view(np.uint32))
+    assert np.array_equal(out["several"][2].view(np.uint32), out["one"][2].view(np.uint32))
+    assert out["several"][3] == out["one"][3]
+
+
 @pytest.mark.parametrize("dim,n", [(512, 0), (512, 1), (512, 33), (256, 70), (768, 90), (1020, 512), (64, 1024)])
 def test_single_launch_fit_other_shapes(dim, n):
     """the one-launch fit on the shapes around its limits: no rows at all (regulariser only), one row, a ragged last
