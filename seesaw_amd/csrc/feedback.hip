@@ -164,23 +164,39 @@ __global__ __launch_bounds__(256) void k_fb_logits_arg(const float *__restrict__
                                                        const float *__restrict__ y, const float *__restrict__ coef,
                                                        float pw, double *__restrict__ item_loss,
                                                        float *__restrict__ r) {
+    // a wave takes FOUR rows: their loads are in flight together and lanes 0-3 each finish one row's label term (the
+    // f64 exp / log1p chain was one lane per wave: a quarter of the waves, the same latency each).  Per row the
+    // arithmetic is unchanged: the lane's fma chain over its columns, the xor butterfly 32 ... 1.
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
-    const float4 *x4 = reinterpret_cast<const float4 *>(X + row * dim);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= n) return;
     const float4 *w4 = reinterpret_cast<const float4 *>(wv.v);
-    float a = 0.f;
+    const float4 *x4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x4[u] = reinterpret_cast<const float4 *>(X + (row0 + u < n ? row0 + u : row0) * dim);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = lane; c < dim / 4; c += 64) {
-        const float4 xv = x4[c], wq = w4[c];
-        a = fmaf(xv.x, wq.x, a);
-        a = fmaf(xv.y, wq.y, a);
-        a = fmaf(xv.z, wq.z, a);
-        a = fmaf(xv.w, wq.w, a);
+        float4 xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = x4[u][c];
+        const float4 wq = w4[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = fmaf(xv[u].x, wq.x, a[u]);
+            a[u] = fmaf(xv[u].y, wq.y, a[u]);
+            a[u] = fmaf(xv[u].z, wq.z, a[u]);
+            a[u] = fmaf(xv[u].w, wq.w, a[u]);
+        }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-    if (lane == 0) {
-        const float zf = a + (has_bias ? wv.v[dim] : 0.f);
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += __shfl_xor(a[u], off, 64);
+    }
+    const float mine = lane == 0 ? a[0] : lane == 1 ? a[1] : lane == 2 ? a[2] : a[3];
+    const int64_t row = row0 + lane;
+    if (lane < 4 && row < n) {
+        const float zf = mine + (has_bias ? wv.v[dim] : 0.f);
         z[row] = zf;
         if (elem) {
             const double zi = zf, yi = y[row], ci = coef[row];
@@ -1586,7 +1602,7 @@ static ssw_status fb_eval(ssw_fb *fb, const ssw_fb_objective *o, const FbObjDev 
         const bool pairwise = rankreg || (o->kind == SSW_FB_MULTIREG && o->loss_type != SSW_FB_LOSS_CE);
         nslabs = (int)((n + FB_SLAB - 1) / FB_SLAB);
         if (by_arg)
-            hipLaunchKernelGGL(k_fb_logits_arg, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, wv, n, dim,
+            hipLaunchKernelGGL(k_fb_logits_arg, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, fb->X, wv, n, dim,
                                dev.has_bias, fb->z, pairwise ? 0 : (dev.exact ? 2 : 1), fb->y, fb->coef, pw, fb->item, fb->r);
         else
             hipLaunchKernelGGL(k_fb_logits, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb->X, fb->w, n, dim,
