@@ -203,6 +203,10 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True):
                 hip_shown = [int(v) for a in ret["session"].acc_indices for v in np.asarray(a).reshape(-1)]
                 res[name] = {"hip_iters_per_s": 1.0 / float(np.mean(g["latencies"])),
                              "hip_ms_per_iter": 1e3 * float(np.mean(g["latencies"])), "iters": len(g["latencies"]),
+                             # the metric is 1 / mean (seesaw_bench.py:310,352); the median and the slowest round say
+                             # whether a mean carries a one-off hiccup of the box
+                             "hip_ms_per_iter_median": 1e3 * float(np.median(g["latencies"])),
+                             "hip_ms_slowest_iter": 1e3 * float(np.max(g["latencies"])),
                              "hip_nfound": g["nfound"]}
                 if with_cpu:  # per-phase ms (rank 0 at N = 1 only)
                     ret = make_session(gdm, p, b=b)
