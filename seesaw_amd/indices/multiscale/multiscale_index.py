@@ -393,13 +393,23 @@ class BoxFeedbackQuery(InteractiveQuery):
         idx = self.index
         cache = self.__dict__.setdefault("_match_cache", {})
         rows_all, iou_all = [], []
-        for dbidx in self.label_db.get_seen():
-            boxes = self.label_db.ldata[int(dbidx)] or []
+        ldb = self.label_db
+        stamps = getattr(ldb, "stamp", None)
+        for dbidx in sorted(ldb.ldata):  # == label_db.get_seen() (ascending dbidx)
+            # an image's entry is good for as long as its labels have not been put() again (LabelDB.stamp); a label
+            # store without stamps is keyed by the boxes themselves
+            fast = (dbidx, stamps[dbidx], target_description) if stamps is not None and dbidx in stamps else None
+            hit = cache.get(fast) if fast is not None else None
+            if hit is not None:
+                rows_all.append(hit[0])
+                iou_all.append(hit[1])
+                continue
+            boxes = ldb.ldata[int(dbidx)] or []
             if target_description is not None:
                 sel = [b for b in boxes if b.description == target_description]
             else:
                 sel = [b for b in boxes if b.marked_accepted]
-            key = (int(dbidx), tuple((b.x1, b.y1, b.x2, b.y2) for b in sel))
+            key = fast if fast is not None else (int(dbidx), tuple((b.x1, b.y1, b.x2, b.y2) for b in sel))
             hit = cache.get(key)
             if hit is None:
                 pos = int(np.searchsorted(idx._dbidx, dbidx))

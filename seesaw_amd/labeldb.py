@@ -19,9 +19,13 @@ _BOX_COLS = ["x1", "x2", "y1", "y2"]
 class LabelDB:
     def __init__(self):
         self.ldata: Dict[int, Optional[List[Box]]] = {}
+        self.stamp: Dict[int, int] = {}  # dbidx -> serial number of its latest put(): a cheap "did this image's labels change"
+        self._serial = 0
 
     def put(self, dbidx: int, boxes: Optional[List[Box]]):
         self.ldata[int(dbidx)] = boxes
+        self._serial += 1
+        self.stamp[int(dbidx)] = self._serial
 
     def get_seen(self) -> BitMap:
         return BitMap(self.ldata.keys())

@@ -70,8 +70,13 @@ class RegModule:
         if n > 0:
             # 1 / (vectors of the same image): matchdf.groupby('dbidx').size() merged back (multi_reg.py:163-165)
             dbidx = matchdf if isinstance(matchdf, np.ndarray) else matchdf.dbidx.values
-            _, inv, cnt = np.unique(dbidx, return_inverse=True, return_counts=True)
-            vec_weight = 1.0 / cnt[inv].astype(np.float64)
+            if dbidx.shape[0] > 1 and np.all(dbidx[1:] >= dbidx[:-1]):  # an image's tiles are adjacent: run lengths
+                cuts = np.flatnonzero(dbidx[1:] != dbidx[:-1]) + 1
+                cnt = np.diff(np.concatenate(([0], cuts, [dbidx.shape[0]])))
+                vec_weight = np.repeat(1.0 / cnt.astype(np.float64), cnt)
+            else:
+                _, inv, cnt = np.unique(dbidx, return_inverse=True, return_counts=True)
+                vec_weight = 1.0 / cnt[inv].astype(np.float64)
             if X is not None:
                 self._engine.set_data(X, center=True)
             else:
