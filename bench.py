@@ -482,18 +482,28 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    # Rehearsal of the N > 1 path on a one-GPU box (SSW_BENCH_REHEARSAL=gloo): every rank uses GPU 0 and the
+    # exchange goes through host tensors over gloo -- the same shards, kernels, messages and merge as the real run,
+    # only the collective's transport differs (RCCL cannot put two ranks on one device).  Its numbers mean nothing.
+    rehearsal = os.environ.get("SSW_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from seesaw_amd.sharded import ShardedSyntheticIndex
 
     n_total = int(args.rows)
     k = args.k
     dev = torch.device("cuda", local_rank)
-    index = ShardedSyntheticIndex(n_total, 512, args.seed, rank, world, local_rank, k_max=max(128, k))
+    index = ShardedSyntheticIndex(n_total, 512, args.seed, rank, world, local_rank, k_max=max(128, k),
+                                  comm_device="cpu" if (rehearsal and world > 1) else None)
     nq = args.steps + args.warmup
     q_host = np.stack([synth_query(i) for i in range(nq)])
     q_dev = torch.from_numpy(q_host).to(dev)
@@ -530,7 +540,7 @@ def main():
     c = int(count.item())
     imgs, scores = decode_keys(keys[:c].cpu().numpy().view(np.uint64))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

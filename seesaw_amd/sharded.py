@@ -237,7 +237,7 @@ class ShardedSyntheticIndex:
     over the ranks of the default process group; each rank generates its slice in place."""
 
     def __init__(self, n_total: int, dim: int, seed: int, rank: int, world: int,
-                 local_device: int, k_max: int = 128, group=None, force_collective: bool = False):
+                 local_device: int, k_max: int = 128, group=None, force_collective: bool = False, comm_device=None):
         import torch
         from .device_index import DeviceIndex
         self.torch = torch
@@ -257,7 +257,7 @@ class ShardedSyntheticIndex:
         self.local_count = torch.as_tensor(_DevArray(count_ptr, (2,), "<i4"), device=self.device)  # count, overflow
         self.xchg = ShardedTopK(rank=rank, world=world, device=self.device,
                                 image_offset=self.row_lo, k_max=k_max, group=group,
-                                force_collective=force_collective)
+                                force_collective=force_collective, comm_device=comm_device)
         # the selection writes the message itself, the merge unpacks it: scan -> select -> all-gather -> merge
         self.xchg.attach(self.local)
         if os.environ.get("SSW_C_COMM"):  # the collective through the library's own RCCL entry point
