@@ -72,10 +72,15 @@ class BaseLabelPropagationRanker:
         self.labels[idxs] = labels  # (a repeated id keeps its last label, as the per-item loop did)
         self.is_labeled[idxs] = 1
         self._label_map.update(zip(idxs.tolist(), labels.tolist()))
+        self._labels_stamp = getattr(self, "_labels_stamp", 0) + 1  # invalidates what was derived from the map
 
     def propagate_now(self):
         """the other half: propagate the recorded labels (PseudoLR runs this beside its pseudo-label draw)"""
-        has_negative = any(v == 0 for v in self._label_map.values())
+        stamp = getattr(self, "_labels_stamp", 0)
+        if getattr(self, "_neg_stamp", None) != stamp:  # once per label update, not once per call
+            self._has_negative = any(v == 0 for v in self._label_map.values())
+            self._neg_stamp = stamp
+        has_negative = self._has_negative
         if has_negative:  # the reference skips propagation until a negative label exists
             print(" propagating")
             self._current_scores = self._propagate(self.prior_scores)
