@@ -49,4 +49,4 @@ for rep in range(2):
         pr.disable()
 print("mean latency ms", 1e3 * np.mean(g["latencies"]))
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(35)
+st.sort_stats(os.environ.get("SSW_PROFILE_SORT", "cumulative")).print_stats(35)
