@@ -739,8 +739,13 @@ static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t 
     if (idx->ws.excl_dirty)  // a list installed by ssw_index_set_excluded does not apply to this call
         SSW_TRY(select_set_excluded(idx->ws, idx->n_images, nullptr, 0, idx->stream));
     if (q_host) {
-        memcpy(idx->small_host, q_host, q_bytes);
-        SSW_TRY(do_scan(idx, reinterpret_cast<const float *>(dev_view)));
+        if (idx->dim <= Q_ARG_FLOATS) {  // through a kernel argument into q_dev: 451 workgroups then read it out of L2
+            SSW_TRY(stage_query(idx, q_host));
+            SSW_TRY(do_scan(idx, idx->q_dev));
+        } else {  // (a wider query stays in the mapped block: every workgroup reads it over the host link)
+            memcpy(idx->small_host, q_host, q_bytes);
+            SSW_TRY(do_scan(idx, reinterpret_cast<const float *>(dev_view)));
+        }
     }
     if (n_excluded > 0) memcpy(idx->small_host + q_bytes, excluded_images, (size_t)n_excluded * sizeof(int64_t));
     unsigned seq = ++idx->small_seq;

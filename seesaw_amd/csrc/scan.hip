@@ -163,23 +163,24 @@ __global__ __launch_bounds__(256) void scan_scores_kernel(const float *__restric
 }
 
 // Small index (fewer rows than the streaming kernel needs to fill the chip: an LVIS-subset index has 14 417): the
-// streaming kernel gives each wave 64 rows, fetched two at a time -- 32 dependent round trips to HBM, ~12 us for 29 MB.
-// Here a wave takes U rows per step (all in flight at once), 16 waves a workgroup, at most 128 workgroups, and the query
-// comes through LDS: one wave's read per workgroup, so q may live in pinned host memory (ssw_index_topk's small-index
-// form) and its fetch overlaps the first rows'.  Same dot_frag / group_reduce order: identical bits.  Plain loads: an
-// index this size stays in the Infinity Cache between rounds.
+// streaming kernel gives each wave 64 rows, fetched two at a time -- 32 dependent round trips to HBM, and only
+// rows / 256 workgroups.  A CU streams ~10 B per clock from HBM (MICROARCH guide), so 29 MB on 57 or 113 CUs is 10+ us
+// however the loads are scheduled; the bytes have to be spread over every CU.  Here a wave takes U rows per step (all in
+// flight at once), four waves a workgroup: 32 rows per workgroup, 451 workgroups for the LVIS subset.  The query comes
+// through LDS (one wave's read per workgroup, from L2).  Same dot_frag / group_reduce order: identical bits.  Plain
+// loads: an index this size stays in the Infinity Cache between rounds.
 template <int C, int U>
-__global__ __launch_bounds__(1024) void scan_small_kernel(const float *__restrict__ X, const float *__restrict__ q,
-                                                          float *__restrict__ scores, int n, int steps) {
+__global__ __launch_bounds__(256) void scan_small_kernel(const float *__restrict__ X, const float *__restrict__ q,
+                                                         float *__restrict__ scores, int n, int steps) {
     __shared__ float4 ql[C * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int last = n - 1;
     const float4 *X4 = reinterpret_cast<const float4 *>(X);
-    const int row_base = (blockIdx.x * 16 + wave) * U * steps;
+    const int row_base = (blockIdx.x * 4 + wave) * U * steps;
     Group<C, U> cur, nxt;
     load_group<C, U, false>(cur, X4, row_base, last, lane);
-    if (threadIdx.x < C * 64) ql[threadIdx.x] = reinterpret_cast<const float4 *>(q)[threadIdx.x];
+    for (int i = threadIdx.x; i < C * 64; i += 256) ql[i] = reinterpret_cast<const float4 *>(q)[i];
     __syncthreads();
     RowFrag<C> qf;
 #pragma unroll
@@ -312,10 +313,10 @@ ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t 
     }
     if (n < SCAN_SMALL_ROWS && g_scan_small) {
         constexpr int SU = C <= 2 ? 8 : 4;
-        const int64_t per_step = 16 * SU;  // rows a workgroup takes per step
-        const int steps = (int)((n + 128 * per_step - 1) / (128 * per_step));
+        const int64_t per_step = 4 * SU;  // rows a workgroup takes per step
+        const int steps = (int)((n + 4096 * per_step - 1) / (4096 * per_step));  // 1 below 131 072 rows
         const int64_t sgrid = (n + per_step * steps - 1) / (per_step * steps);
-        hipLaunchKernelGGL((scan_small_kernel<C, SU>), dim3((unsigned)sgrid), dim3(1024), 0, stream, X, q, scores, (int)n,
+        hipLaunchKernelGGL((scan_small_kernel<C, SU>), dim3((unsigned)sgrid), dim3(256), 0, stream, X, q, scores, (int)n,
                            steps);
         SSW_HIP_TRY(hipGetLastError());
         return SSW_OK;
