@@ -8,7 +8,6 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
 export PYTHONPATH=.
 
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -o bench -- \
     python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -o bench -- \
@@ -26,6 +25,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn 
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
 python3 tools/make_traffic_json.py "$OUT" 100000000 > "$OUT/traffic.log" 2>&1   # -> profiles/traffic.json (stamp git locally)
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"   # after the PMC passes: its roofline.traffic reads the file just made
 python3 tools/summarise_pmc.py "$OUT/bench_fetch" scan_scores > "$OUT/fetch_summary.csv"
 python3 tools/summarise_pmc.py "$OUT/bench_write" scan_scores > "$OUT/write_summary.csv"
 ( echo "# mean per launch of scan_scores_kernel, rocprofv3 --pmc (two passes), bench.py --steps 3 --warmup 1"; cat "$OUT/fetch_summary.csv"; grep WRITE_SIZE "$OUT/write_summary.csv" ) > "profiles/${R}_bench_100M_pmc_fetch_write.csv"
