@@ -41,7 +41,7 @@ class Session:
                 print(f"warning, no entries found for category {params.annotation_category}")
             self.label_db.fill(df)
         self.loop = build_loop_from_params(gdm, self.q, params=params)
-        self.action_log = []
+        self._log_raw = []  # (time, message, seen, accepted): LogEntry objects are built when somebody reads action_log
         self._last_change = None
         self._log("init")
 
@@ -54,8 +54,19 @@ class Session:
         return self.loop.get_stats()
 
     def _log(self, message: str):
-        self.action_log.append(LogEntry.model_construct(logger="server", time=time.time(), message=message,
-                                                        seen=len(self.seen), accepted=len(self.accepted)))
+        self._log_raw.append((time.time(), message, len(self.seen), len(self.accepted)))
+
+    @property
+    def action_log(self):
+        """the reference's list of LogEntry (seesaw_session.py:56-62), materialised on demand: five pydantic objects a
+        round were a tenth of a `plain` round at LVIS-subset size"""
+        return [e if not isinstance(e, tuple) else
+                LogEntry.model_construct(logger="server", time=e[0], message=e[1], seen=e[2], accepted=e[3])
+                for e in self._log_raw]
+
+    @action_log.setter
+    def action_log(self, entries):  # update_state: the client hands the log back with its own entries in it
+        self._log_raw = list(entries)
 
     def next(self):
         """next batch of image ids from the loop; the batch and its activations are remembered for get_state"""
