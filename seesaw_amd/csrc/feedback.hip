@@ -1428,7 +1428,7 @@ struct ssw_fb {
     std::vector<float> y_host, sw_host;
     // pinned staging of the per-round uploads (row ids, targets, query): queued on the stream without a wait -- the fit
     // that follows is stream-ordered behind them (a refine spent ~35 us in three synchronisations here)
-    PinnedStage rows_stage, y_stage, q_stage;
+    PinnedStage rows_stage, y_stage, q_stage, coef_stage;
     std::vector<float> qhat_host;  // the normalised query (host copy, for the two-output objective's host part)
     // diagnostics of the last fit
     int last_iters = 0, last_evals = 0;
@@ -1578,10 +1578,8 @@ static ssw_status fb_prepare(ssw_fb *fb, const ssw_fb_objective *o, FbObjDev *de
         set_error("feedback: unknown objective kind %d", o->kind);
         return SSW_ERR_INVALID;
     }
-    if (n > 0)
-        SSW_HIP_TRY(hipMemcpyAsync(fb->coef, coef.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, fb->stream));
-    // coef is a local: the copy must be staged before it goes out of scope
-    SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+    // through pinned staging (coef is a local), without a wait: the evaluations are stream-ordered behind the copy
+    if (n > 0) SSW_TRY(fb->coef_stage.push(fb->coef, coef.data(), (size_t)n * sizeof(float), fb->stream));
     return SSW_OK;
 }
 
@@ -2059,6 +2057,7 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     fb->rows_stage.release();
     fb->y_stage.release();
     fb->q_stage.release();
+    fb->coef_stage.release();
     (void)hipFree(fb->X);
     (void)hipFree(fb->mu);
     (void)hipFree(fb->y);
@@ -2298,8 +2297,13 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
         }
         const size_t lds = fit_wg_lds_bytes(fb->dim);
         auto kern = fb->dim + 1 <= 9 * 64 ? k_fb_fit_wg<9> : k_fb_fit_wg<16>;
-        // the attribute is per device: set it on every fit (microseconds next to a fit) rather than cache a process-wide flag
-        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // the attribute is per device: one flag per (device, kernel)
+        static bool attr_done[64][2] = {};
+        const int dslot = fb->device >= 0 && fb->device < 64 ? fb->device : -1, kslot = fb->dim + 1 <= 9 * 64 ? 0 : 1;
+        if (dslot < 0 || !attr_done[dslot][kslot]) {
+            SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (dslot >= 0) attr_done[dslot][kslot] = true;
+        }
         hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, fb->stream, a, w0v);
         SSW_HIP_TRY(hipGetLastError());
         {
