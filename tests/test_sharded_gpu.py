@@ -214,3 +214,28 @@ def test_exchange_over_rccl_world_size_1():
     tail = "\n".join((proc.stdout + proc.stderr).splitlines()[-30:])
     assert proc.returncode == 0, tail
     assert "RCCL_WORLD1_OK" in proc.stdout, tail
+
+
+def test_bench_with_two_ranks_on_one_gpu_returns_the_single_gpu_answer():
+    """bench.py's N > 1 path end to end (shards, selection writing the exchange message, all-gather, merge from the
+    messages, overflow check, max-over-ranks timing, rank 0's JSON line) with two ranks sharing GPU 0 and the collective
+    over gloo (SSW_BENCH_REHEARSAL: RCCL cannot put two ranks on one device): the last query's top-1 equals the N = 1
+    run's, bit for bit."""
+    import json
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    args = ["--steps", "3", "--warmup", "1", "--rows", "3000000", "--no-extras", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, "\n".join((one.stdout + one.stderr).splitlines()[-20:])
+    env2 = dict(env)
+    env2["SSW_BENCH_REHEARSAL"] = "gloo"
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env2, capture_output=True, text=True,
+                         timeout=600)
+    assert two.returncode == 0, "\n".join((two.stdout + two.stderr).splitlines()[-20:])
+    line = lambda out: json.loads([x for x in out.splitlines() if x.startswith("{")][-1])  # noqa: E731
+    a, b = line(one.stdout), line(two.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["rows_per_gpu"] == 1500000
+    assert a["top1"] == b["top1"], (a["top1"], b["top1"])
