@@ -188,15 +188,21 @@ __global__ __launch_bounds__(256) void stack_input_rows(const float *__restrict_
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_MAX_S = 80;
 
-template <int NT>
-__global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
+// TPW: query tiles per wave (round 3).  With one tile per wave a (image, head) pair is four waves and a CU holds eight pairs;
+// 2400 pairs on 2048 places run as a full round and a nearly empty one.  With two tiles per wave a pair is two waves, all
+// pairs are resident at once, and a wave reads its K fragments once for both of its tiles.  Per pair the arithmetic is
+// unchanged (same fragments, same MFMA order per tile): identical output.
+template <int NT, int TPW = 1>
+__global__ __launch_bounds__(NT / TPW * 64) void attention_mfma(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S,
                                                           int D, int H, float scale, int causal) {
     constexpr int KP = ((NT * 16 + 31) / 32) * 32;  // keys padded to the MFMA K step
     constexpr bool PSW = KP == 64;                  // P rows of exactly 128 B: swizzled instead of padded
     constexpr int LDP = PSW ? 64 : KP + 8;          // LDS row stride of the P tile (bf16)
-    constexpr int VCH = (KP * 8 + NT * 64 - 1) / (NT * 64);  // 16-byte V chunks per thread
+    static_assert(NT % TPW == 0, "whole waves");
+    constexpr int NW = NT / TPW;                    // waves per workgroup
+    constexpr int VCH = (KP * 8 + NW * 64 - 1) / (NW * 64);  // 16-byte V chunks per thread
     __shared__ __attribute__((aligned(16))) bf16 sV[KP * 64];  // [key][64 head dims], 32-byte chunks swizzled
-    __shared__ __attribute__((aligned(16))) bf16 sP[NT][16 * LDP];
+    __shared__ __attribute__((aligned(16))) bf16 sP[NT][16 * LDP];  // one 16-row tile per query tile
     // element offset of column `col` (a multiple of 4) of P row `row`
     auto p_off = [](int row, int col) {
         return PSW ? row * 64 + ((((col >> 3) ^ ((row >> 1) & 7)) << 3) | (col & 7)) : row * LDP + col;
@@ -208,21 +214,33 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16 *base = qkv + (int64_t)b * S * 3 * D + h * 64;
-    bf16 *pt = sP[wave];
 
     // V rows of this head (whole workgroup, 128-byte rows); keys >= S are zero
     bf16x8 vreg[VCH];
 #pragma unroll
     for (int c = 0; c < VCH; ++c) {
-        const int ch = t + c * NT * 64, key = ch >> 3, d0 = (ch & 7) * 8;
+        const int ch = t + c * NW * 64, key = ch >> 3, d0 = (ch & 7) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) vreg[c][j] = (bf16)0.f;
         if (ch < KP * 8 && key < S) vreg[c] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + 2 * D + d0);
     }
-    const int i = wave;                 // query tile
-    const bool tile_live = i * 16 < S;  // wave-uniform
-    f32x4 sc[NT];
-    if (tile_live) {
+    const bool wave_live = wave * TPW * 16 < S;  // wave-uniform: its first tile has a live query
+    if (wave_live) {
+      // K fragments of every key tile, once for all of this wave's query tiles
+      bf16x8 kf[NT][2];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+          const int key = min(j * 16 + fr, S - 1);  // clamped rows are masked below
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+              kf[j][ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + D + ks * 32 + fq * 8);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) {
+        const int i = wave * TPW + tt;  // query tile
+        if (i * 16 >= S) break;         // wave-uniform
+        bf16 *pt = sP[i];
+        f32x4 sc[NT];
         const int qrow = min(i * 16 + fr, S - 1);
         bf16x8 qf[2];
 #pragma unroll
@@ -230,13 +248,10 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
             qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qrow * 3 * D + ks * 32 + fq * 8);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int key = min(j * 16 + fr, S - 1);  // clamped rows are masked below
             sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(base + (int64_t)key * 3 * D + D + ks * 32 + fq * 8);
-                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[j], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+                sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], sc[j], 0, 0, 0);
         }
         // this lane holds scores[query = 16 i + fr][key = 16 j + 4 fq + r]
         const int q = i * 16 + fr;
@@ -279,15 +294,21 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
             for (int r = 0; r < 4; ++r) z[r] = (bf16)0.f;
             *reinterpret_cast<bf16x4 *>(&pt[p_off(fr, NT * 16 + fq * 4)]) = z;
         }
+      }
     }
     // V into LDS as it is: sV[key][d]
 #pragma unroll
     for (int c = 0; c < VCH; ++c) {
-        const int ch = t + c * NT * 64, key = ch >> 3, c16 = ch & 7;
+        const int ch = t + c * NW * 64, key = ch >> 3, c16 = ch & 7;
         if (ch < KP * 8) *reinterpret_cast<bf16x8 *>(&sV[v_off(key, c16 >> 1) + (c16 & 1) * 8]) = vreg[c];
     }
     __syncthreads();
-    if (!tile_live) return;  // whole waves leave: the transposed reads below need all 64 lanes of a wave
+    if (!wave_live) return;  // whole waves leave: the transposed reads below need all 64 lanes of a wave
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+    const int i = wave * TPW + tt;
+    if (i * 16 >= S) break;
+    const bf16 *pt = sP[i];
     // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
     f32x4 o[4];
 #pragma unroll
@@ -320,6 +341,7 @@ __global__ __launch_bounds__(NT * 64) void attention_mfma(const bf16 *__restrict
             for (int r = 0; r < 4; ++r) ov[r] = to_bf16(o[dt][r]);
             *reinterpret_cast<bf16x4 *>(orow + dt * 16) = ov;
         }
+    }
     }
 }
 
@@ -1080,7 +1102,11 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         }
         const int n_heads = B * tw.H;
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
-        if (S <= 64)
+        static const bool one_tile_waves = getenv("SSW_CLIP_ATTN_TPW1") != nullptr;  // A/B: the four-wave form
+        if (S <= 64 && !one_tile_waves)
+            hipLaunchKernelGGL((attention_mfma<4, 2>), dim3(n_heads), dim3(128), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
+                               causal);
+        else if (S <= 64)
             hipLaunchKernelGGL(attention_mfma<4>, dim3(n_heads), dim3(256), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
                                causal);
         else
