@@ -211,9 +211,9 @@ ssw_status ssw_topk_allgather(ssw_comm *comm, void *hip_stream, const uint64_t *
  * through LDS) unless a variant is named; -2 = the default streaming variant at every size.  All produce identical bits. */
 ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu);
 
-/* ssw_index_topk on an index of <= 8192 images / 65536 rows and <= 8192 excluded ids runs as two launches (scan;
- * per-image max + exclusion + sort in one workgroup) with the query, the ids and the result in pinned memory the device
- * maps -- no copies, no stream wait (flag bit 0).  From 2^24 values on and k <= 2048 the selection's threshold comes from a
+/* ssw_index_topk on an index of <= 8192 images / 65536 rows and <= 8192 excluded ids runs as three launches (query staged
+ * through a kernel argument; scan; per-image max + exclusion + selection in one workgroup) with the ids and the result in
+ * pinned memory the device maps -- no copies, no stream wait (flag bit 0).  From 2^24 values on and k <= 2048 the selection's threshold comes from a
  * 1-in-16 sample instead of two full histogram passes (flag bit 1; exact all the same: a sample that leaves fewer than k
  * candidates raises the overflow word and the deep path runs).  Default 3; tests switch the forms off to compare. */
 ssw_status ssw_tune_topk(int32_t flags);

@@ -706,11 +706,11 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
 
 // An index of a few thousand images (an LVIS-category subset: 1 109 images x 13 tiles) spends its round in fixed
 // costs, not in the scan: three copies, five launches and a stream wait were ~95 us around ~10 us of kernels.  This form
-// is two launches and no copy: the scan reads the query and the selection reads the excluded ids from pinned memory the
-// device maps, the selection (per-image max + exclusion + sort in one workgroup) writes the packed result into the same
-// block and releases a sequence word the host spins on.
+// is three launches and no copy: the query goes to q_dev through a kernel argument, the scan runs on every CU, and ONE
+// kernel takes the per-image maximum, strikes out the excluded ids (read from pinned memory the device maps), selects
+// and writes the packed result into the same pinned block, releasing a sequence word the host spins on.
 constexpr int64_t SMALL_EXCL_CAP = 8192;
-constexpr int64_t SMALL_ROWS = 65536;  // <= 256 scan workgroups read the query over the host link
+constexpr int64_t SMALL_ROWS = 65536;  // the small scan kernel's range (scan.hip)
 
 static bool g_small_path = true;  // ssw_tune_topk
 
