@@ -808,7 +808,12 @@ ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *ex
     // the selection's last kernel writes the packed result into the pinned mirror and releases a sequence word: the
     // host spins on it (no device-to-host copy, no stream wait)
     SSW_TRY(arm_host_result(idx));
-    SSW_TRY(do_select(idx, k));
+    const ssw_status st = do_select(idx, k);
+    if (st != SSW_OK) {  // nothing was launched that would publish: disarm
+        idx->ws.host_packed = nullptr;
+        idx->res_pending_seq = 0;
+        return st;
+    }
     return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
 }
 
