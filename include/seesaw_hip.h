@@ -487,6 +487,11 @@ ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t 
  * 14 the same with 8 waves per tile, 7 256-row pipelined, 9 the 8-wave 256 x 256 tile, 20-23 the persistent
  * four-wave kernel of csrc/gemm_pw4.hip with its column tile chosen / 256 / 192 / 128). */
 ssw_status ssw_tune_gemm(int32_t variant);
+/* Residual stream of the towers' tile path (csrc/clip.hip, run_tower).  Default 0: the image tower keeps its residual
+ * rows in bf16 (the out-projection / fc2 epilogues add into them in place), the text tower in f32.
+ * bit 0: f32 rows for the image tower too (the round-2 arithmetic); bit 1: bf16 rows for the text tower too.
+ * Not part of the reference's interface. */
+ssw_status ssw_tune_clip(int32_t flags);
 /* Diagnostics of csrc/gemm_pw4.hip for tools/perf_gemm.py: mode 0 the kernel, 1 cycle stamps (out6 = cycles in the
  * mid-step wait + barrier, cycles in K-steps, K-steps, waves, s_memtime and s_memrealtime ticks per kernel; read and reset), 2-4 ablations (no LDS-DMA / no MFMA /
  * no fragment reads inside the loop: wrong results, timing only). */

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "ssw_clip_sync": (c_i32, [c_void_p]),
     "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "ssw_tune_gemm": (c_i32, [c_i32]),
+    "ssw_tune_clip": (c_i32, [c_i32]),
     "ssw_wm_build_symmetric": (c_i32, [c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
     "ssw_wm_fetch": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_wm_destroy": (c_i32, [c_void_p]),

@@ -32,7 +32,7 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3, EPI_BF16_LN = 4, EPI_BF16_LN_GELU = 5,
-                EPI_F32_BIAS_RESIDUAL_STATS = 6 };  // as gemm_bf16.hip
+                EPI_F32_BIAS_RESIDUAL_STATS = 6, EPI_BF16_STREAM_STATS = 7 };  // as gemm_bf16.hip
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
@@ -814,6 +814,14 @@ __global__ void eos_rows(const int *__restrict__ ids, int B, int L, int eos, int
     rows[b] = b * L + pos;
 }
 
+// the pooled rows of a bf16 residual stream, widened into the f32 rows the final LayerNorm reads
+__global__ void widen_rows(const bf16 *__restrict__ x, const int *__restrict__ rows, int B, int D, float *__restrict__ out) {
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const int64_t o = (int64_t)rows[b] * D;
+        for (int d = threadIdx.x; d < D; d += blockDim.x) out[o + d] = (float)x[o + d];
+    }
+}
+
 __global__ void cls_rows(int B, int T, int *__restrict__ rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) rows[b] = b * T;
@@ -868,6 +876,7 @@ struct ssw_clip {
     int64_t cap_rows = 0, cap_mlp = 0, cap_batch = 0;
     float *hidden = nullptr, *hidden2 = nullptr, *pooled = nullptr, *patch_out = nullptr;
     bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *h1 = nullptr, *patches = nullptr;
+    bool stream_in_xn = false;  // run_tower left the residual stream in xn (bf16), not in hidden
     float *stats_a = nullptr, *stats_b = nullptr;  // [rows][D / 128][2] partial LayerNorm statistics of hidden / hidden2
     float *pixels = nullptr, *out = nullptr;
     int *ids = nullptr, *rows = nullptr;
@@ -1051,6 +1060,9 @@ bool skinny_rows(int R, int D, int M) {
     return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);  // (head dim 64: 8 heads)
 }
 
+// ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's
+int g_clip_flags = getenv("SSW_CLIP_F32_STREAM") ? 1 : 0;
+
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     hipStream_t s = c->stream;
     const int R = B * S, D = tw.D, M = tw.M;
@@ -1082,6 +1094,13 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     // its partial statistics; QKV / fc1 multiply that copy by gamma (.) W and apply mean / rstd in their epilogue.
     // c->xn and stats_in arrive filled by whoever produced c->hidden (stack_input_rows).
     static const bool unfused_ln = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
+    // the residual stream of the tile path in bf16: the producers' bf16 copy IS the stream (read, added to, written back
+    // in place by EPI_BF16_STREAM_STATS), the f32 row and its 30 MB + 30 MB a product at B = 200 are gone
+    // Measured against transformers' f32 towers (tools/clip_stream_error.py, 26 images): min cosine 0.999994 -> 0.999952,
+    // max |delta| of a unit vector's component 5.0e-4 -> 1.5e-3 (bar: 0.999 / 5e-3); B = 200 forward 2.91 -> 2.75 ms.
+    // On for the image tower (the batch path); the text tower -- the query side -- keeps its f32 rows.
+    const bool bf16_stream = causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0;
+    c->stream_in_xn = false;
     const int np = D / 128;
     float *st_h = c->stats_a, *st_h2 = c->stats_b;
     for (int l = 0; l < tw.L && !skinny; ++l) {
@@ -1119,6 +1138,15 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
                                ly.ln2w, ly.ln2b, eps, c->xn);
             SSW_TRY(gemm<EPI_BF16_BIAS_GELU>(s, c->xn, ly.w1, ly.b1, nullptr, c->h1, R, M, D));
             SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->h1, ly.w2, ly.b2, h2, h, R, D, M));
+        } else if (bf16_stream) {
+            c->stream_in_xn = true;
+            prod.stats_out = st_h2;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_STREAM_STATS, s, c->att, ly.wo, ly.bo, nullptr, nullptr, R, D, D, prod));
+            cons.stats_in = st_h2;
+            cons.c1 = ly.c1fc1;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->xn, ly.w1_ln, ly.c2fc1, nullptr, c->h1, R, M, D, cons));
+            prod.stats_out = st_h;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_STREAM_STATS, s, c->h1, ly.w2, ly.b2, nullptr, nullptr, R, D, M, prod));
         } else {
             prod.stats_out = st_h2;
             SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->att, ly.wo, ly.bo, h, h2, R, D, D, prod));
@@ -1138,6 +1166,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
 ssw_status pool_and_project(ssw_clip *c, const Tower &tw, int B, int D, int normalize, float *out_dev) {
     hipStream_t s = c->stream;
     const Header &h = c->hdr;
+    if (c->stream_in_xn) hipLaunchKernelGGL(widen_rows, dim3(B < 1024 ? B : 1024), dim3(256), 0, s, c->xn, c->rows, B, D, c->hidden);
     if (h.proj % 16 == 0 && skinny_rows(B, D, tw.M)) {
         launch_skinny<SK_F32, true>(s, c->hidden, c->rows, tw.lnf_w, tw.lnf_b, h.ln_eps, tw.proj, nullptr, nullptr,
                                     out_dev, B, h.proj, D);
@@ -1206,6 +1235,15 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
 }  // namespace
 
 extern "C" {
+
+ssw_status ssw_tune_clip(int32_t flags) {
+    if (flags < 0 || flags > 3) {
+        ssw::set_error("ssw_tune_clip: flags %d unknown (bit 0 f32 stream for images, bit 1 bf16 stream for text)", flags);
+        return SSW_ERR_INVALID;
+    }
+    g_clip_flags = flags;
+    return SSW_OK;
+}
 
 ssw_status ssw_clip_destroy(ssw_clip *c) {
     if (!c) return SSW_OK;

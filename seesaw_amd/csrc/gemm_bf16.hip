@@ -35,13 +35,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 
 // 4 / 5: LayerNorm folded into the product (GemmLn, ssw_common.h) -> bf16 [+ quick-GELU]; 6: +bias +residual -> f32, plus the
-// bf16 copy of the new residual row and its partial LayerNorm statistics for the next product
+// bf16 copy of the new residual row and its partial LayerNorm statistics for the next product; 7: the same with the
+// residual stream itself held in bf16 (read from and written back to GemmLn::xcopy, no f32 row)
 enum Epilogue { EPI_F32 = 0, EPI_BF16_BIAS = 1, EPI_BF16_BIAS_GELU = 2, EPI_F32_BIAS_RESIDUAL = 3, EPI_BF16_LN = 4,
-                EPI_BF16_LN_GELU = 5, EPI_F32_BIAS_RESIDUAL_STATS = 6 };
+                EPI_BF16_LN_GELU = 5, EPI_F32_BIAS_RESIDUAL_STATS = 6, EPI_BF16_STREAM_STATS = 7 };
 constexpr bool epi_ln(int e) { return e == EPI_BF16_LN || e == EPI_BF16_LN_GELU; }
 constexpr bool epi_bf16_out(int e) { return e == EPI_BF16_BIAS || e == EPI_BF16_BIAS_GELU || epi_ln(e); }
 constexpr bool epi_gelu(int e) { return e == EPI_BF16_BIAS_GELU || e == EPI_BF16_LN_GELU; }
 constexpr bool epi_residual(int e) { return e == EPI_F32_BIAS_RESIDUAL || e == EPI_F32_BIAS_RESIDUAL_STATS; }
+constexpr bool epi_stats(int e) { return e == EPI_F32_BIAS_RESIDUAL_STATS || e == EPI_BF16_STREAM_STATS; }
 
 // LayerNorm folded into a product (no layernorm launch in the tile path).  With x the f32 residual row,
 // LN(x) W^T + b = rstd * (x W'^T - mean * c1) + c2,  W' = gamma (.) W (folded once at load, bf16), c1_n = sum_k W'_nk,
@@ -70,7 +72,11 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, cons
             v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
     }
     if constexpr (epi_residual(EPI)) v += *reinterpret_cast<const f32x4 *>(residual + o);
-    if constexpr (epi_bf16_out(EPI)) {
+    if constexpr (EPI == EPI_BF16_STREAM_STATS) {  // the stream's own element: read here, replaced below by this thread
+        const bf16x4 rb = *reinterpret_cast<const bf16x4 *>(ln.xcopy + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rb[r];
+    } else if constexpr (epi_bf16_out(EPI)) {
         bf16x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
@@ -78,11 +84,15 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, cons
     } else {
         *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + o) = v;
     }
-    if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {
+    if constexpr (epi_stats(EPI)) {
         bf16x4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
         *reinterpret_cast<bf16x4 *>(ln.xcopy + o) = h;
+        if constexpr (EPI == EPI_BF16_STREAM_STATS) {  // statistics of the row as stored: the next product normalises that
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)h[r];
+        }
         *sum += (v[0] + v[1]) + (v[2] + v[3]);
         *sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                                     ln_c + (col - n0), ln_c + 128 + (col - n0));
             }
         }
-        if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {  // this wave's 128 / WN columns of the row: the four fq lanes
+        if constexpr (epi_stats(EPI)) {  // this wave's 128 / WN columns of the row: the four fq lanes
             ssum += __shfl_xor(ssum, 16, 64);
             ssq += __shfl_xor(ssq, 16, 64);
             ssum += __shfl_xor(ssum, 32, 64);
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
             }
         }
     }
-    if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS) {
+    if constexpr (epi_stats(EPI)) {
         __syncthreads();
         if (t < TM && m0 + t < M) {  // the tile's 128 columns of row t: the WN wave partials in wave order
             float sm = 0.f, sq = 0.f;
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
 #undef T256_LGKM0_BARRIER
 
     // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
-    static_assert(EPI != EPI_F32_BIAS_RESIDUAL_STATS, "the statistics epilogue lives in gemm_glds (N = hidden width shapes)");
+    static_assert(!epi_stats(EPI), "the statistics epilogue lives in gemm_glds (N = hidden width shapes)");
     if constexpr (epi_ln(EPI)) {
         float sm = 0.f, sq = 0.f;
 #pragma unroll
@@ -789,7 +799,7 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 template <int EPI>
 ssw_status launch_epi_ln(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                          int N, int K, const GemmLn &ln) {
-    if constexpr (EPI != EPI_F32_BIAS_RESIDUAL_STATS) {
+    if constexpr (!epi_stats(EPI)) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
@@ -848,6 +858,12 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t s, const void *A_, const voi
                 return SSW_ERR_INVALID;
             }
             return launch_epi_ln<EPI_F32_BIAS_RESIDUAL_STATS>(s, A, W, bias, res, C, M, N, K, ln);
+        case EPI_BF16_STREAM_STATS:
+            if (!ln.xcopy || !ln.stats_out || !bias) {
+                set_error("gemm_bf16_ln: the bf16-stream epilogue needs the stream rows, the partial-sum buffer and bias");
+                return SSW_ERR_INVALID;
+            }
+            return launch_epi_ln<EPI_BF16_STREAM_STATS>(s, A, W, bias, nullptr, nullptr, M, N, K, ln);
     }
     set_error("gemm_bf16_ln: epilogue %d is not a LayerNorm-folded one", epi);
     return SSW_ERR_INVALID;

@@ -47,6 +47,39 @@ def test_image_tower_vs_hf(models):
     assert np.abs(got[0] - got[1]).max() > 1e-3
 
 
+def test_residual_stream_precisions_vs_hf(models):
+    """The tile path holds the image tower's residual rows in bf16 by default and the text tower's in f32
+    (ssw_tune_clip): both arithmetic forms of both towers meet the bar, and the switch is live."""
+    import torch
+    from seesaw_amd import _lib
+    hf, ours = models
+    torch.manual_seed(5)
+    x = torch.randn(6, 3, 224, 224)
+    rng = np.random.default_rng(11)
+    ids = rng.integers(0, 49405, size=(4, 40)).astype(np.int64)
+    ids[:, 0] = 49406
+    ids[:, 39] = 49407
+    with torch.inference_mode():
+        ref_i = hf.get_image_features(pixel_values=x)
+        ref_i = _unit((ref_i.pooler_output if hasattr(ref_i, "pooler_output") else ref_i).numpy())
+        ref_t = hf.get_text_features(input_ids=torch.from_numpy(ids))
+        ref_t = _unit((ref_t.pooler_output if hasattr(ref_t, "pooler_output") else ref_t).numpy())
+    got = {}
+    try:
+        for flags in (0, 3):  # 0: images bf16 / text f32 (default); 3: images f32 / text bf16
+            _lib.call("ssw_tune_clip", flags)
+            got[flags] = (ours.embed_image(x.numpy(), normalize=True), _unit(ours.embed_text(ids.astype(np.int32), normalize=False)))
+    finally:
+        _lib.call("ssw_tune_clip", 0)
+    for flags, (gi, gt) in got.items():
+        assert (gi * ref_i).sum(1).min() >= COS_MIN and (gt * ref_t).sum(1).min() >= COS_MIN, flags
+        assert np.abs(gi - ref_i).max() <= ABS_MAX and np.abs(gt - ref_t).max() <= ABS_MAX, flags
+    for a, b in zip(got[0], got[3]):
+        assert 0 < np.abs(a - b).max() <= 3e-3
+    with pytest.raises(_lib.SeesawHipError):
+        _lib.call("ssw_tune_clip", 4)
+
+
 @pytest.mark.parametrize("L", [8, 77])
 def test_text_tower_vs_hf(models, L):
     import torch
