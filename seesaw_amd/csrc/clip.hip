@@ -95,15 +95,25 @@ __global__ __launch_bounds__(256) void layernorm_rows(const float *__restrict__ 
 // position embedding): besides the f32 residual row, the stack's first QKV product wants its bf16 copy and its
 // LayerNorm statistics as `np` partial (sum, sum of squares) pairs (GemmLn, ssw_common.h) -- the whole row in partial 0.
 // LN = true: y = LayerNorm(x) with (w, b) is the row (x is consumed); LN = false: y = x.
+// With `pos` given, x is the patch embedding's output and the row is put together here, the image tower's input:
+// token 0 of an image = cls + pos[0], token 1 + p = x[image * (T - 1) + p] + pos[1 + p].  y_out may be null (bf16 stream).
 template <bool LN>
 __global__ __launch_bounds__(256) void stack_input_rows(const float *__restrict__ x, int n_rows, int D,
                                                         const float *__restrict__ w, const float *__restrict__ b,
                                                         float eps, float *__restrict__ y_out, bf16 *__restrict__ y_bf16,
-                                                        float *__restrict__ stats, int np) {
+                                                        float *__restrict__ stats, int np,
+                                                        const float *__restrict__ cls = nullptr,
+                                                        const float *__restrict__ pos = nullptr, int T = 1) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)r * D);
+    const float4 *pr = nullptr;
+    if (pos) {
+        const int tk = r % T, img = r / T;
+        xr = reinterpret_cast<const float4 *>(tk == 0 ? cls : x + ((int64_t)img * (T - 1) + tk - 1) * D);
+        pr = reinterpret_cast<const float4 *>(pos + (int64_t)tk * D);
+    }
     const int nv = D >> 2;
     float4 v[4];
     float s = 0.f;
@@ -111,6 +121,10 @@ __global__ __launch_bounds__(256) void stack_input_rows(const float *__restrict_
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr && c < nv) {
+            const float4 pp = pr[c];
+            v[i].x += pp.x; v[i].y += pp.y; v[i].z += pp.z; v[i].w += pp.w;
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     if (LN) {
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(256) void stack_input_rows(const float *__restrict_
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            if (LN) yo[c] = v[i];
+            if (LN && y_out) yo[c] = v[i];
             bf16x4 h;
             h[0] = (bf16)v[i].x; h[1] = (bf16)v[i].y; h[2] = (bf16)v[i].z; h[3] = (bf16)v[i].w;
             yb[c] = h;
@@ -712,19 +726,6 @@ __global__ void im2col_patches_u8(const uint8_t *__restrict__ tiles, bf16 *__res
     }
 }
 
-// hidden[b, 0] = cls + pos[0]; hidden[b, 1+p] = patch_out[b*np + p] + pos[1+p]
-__global__ void vision_assemble(const float *__restrict__ patch_out, const float *__restrict__ cls,
-                                const float *__restrict__ pos, float *__restrict__ hidden, int B, int T, int D) {
-    const int64_t total = (int64_t)B * T * D;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int tk = (int)((i / D) % T);
-        const int b = (int)(i / ((int64_t)D * T));
-        const float v = tk == 0 ? cls[d] : patch_out[((int64_t)b * (T - 1) + tk - 1) * D + d];
-        hidden[i] = v + pos[tk * D + d];
-    }
-}
-
 __global__ void text_embed(const int *__restrict__ ids, const float *__restrict__ tok, const float *__restrict__ pos,
                            float *__restrict__ hidden, int B, int L, int D) {
     const int64_t total = (int64_t)B * L * D;
@@ -1062,6 +1063,14 @@ bool skinny_rows(int R, int D, int M) {
 
 // ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's
 int g_clip_flags = getenv("SSW_CLIP_F32_STREAM") ? 1 : 0;
+bool unfused_ln_forced() {
+    static const bool v = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
+    return v;
+}
+// does this tower's tile path keep its residual rows in bf16?
+bool bf16_rows(const Tower &tw, int causal) {
+    return !unfused_ln_forced() && tw.D % 128 == 0 && (causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0);
+}
 
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     hipStream_t s = c->stream;
@@ -1093,13 +1102,13 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     // ssw_common.h): the out-projection / fc2 epilogues leave, next to the f32 residual row, its bf16 copy (c->xn) and
     // its partial statistics; QKV / fc1 multiply that copy by gamma (.) W and apply mean / rstd in their epilogue.
     // c->xn and stats_in arrive filled by whoever produced c->hidden (stack_input_rows).
-    static const bool unfused_ln = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
+    const bool unfused_ln = unfused_ln_forced();
     // the residual stream of the tile path in bf16: the producers' bf16 copy IS the stream (read, added to, written back
     // in place by EPI_BF16_STREAM_STATS), the f32 row and its 30 MB + 30 MB a product at B = 200 are gone
     // Measured against transformers' f32 towers (tools/clip_stream_error.py, 26 images): min cosine 0.999994 -> 0.999952,
     // max |delta| of a unit vector's component 5.0e-4 -> 1.5e-3 (bar: 0.999 / 5e-3); B = 200 forward 2.91 -> 2.75 ms.
     // On for the image tower (the batch path); the text tower -- the query side -- keeps its f32 rows.
-    const bool bf16_stream = causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0;
+    const bool bf16_stream = bf16_rows(tw, causal);
     c->stream_in_xn = false;
     const int np = D / 128;
     float *st_h = c->stats_a, *st_h2 = c->stats_b;
@@ -1192,10 +1201,12 @@ ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *
     const int g = h.image / h.patch, T = g * g + 1, D = h.v_hidden;
     const int pcols = 3 * h.patch * h.patch;
     SSW_TRY(gemm<EPI_F32>(s, c->patches, c->patch_w, nullptr, nullptr, c->patch_out, B * (T - 1), D, pcols));
-    hipLaunchKernelGGL(vision_assemble, dim3(2048), dim3(256), 0, s, c->patch_out, c->cls, c->vpos, c->hidden2, B, T, D);
-    // pre-LayerNorm = the stack's input row: f32 into c->hidden, bf16 copy and statistics for layer 0's QKV
-    hipLaunchKernelGGL(stack_input_rows<true>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->hidden2, B * T, D, c->pre_w,
-                       c->pre_b, h.ln_eps, c->hidden, c->xn, c->stats_a, D / 128 > 0 ? D / 128 : 1);
+    // cls / patch rows + position embedding, then the pre-LayerNorm = the stack's input row, in one pass: bf16 copy and
+    // statistics for layer 0's QKV, and the f32 row into c->hidden unless the stack keeps its rows in bf16
+    // (round 3: putting the rows together was a launch and a 30-MB round trip of its own at B = 200)
+    hipLaunchKernelGGL(stack_input_rows<true>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->patch_out, B * T, D, c->pre_w,
+                       c->pre_b, h.ln_eps, bf16_rows(c->vis, 0) ? (float *)nullptr : c->hidden, c->xn, c->stats_a,
+                       D / 128 > 0 ? D / 128 : 1, c->cls, c->vpos, T);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
     hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
     return pool_and_project(c, c->vis, B, D, normalize, out_dev);
