@@ -531,10 +531,15 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+    // workgroup ids b and b + 8 run on the same XCD: XCD x takes a contiguous eighth of the tiles in row-major order
+    // (its workgroups share A row tiles through its L2), every XCD the same number to within one -- with whole row
+    // tiles dealt round-robin (the 128 x 128 kernel's order) 28 row tiles x 9 put 36 tiles on the 32 CUs of four XCDs
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
-    if (mt >= m_tiles) return;
+    const int n_all = m_tiles * n_tiles, per_xcd = (n_all + 7) >> 3;
+    const int tile = xcd * per_xcd + idx;
+    if (tile >= n_all) return;
+    const int mt = tile / n_tiles, nt = tile % n_tiles;
     const int m0 = mt * 256, n0 = nt * 256;
 
     // staging: half-tile = 16 pieces of 8 rows x 128 B; wave w issues pieces 2w and 2w+1 of every half
@@ -719,7 +724,7 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     const int m_tiles = (M + 255) / 256, n_tiles = N / 256;
-    const int grid = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    const int grid = ((m_tiles * n_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL((gemm_256<EPI>), dim3(grid), dim3(512), lds, s, A, W, bias, res, C, M, N, K, m_tiles, n_tiles, ln);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -766,6 +771,27 @@ ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float 
     return SSW_OK;
 }
 
+// The default choice between the two tile kernels (variant 14 of ssw_tune_gemm; 15 = the 128 x 128 kernel only).
+// The 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills the chip about twice or
+// more: measured at M = 10 000 (profiles/r02_gemm_ab.txt) it wins on fc1 (480 tiles, 1.9 rounds of 256 CUs: 777 vs
+// 674 TFLOP/s) and loses on QKV (360 tiles: one round and 0.4 of a second) and on every N = 768 shape (120 tiles).
+// (Round 3 also measured a split by rows for the grids in between -- the 7168 rows of QKV that make exactly one round
+// on the 256 x 256 kernel, the other 2832 on the 128 x 128 kernel behind it: 48.7 us against 47.1 for the small tiles
+// alone, text QKV 38.4 against 36.2, the B = 200 forward unchanged at 2.47 ms.  Removed.)
+template <int EPI>
+ssw_status launch_auto(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
+                       int N, int K, const GemmLn &ln) {
+    if constexpr (!epi_stats(EPI)) {
+        if (g_gemm_variant != 15 && N % 256 == 0) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
+            if (10 * tiles256 >= 18 * (int64_t)num_cus(dev)) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
+        }
+    }
+    return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
+}
+
 template <int EPI>
 ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                       int N, int K) {
@@ -781,17 +807,7 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
             if (N % 256 == 0) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, none);
             return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, none);
         case 2: return launch_glds<EPI, 2, 128>(s, A, W, bias, res, C, M, N, K, none);
-        default: {
-            // the 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills the chip
-            // about twice or more: measured at M = 10 000 (profiles/r02_gemm_ab.txt) it wins on fc1 (480 tiles,
-            // 777 vs 674 TFLOP/s) and loses on QKV (360 tiles: 1.4 rounds) and on every N = 768 shape (120 tiles)
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
-            if (g_gemm_variant == 14 && N % 256 == 0 && 10 * tiles256 >= 18 * (int64_t)num_cus(dev))
-                return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, none);
-            return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, none);
-        }
+        default: return launch_auto<EPI>(s, A, W, bias, res, C, M, N, K, none);
     }
 }
 
@@ -799,14 +815,7 @@ ssw_status launch_epi(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 template <int EPI>
 ssw_status launch_epi_ln(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                          int N, int K, const GemmLn &ln) {
-    if constexpr (!epi_stats(EPI)) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
-        if (g_gemm_variant != 15 && N % 256 == 0 && 10 * tiles256 >= 18 * (int64_t)num_cus(dev))
-            return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
-    }
-    return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
+    return launch_auto<EPI>(s, A, W, bias, res, C, M, N, K, ln);
 }
 
 }  // namespace
