@@ -98,6 +98,62 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, cons
     }
 }
 
+// bf16 outputs leave through LDS (round 3).  Straight from the accumulators a lane stores the 4 consecutive columns it
+// holds -- 8 bytes -- and the 64 lanes of one store instruction touch 16 different rows: 8-byte write requests, 7.6 M
+// of them for fc1's 61 MB.  A timing-only ablation with 16 bytes per lane took gemm_256 from 60 to 52 us on fc1 and
+// from 55.5 to 47.3 on QKV: the request count, not the bytes, was what the epilogue cost.  So a wave parks RH x 16 rows
+// of its sub-tile as bf16 in a private piece of the (by now idle) staging area, rows padded by 16 bytes so the 16
+// rows of a write land on different banks, and reads them back row-major: every store instruction then writes whole
+// 64- or 128-byte row segments, 16 bytes a lane.  Same values, same bits.
+template <int EPI>
+__device__ __forceinline__ f32x4 epilogue_value(f32x4 v, float mean, float rstd, const float *c1_lds, const float *c2_lds) {
+    if constexpr (epi_ln(EPI)) {
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(c1_lds), c2 = *reinterpret_cast<const f32x4 *>(c2_lds);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * c1[r]) + c2[r];
+    }
+    if constexpr (epi_gelu(EPI)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504f * v[r]));
+    }
+    return v;
+}
+
+// acc: [RH][NJ] accumulator tiles of this wave (rows row0 + i*16 + fr, columns col0 + j*16 + fq*4 + r); wl: the wave's
+// RH*16 x (NJ*32 + 16) bytes of LDS; ln_rows: statistics of the tile's rows from local row lrow0 on; c1 / c2 at col0
+template <int EPI, int RH, int NJ>
+__device__ __forceinline__ void store_rows_via_lds(const f32x4 (*acc)[NJ], unsigned char *wl, int lane, int row0, int col0,
+                                                   int M, int N, bf16 *__restrict__ C, const float *ln_rows,
+                                                   const float *c1_lds, const float *c2_lds) {
+    static_assert(epi_bf16_out(EPI), "bf16 outputs only");
+    constexpr int RB = NJ * 32 + 16;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < RH; ++i) {
+        float mean = 0.f, rstd = 1.f;
+        if constexpr (epi_ln(EPI)) {
+            mean = ln_rows[2 * (i * 16 + fr)];
+            rstd = ln_rows[2 * (i * 16 + fr) + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const f32x4 v = epilogue_value<EPI>(acc[i][j], mean, rstd, c1_lds + j * 16 + fq * 4, c2_lds + j * 16 + fq * 4);
+            bf16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = to_bf16(v[r]);
+            *reinterpret_cast<bf16x4 *>(wl + (i * 16 + fr) * RB + j * 32 + fq * 8) = h;
+        }
+    }
+    constexpr int CH = NJ * 2, RPI = 64 / CH;  // 16-byte chunks per row, rows per store instruction
+    const int rr = lane / CH, cc = lane % CH;
+#pragma unroll
+    for (int it = 0; it < RH * 16 / RPI; ++it) {
+        const int row = it * RPI + rr;
+        const bf16x8 h = *reinterpret_cast<const bf16x8 *>(wl + row * RB + cc * 16);
+        if (row0 + row < M) *reinterpret_cast<bf16x8 *>(C + (int64_t)(row0 + row) * N + col0 + cc * 8) = h;
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------
 // variant 0: register-staged double buffer (global -> VGPR -> padded LDS), one tile of lookahead
@@ -452,6 +508,15 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
         if (t < 64) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
         __syncthreads();
     }
+    if constexpr (epi_bf16_out(EPI) && WN == 4 && TM == 128 && !PIPE) {
+        // (the LayerNorm variants passed a barrier just above; the others need one: another wave may still be reading
+        //  its last fragments out of the bytes this wave is about to overwrite)
+        if constexpr (!epi_ln(EPI)) __syncthreads();
+        store_rows_via_lds<EPI, 4, NJ>(acc, smem + wave * (64 * (NJ * 32 + 16)), lane, m0 + wm * 64, n0 + wn * (128 / WN), M, N,
+                                       reinterpret_cast<bf16 *>(Cout), ln_lds + 2 * (wm * 64), ln_c + wn * (128 / WN),
+                                       ln_c + 128 + wn * (128 / WN));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lrow = wm * 64 + i * 16 + fr;
@@ -691,6 +756,15 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
         asm volatile("" : "+v"(ln_cpre));
         if (t < 128) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
         __syncthreads();
+    }
+    if constexpr (epi_bf16_out(EPI)) {
+        if constexpr (!epi_ln(EPI)) __syncthreads();  // as in gemm_glds: the staging bytes are about to be reused
+#pragma unroll
+        for (int h = 0; h < 2; ++h)  // 64 rows at a time: 9 KB of LDS per wave
+            store_rows_via_lds<EPI, 4, 4>(acc + 4 * h, smem + wave * (64 * 144), lane, m0 + wr * 128 + h * 64, n0 + wc * 64, M, N,
+                                          reinterpret_cast<bf16 *>(Cout), ln_lds + 2 * (wr * 128 + h * 64), ln_c + wc * 64,
+                                          ln_c + 256 + wc * 64);
+        return;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
