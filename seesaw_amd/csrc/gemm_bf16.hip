@@ -517,6 +517,61 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                                        ln_c + 128 + wn * (128 / WN));
         return;
     }
+    if constexpr (EPI == EPI_BF16_STREAM_STATS && WN == 4 && TM == 128 && !PIPE) {
+        // The bf16 residual stream, the same way: the wave's 64 x 32 sub-tile goes through LDS as f32, 32 rows at a time
+        // (144-byte rows: the 16 rows of a write on different banks), and comes back row-major, four lanes a row with 8
+        // consecutive columns each -- the stream row is read and written back in 16-byte pieces (64-byte segments per
+        // row) instead of 8-byte ones, the sum is taken in f32 as before, and the row's partial statistics are those of
+        // the rounded values: 8 per lane, then the 4 lanes of the row, then the WN waves in wave order.
+        constexpr int RBF = 32 * 4 + 16;
+        unsigned char *wl = smem + wave * (32 * RBF);
+        const int rr = lane >> 2, cc = lane & 3;
+        const int col0 = n0 + wn * 32 + cc * 8;
+        bf16x8 res[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // all four 16-row groups of the stream rows, requested before the LDS round trip
+            const int row = m0 + wm * 64 + it * 16 + rr;
+            res[it] = *reinterpret_cast<const bf16x8 *>(ln.xcopy + (int64_t)min(row, M - 1) * N + col0);
+        }
+        __syncthreads();  // another wave may still be reading its last fragments out of these bytes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4 *>(wl + (il * 16 + fr) * RBF + j * 64 + fq * 16) = acc[2 * h + il][j];
+#pragma unroll
+            for (int il = 0; il < 2; ++il) {
+                const int it = 2 * h + il;
+                const int lrow = wm * 64 + it * 16 + rr;
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32 + 16);
+                bf16x8 o;
+                float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = to_bf16(lo[r] + (float)res[it][r]);
+                    o[4 + r] = to_bf16(hi[r] + (float)res[it][4 + r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float vr = (float)o[r];
+                    ssum += vr;
+                    ssq += vr * vr;
+                }
+                if (m0 + lrow < M) *reinterpret_cast<bf16x8 *>(ln.xcopy + (int64_t)(m0 + lrow) * N + col0) = o;
+                ssum += __shfl_xor(ssum, 1, 64);
+                ssq += __shfl_xor(ssq, 1, 64);
+                ssum += __shfl_xor(ssum, 2, 64);
+                ssq += __shfl_xor(ssq, 2, 64);
+                if (cc == 0) {
+                    ln_lds[(wn * TM + lrow) * 2] = ssum;
+                    ln_lds[(wn * TM + lrow) * 2 + 1] = ssq;
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lrow = wm * 64 + i * 16 + fr;
