@@ -359,6 +359,159 @@ __global__ __launch_bounds__(NT / TPW * 64) void attention_mfma(const bf16 *__re
     }
 }
 
+// Round 3, S <= 64 (the image tower): the same arithmetic with every global access a whole 128-byte row.  Above, a lane
+// fetches its K / Q fragments straight from memory -- 16 bytes each from 16 different rows per instruction, K once per
+// wave -- and stores the 4 head dims it ends with (8 bytes): 16- and 8-byte requests, and from B ~ 100 on the kernel ran
+// at the rate of its requests, not of its 61 MB.  Here the workgroup's 128 threads fetch the K, Q and V rows of the
+// (image, head) pair coalesced (8 lanes a row, K once), K and Q go to LDS in the GEMM's swizzled 128-byte rows and the
+// fragments are read from there; a query tile's 2 KB of LDS holds first its Q rows, then its P tile, then its output
+// tile, which leaves row-major (16 bytes a lane); V takes K's place once every wave has its K fragments.  16 KB of LDS
+// as before.  Same fragments, same MFMA order: identical output.
+__global__ __launch_bounds__(128) void attention_rows64(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S, int D, int H,
+                                                        float scale, int causal) {
+    constexpr int NT = 4, TPW = 2, KP = 64;
+    __shared__ __attribute__((aligned(16))) bf16 sKV[KP * 64];      // K rows (GEMM swizzle), later V rows (v_off)
+    __shared__ __attribute__((aligned(16))) bf16 sQP[NT][16 * 64];  // per query tile: Q rows, then P, then the output
+    // element offset of 16-byte chunk c16 of a 128-byte row
+    auto g_off = [](int row, int c16) { return row * 64 + ((c16 ^ ((row >> 1) & 7)) << 3); };
+    auto v_off = [](int key, int c32) { return key * 64 + ((c32 ^ (((key >> 1) & 1) | (((key >> 3) & 1) << 1))) << 4); };
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16 *base = qkv + (int64_t)b * S * 3 * D + h * 64;
+
+    bf16x8 kreg[4], qreg[4], vreg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = t + c * 128, row = ch >> 3, d0 = (ch & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kreg[c][j] = qreg[c][j] = vreg[c][j] = (bf16)0.f;
+        if (row < S) {
+            const bf16 *r = base + (int64_t)row * 3 * D + d0;
+            qreg[c] = *reinterpret_cast<const bf16x8 *>(r);
+            kreg[c] = *reinterpret_cast<const bf16x8 *>(r + D);
+            vreg[c] = *reinterpret_cast<const bf16x8 *>(r + 2 * D);
+        }
+    }
+    bf16 *const sQ = &sQP[0][0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = t + c * 128, row = ch >> 3, c16 = ch & 7;
+        *reinterpret_cast<bf16x8 *>(&sKV[g_off(row, c16)]) = kreg[c];
+        *reinterpret_cast<bf16x8 *>(&sQ[g_off(row, c16)]) = qreg[c];
+    }
+    __syncthreads();
+    const bool wave_live = wave * TPW * 16 < S;  // wave-uniform: its first tile has a live query
+    if (wave_live) {
+        bf16x8 kf[NT][2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8 *>(&sKV[g_off(j * 16 + fr, ks * 4 + fq)]);
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int i = wave * TPW + tt;  // query tile
+            if (i * 16 >= S) break;         // wave-uniform
+            bf16 *pt = sQP[i];
+            f32x4 sc[NT];
+            bf16x8 qf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(&pt[g_off(fr, ks * 4 + fq)]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], sc[j], 0, 0, 0);
+            }
+            // this lane holds scores[query = 16 i + fr][key = 16 j + 4 fq + r]
+            const int q = i * 16 + fr;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = j * 16 + fq * 4 + r;
+                    float v = sc[j][r] * scale;
+                    if (key >= S || (causal && key > q)) v = -INFINITY;
+                    sc[j][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(sc[j][r] - mx);  // key 0 is never masked, so mx is finite
+                    sc[j][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            // P (bf16) over this tile's Q rows (its fragments are in registers): [16 queries][64 keys]
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x4 pv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pv[r] = to_bf16(sc[j][r] * inv);
+                *reinterpret_cast<bf16x4 *>(&pt[g_off(fr, j * 2 + (fq >> 1)) + (fq & 1) * 4]) = pv;
+            }
+        }
+    }
+    __syncthreads();  // every wave has its K fragments: V takes K's bytes
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = t + c * 128, key = ch >> 3, c16 = ch & 7;
+        *reinterpret_cast<bf16x8 *>(&sKV[v_off(key, c16 >> 1) + (c16 & 1) * 8]) = vreg[c];
+    }
+    __syncthreads();
+    if (!wave_live) return;  // whole waves leave: the transposed reads below need all 64 lanes of a wave
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        const int i = wave * TPW + tt;
+        if (i * 16 >= S) break;
+        bf16 *pt = sQP[i];
+        // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KP / 32; ++ks) {
+            const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[g_off(fr, ks * 4 + fq)]);
+            const int kq = ks * 32 + 8 * fq + (fr >> 2), dp = (fr & 3) * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sKV[v_off(kq, dt) + dp]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sKV[v_off(kq + 4, dt) + dp]));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vb = __builtin_bit_cast(bf16x8, both);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[dt], 0, 0, 0);
+            }
+        }
+        // the output tile over the P tile (read above by this wave only), then out row-major: 8 lanes a row
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = to_bf16(o[dt][r]);
+            *reinterpret_cast<bf16x4 *>(&pt[g_off(fr, dt * 2 + (fq >> 1)) + (fq & 1) * 4]) = ov;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + (lane >> 3), c16 = lane & 7;
+            const bf16x8 h8 = *reinterpret_cast<const bf16x8 *>(&pt[g_off(row, c16)]);
+            const int q = i * 16 + row;
+            if (q < S) *reinterpret_cast<bf16x8 *>(out + ((int64_t)b * S + q) * D + h * 64 + c16 * 8) = h8;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // skinny linear: out[R <= 32, N] = epilogue(LN?(X)[R, K] W[N, K]^T) for the handful of rows a single text query has.
 // The tile kernels above give such a product to N/128 workgroups that each walk all of K (a [8 x 2048] x [2048 x 512]
@@ -1132,7 +1285,10 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
         static const bool one_tile_waves = getenv("SSW_CLIP_ATTN_TPW1") != nullptr;  // A/B: the four-wave form
         // (one wave per pair with four tiles, attention_mfma<4, 4>: 21.6 us per layer against 17.1 -- measured, not kept)
-        if (S <= 64 && !one_tile_waves)
+        static const bool direct_frags = getenv("SSW_CLIP_ATTN_DIRECT") != nullptr;  // A/B: fragments straight from memory
+        if (S <= 64 && !one_tile_waves && !direct_frags)
+            hipLaunchKernelGGL(attention_rows64, dim3(n_heads), dim3(128), 0, s, c->qkv, c->att, S, D, tw.H, att_scale, causal);
+        else if (S <= 64 && !one_tile_waves)
             hipLaunchKernelGGL((attention_mfma<4, 2>), dim3(n_heads), dim3(128), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
                                causal);
         else if (S <= 64)
