@@ -571,6 +571,36 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                 }
             }
         }
+    } else if constexpr ((EPI == EPI_F32 || EPI == EPI_F32_BIAS_RESIDUAL) && WN == 4 && TM == 128 && !PIPE) {
+        // f32 outputs, the same way (a lane's 4 columns are 16 bytes here, but still 16 rows an instruction): 32 rows of
+        // the wave's 64 x 32 sub-tile at a time through LDS, back row-major, 8 lanes a row -- 128-byte segments for the
+        // store and for the residual row it adds
+        constexpr int RBF = 32 * 4 + 16;
+        unsigned char *wl = smem + wave * (32 * RBF);
+        const int rr = lane >> 3, cc = lane & 7;
+        const int col0 = n0 + wn * 32 + cc * 4;
+        f32x4 res[8];
+        if constexpr (EPI == EPI_F32_BIAS_RESIDUAL) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                res[it] = *reinterpret_cast<const f32x4 *>(residual + (int64_t)min(m0 + wm * 64 + it * 8 + rr, M - 1) * N + col0);
+        }
+        __syncthreads();  // another wave may still be reading its last fragments out of these bytes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<f32x4 *>(wl + (il * 16 + fr) * RBF + j * 64 + fq * 16) = acc[2 * h + il][j];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(wl + (it * 8 + rr) * RBF + cc * 16);
+                if constexpr (EPI == EPI_F32_BIAS_RESIDUAL) v += res[h * 4 + it];
+                const int row = m0 + wm * 64 + h * 32 + it * 8 + rr;
+                if (row < M) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + (int64_t)row * N + col0) = v;
+            }
+        }
     } else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
