@@ -931,21 +931,27 @@ ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float 
 }
 
 // The default choice between the two tile kernels (variant 14 of ssw_tune_gemm; 15 = the 128 x 128 kernel only).
-// The 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills the chip about twice or
-// more: measured at M = 10 000 (profiles/r02_gemm_ab.txt) it wins on fc1 (480 tiles, 1.9 rounds of 256 CUs: 777 vs
-// 674 TFLOP/s) and loses on QKV (360 tiles: one round and 0.4 of a second) and on every N = 768 shape (120 tiles).
+// The 256 x 256 tile (one workgroup per CU, 128 x 64 per wave) pays only when its grid fills whole rounds of the chip:
+// at M = 10 000 it wins on fc1 (480 tiles, 1.9 rounds of 256 CUs) and loses on QKV (360 tiles: one round and 0.4 of a
+// second) and on every N = 768 shape (120 tiles).
 // (Round 3 also measured a split by rows for the grids in between -- the 7168 rows of QKV that make exactly one round
 // on the 256 x 256 kernel, the other 2832 on the 128 x 128 kernel behind it: 48.7 us against 47.1 for the small tiles
 // alone, text QKV 38.4 against 36.2, the B = 200 forward unchanged at 2.47 ms.  Removed.)
 template <int EPI>
 ssw_status launch_auto(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                        int N, int K, const GemmLn &ln) {
-    if constexpr (!epi_stats(EPI)) {
+    if constexpr (epi_bf16_out(EPI)) {  // (f32 outputs leave through LDS in the 128 x 128 kernel only)
         if (g_gemm_variant != 15 && N % 256 == 0) {
             int dev = 0;
             (void)hipGetDevice(&dev);
+            // its tiles run in rounds of one per CU: it pays when the last round is nearly full.  Measured with the
+            // row-segment epilogues, QKV / fc1 (N = 2304 / 3072, K = 768), 128-square vs 256-square kernel, us:
+            //   M  2500: 15.0 / 21.8, 24.4 / 25.4      5000: 23.7 / 24.4, 30.5 / 28.6 (0.94 of a round)
+            //      7500: 34.3 / 42.2, 44.2 / 50.3     10000: 39.2 / 43.0 (1.41 rounds), 56.1 / 51.5 (1.88)
+            //     15000: 57.3 / 63.3 (2.07), 81.9 / 75.8 (2.77)    20000: 74.6 / 68.6 (2.78), 107.7 / 99.5
             const int64_t tiles256 = (int64_t)((M + 255) / 256) * (N / 256);
-            if (10 * tiles256 >= 18 * (int64_t)num_cus(dev)) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
+            const int64_t cus = num_cus(dev), rounds = (tiles256 + cus - 1) / cus;
+            if (100 * tiles256 >= 85 * rounds * cus) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
         }
     }
     return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
