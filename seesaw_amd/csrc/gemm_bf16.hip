@@ -517,21 +517,30 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                                        ln_c + 128 + wn * (128 / WN));
         return;
     }
-    if constexpr (EPI == EPI_BF16_STREAM_STATS && WN == 4 && TM == 128 && !PIPE) {
-        // The bf16 residual stream, the same way: the wave's 64 x 32 sub-tile goes through LDS as f32, 32 rows at a time
+    if constexpr (epi_stats(EPI) && WN == 4 && TM == 128 && !PIPE) {
+        // The residual stream, the same way: the wave's 64 x 32 sub-tile goes through LDS as f32, 32 rows at a time
         // (144-byte rows: the 16 rows of a write on different banks), and comes back row-major, four lanes a row with 8
-        // consecutive columns each -- the stream row is read and written back in 16-byte pieces (64-byte segments per
-        // row) instead of 8-byte ones, the sum is taken in f32 as before, and the row's partial statistics are those of
-        // the rounded values: 8 per lane, then the 4 lanes of the row, then the WN waves in wave order.
+        // consecutive columns each.  bf16 stream (7): the row is read and written back in 16-byte pieces (64-byte
+        // segments per row) instead of 8-byte ones, the sum is taken in f32 as before, the statistics are those of the
+        // rounded values.  f32 stream (6): residual and output rows in 32-byte pieces (128-byte segments), the bf16 copy
+        // in 16-byte ones, statistics of the f32 values.  Partial sums: 8 per lane, the 4 lanes of the row, then the
+        // WN waves in wave order.
+        constexpr bool BF = EPI == EPI_BF16_STREAM_STATS;
         constexpr int RBF = 32 * 4 + 16;
         unsigned char *wl = smem + wave * (32 * RBF);
         const int rr = lane >> 2, cc = lane & 3;
         const int col0 = n0 + wn * 32 + cc * 8;
-        bf16x8 res[4];
+        bf16x8 resb[4];
+        f32x4 resf[4][2];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {  // all four 16-row groups of the stream rows, requested before the LDS round trip
-            const int row = m0 + wm * 64 + it * 16 + rr;
-            res[it] = *reinterpret_cast<const bf16x8 *>(ln.xcopy + (int64_t)min(row, M - 1) * N + col0);
+            const int64_t o = (int64_t)min(m0 + wm * 64 + it * 16 + rr, M - 1) * N + col0;
+            if constexpr (BF) {
+                resb[it] = *reinterpret_cast<const bf16x8 *>(ln.xcopy + o);
+            } else {
+                resf[it][0] = *reinterpret_cast<const f32x4 *>(residual + o);
+                resf[it][1] = *reinterpret_cast<const f32x4 *>(residual + o + 4);
+            }
         }
         __syncthreads();  // another wave may still be reading its last fragments out of these bytes
 #pragma unroll
@@ -545,22 +554,38 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
             for (int il = 0; il < 2; ++il) {
                 const int it = 2 * h + il;
                 const int lrow = wm * 64 + it * 16 + rr;
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32);
-                const f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32 + 16);
+                f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32);
+                f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32 + 16);
                 bf16x8 o;
                 float ssum = 0.f, ssq = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    o[r] = to_bf16(lo[r] + (float)res[it][r]);
-                    o[4 + r] = to_bf16(hi[r] + (float)res[it][4 + r]);
+                    if constexpr (BF) {
+                        lo[r] += (float)resb[it][r];
+                        hi[r] += (float)resb[it][4 + r];
+                    } else {
+                        lo[r] += resf[it][0][r];
+                        hi[r] += resf[it][1][r];
+                    }
+                    o[r] = to_bf16(lo[r]);
+                    o[4 + r] = to_bf16(hi[r]);
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const float vr = (float)o[r];
-                    ssum += vr;
-                    ssq += vr * vr;
+                for (int r = 0; r < 4; ++r) {
+                    const float a = BF ? (float)o[r] : lo[r], b = BF ? (float)o[4 + r] : hi[r];
+                    ssum += a;
+                    ssq += a * a;
+                    ssum += b;
+                    ssq += b * b;
                 }
-                if (m0 + lrow < M) *reinterpret_cast<bf16x8 *>(ln.xcopy + (int64_t)(m0 + lrow) * N + col0) = o;
+                if (m0 + lrow < M) {
+                    const int64_t off = (int64_t)(m0 + lrow) * N + col0;
+                    *reinterpret_cast<bf16x8 *>(ln.xcopy + off) = o;
+                    if constexpr (!BF) {
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off) = lo;
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off + 4) = hi;
+                    }
+                }
                 ssum += __shfl_xor(ssum, 1, 64);
                 ssq += __shfl_xor(ssq, 1, 64);
                 ssum += __shfl_xor(ssum, 2, 64);
