@@ -489,7 +489,8 @@ ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t 
 ssw_status ssw_tune_gemm(int32_t variant);
 /* Residual stream of the towers' tile path (csrc/clip.hip, run_tower).  Default 0: the image tower keeps its residual
  * rows in bf16 (the out-projection / fc2 epilogues add into them in place), the text tower in f32.
- * bit 0: f32 rows for the image tower too (the round-2 arithmetic); bit 1: bf16 rows for the text tower too.
+ * bit 0: f32 rows for the image tower too (the round-2 arithmetic); bit 1: bf16 rows for the text tower too;
+ * bit 2: the image tower's attention in its earlier form (fragments fetched straight from memory; same bits out).
  * Not part of the reference's interface. */
 ssw_status ssw_tune_clip(int32_t flags);
 /* Diagnostics of csrc/gemm_pw4.hip for tools/perf_gemm.py: mode 0 the kernel, 1 cycle stamps (out6 = cycles in the

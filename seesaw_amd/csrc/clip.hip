@@ -1214,7 +1214,8 @@ bool skinny_rows(int R, int D, int M) {
     return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);  // (head dim 64: 8 heads)
 }
 
-// ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's
+// ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's,
+// bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too
 int g_clip_flags = getenv("SSW_CLIP_F32_STREAM") ? 1 : 0;
 bool unfused_ln_forced() {
     static const bool v = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
@@ -1285,7 +1286,8 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
         static const bool one_tile_waves = getenv("SSW_CLIP_ATTN_TPW1") != nullptr;  // A/B: the four-wave form
         // (one wave per pair with four tiles, attention_mfma<4, 4>: 21.6 us per layer against 17.1 -- measured, not kept)
-        static const bool direct_frags = getenv("SSW_CLIP_ATTN_DIRECT") != nullptr;  // A/B: fragments straight from memory
+        static const bool direct_env = getenv("SSW_CLIP_ATTN_DIRECT") != nullptr;  // A/B: fragments straight from memory
+        const bool direct_frags = direct_env || (g_clip_flags & 4) != 0;
         if (S <= 64 && !one_tile_waves && !direct_frags)
             hipLaunchKernelGGL(attention_rows64, dim3(n_heads), dim3(128), 0, s, c->qkv, c->att, S, D, tw.H, att_scale, causal);
         else if (S <= 64 && !one_tile_waves)
@@ -1404,8 +1406,8 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
 extern "C" {
 
 ssw_status ssw_tune_clip(int32_t flags) {
-    if (flags < 0 || flags > 3) {
-        ssw::set_error("ssw_tune_clip: flags %d unknown (bit 0 f32 stream for images, bit 1 bf16 stream for text)", flags);
+    if (flags < 0 || flags > 7) {
+        ssw::set_error("ssw_tune_clip: flags %d unknown (bit 0 f32 stream for images, bit 1 bf16 stream for text, bit 2 direct attention fragments)", flags);
         return SSW_ERR_INVALID;
     }
     g_clip_flags = flags;

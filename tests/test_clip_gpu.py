@@ -77,7 +77,22 @@ def test_residual_stream_precisions_vs_hf(models):
     for a, b in zip(got[0], got[3]):
         assert 0 < np.abs(a - b).max() <= 3e-3
     with pytest.raises(_lib.SeesawHipError):
+        _lib.call("ssw_tune_clip", 8)
+
+
+def test_image_attention_forms_give_the_same_bits(models):
+    """attention_rows64 (K / Q / V rows fetched coalesced, fragments out of LDS, the output tile stored row-major) against
+    attention_mfma<4, 2> (fragments straight from memory): same fragments, same MFMA order -- identical embeddings."""
+    from seesaw_amd import _lib
+    _, ours = models
+    x = np.random.default_rng(21).standard_normal((9, 3, 224, 224), dtype=np.float32)
+    try:
+        a = ours.embed_image(x, normalize=False)
         _lib.call("ssw_tune_clip", 4)
+        b = ours.embed_image(x, normalize=False)
+    finally:
+        _lib.call("ssw_tune_clip", 0)
+    assert a.tobytes() == b.tobytes()
 
 
 @pytest.mark.parametrize("L", [8, 77])
