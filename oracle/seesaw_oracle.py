@@ -38,13 +38,18 @@ def build_c_oracle(force: bool = False) -> str:
     out = os.path.join(_HERE, "_build", "libssw_oracle.so")
     stamp = os.path.join(_HERE, "_build", f".fma_{int(_cpu_has_fma())}")
     cmd = ["make", "-C", _HERE]
-    if force or not os.path.exists(stamp):
+    rebuild = force or not os.path.exists(stamp)
+    if rebuild:
         cmd.append("-B")
     subprocess.run(cmd, check=True, capture_output=True)
-    for f in os.listdir(os.path.join(_HERE, "_build")):
-        if f.startswith(".fma_"):
-            os.remove(os.path.join(_HERE, "_build", f))
-    open(stamp, "w").close()
+    if rebuild:  # (the stamps are touched only then: two ranks of a gloo test come through here at the same time)
+        for f in os.listdir(os.path.join(_HERE, "_build")):
+            if f.startswith(".fma_") and os.path.join(_HERE, "_build", f) != stamp:
+                try:
+                    os.remove(os.path.join(_HERE, "_build", f))
+                except FileNotFoundError:
+                    pass
+        open(stamp, "w").close()
     return out
 
 
