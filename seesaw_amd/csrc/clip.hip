@@ -1352,6 +1352,12 @@ ssw_status pool_and_project(ssw_clip *c, const Tower &tw, int B, int D, int norm
     return SSW_OK;
 }
 
+// Tiles (or texts) a host-side call hands to the device at a time.  A row's result does not depend on its batch
+// (tests/test_clip_gpu.py::test_more_tiles_than_one_device_chunk), so the size is a throughput choice: the image tower
+// costs 12.2-12.3 us a tile at 200-256 tiles a call and 10.4-10.8 from 384 on (tile-count rounding of the 256-row GEMM
+// tiles, launch ramps); 1024 tiles are ~2 GB of activations of the 288.
+constexpr int HOST_CHUNK = 1024;
+
 // c->patches holds the im2col'ed bf16 patches of B images
 ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *out_dev) {
     hipStream_t s = c->stream;
@@ -1500,7 +1506,7 @@ ssw_status ssw_clip_embed_image(ssw_clip *c, const float *nchw_host, int32_t b, 
     SSW_REQUIRE(c && nchw_host && out_host && b > 0, "bad argument");
     DeviceGuard guard(c->device);
     const Header &h = c->hdr;
-    const int chunk = 256;
+    const int chunk = HOST_CHUNK;
     SSW_TRY(reserve(c, std::min<int64_t>(b, chunk)));
     const size_t per = (size_t)3 * h.image * h.image;
     for (int b0 = 0; b0 < b; b0 += chunk) {
@@ -1521,7 +1527,7 @@ ssw_status ssw_clip_embed_tiles_u8(ssw_clip *c, const uint8_t *tiles_hwc_host, i
     DeviceGuard guard(c->device);
     const Header &h = c->hdr;
     SSW_REQUIRE(h.patch % 8 == 0, "clip: patch size %d is not a multiple of 8", h.patch);
-    const int chunk = 256;
+    const int chunk = HOST_CHUNK;
     SSW_TRY(reserve(c, std::min<int64_t>(b, chunk)));
     const size_t per = (size_t)3 * h.image * h.image;  // bytes per tile; c->pixels (f32) is 4x that
     for (int b0 = 0; b0 < b; b0 += chunk) {
@@ -1563,7 +1569,7 @@ ssw_status ssw_clip_embed_text(ssw_clip *c, const int32_t *ids_host, int32_t b, 
             SSW_REQUIRE(found, "clip: sequence %d holds no end-of-text token (id %d): nothing to pool", r, h.eos);
         }
     DeviceGuard guard(c->device);
-    const int chunk = 256;
+    const int chunk = HOST_CHUNK;
     SSW_TRY(reserve(c, std::min<int64_t>(b, chunk)));
     for (int b0 = 0; b0 < b; b0 += chunk) {
         const int nb = std::min(chunk, b - b0);

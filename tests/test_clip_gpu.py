@@ -261,12 +261,12 @@ def test_create_multiscale_index_round_trip(models, tmp_path):
 
 
 def test_more_tiles_than_one_device_chunk(models):
-    """300 tiles cross the 256-tile device chunk: row b of the result is the embedding of tile b"""
+    """1040 tiles cross the 1024-tile device chunk: row b of the result is the embedding of tile b"""
     _, ours = models
-    tiles = np.random.default_rng(11).integers(0, 256, size=(300, 224, 224, 3), dtype=np.uint8)
+    tiles = np.random.default_rng(11).integers(0, 256, size=(1040, 224, 224, 3), dtype=np.uint8)
     whole = ours.embed_tiles_u8(tiles, normalize=True)
-    assert whole.shape == (300, 512)
-    for lo, hi in ((0, 7), (250, 262), (293, 300)):
+    assert whole.shape == (1040, 512)
+    for lo, hi in ((0, 7), (250, 262), (500, 700), (1018, 1030), (1033, 1040)):
         part = ours.embed_tiles_u8(tiles[lo:hi], normalize=True)
         # a tile's embedding does not depend on its batch neighbours (same kernels, same per-row arithmetic)
         assert np.array_equal(part.view(np.uint32), whole[lo:hi].view(np.uint32)), (lo, hi)
