@@ -1223,7 +1223,7 @@ bool unfused_ln_forced() {
 }
 // does this tower's tile path keep its residual rows in bf16?
 bool bf16_rows(const Tower &tw, int causal) {
-    return !unfused_ln_forced() && tw.D % 128 == 0 && (causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0);
+    return !unfused_ln_forced() && tw.D % 256 == 0 && (causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0);
 }
 
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
@@ -1273,7 +1273,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         cons.inv_dim = 1.0f / (float)D;
         cons.eps = eps;
         prod.xcopy = c->xn;
-        if (unfused_ln || D % 128 != 0) {
+        if (unfused_ln || D % 256 != 0) {
             hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h, (const int *)nullptr, R, D,
                                ly.ln1w, ly.ln1b, eps, c->xn);
             SSW_TRY(gemm<EPI_BF16_BIAS>(s, c->xn, ly.wqkv, ly.bqkv, nullptr, c->qkv, R, 3 * D, D));
@@ -1299,7 +1299,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         else
             hipLaunchKernelGGL(attention_mfma<5>, dim3(n_heads), dim3(320), 0, s, c->qkv, c->att, S, D, tw.H, att_scale,
                                causal);
-        if (unfused_ln || D % 128 != 0) {
+        if (unfused_ln || D % 256 != 0) {
             SSW_TRY(gemm<EPI_F32_BIAS_RESIDUAL>(s, c->att, ly.wo, ly.bo, h, h2, R, D, D));
             hipLaunchKernelGGL(layernorm_rows<bf16>, dim3((R + 3) / 4), dim3(256), 0, s, h2, (const int *)nullptr, R, D,
                                ly.ln2w, ly.ln2b, eps, c->xn);

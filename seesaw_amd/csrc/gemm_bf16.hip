@@ -361,14 +361,19 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     // LayerNorm-folded variants: thread t < TM requests the partial sums of row m0 + t NOW (ordinary loads, ahead of the
     // ring's first pieces) and touches them only behind the K loop, where the compiler's vmcnt(0) for them finds every
     // LDS-DMA piece long landed; in between they cost eight registers and no wait.
-    constexpr int LN_NP = 8;  // partial pairs held in registers (hidden width <= 1024)
-    float2 ln_part[LN_NP];
+    // (Round 3: the tile's TM x np_in partial pairs are one contiguous block -- rows m0 .. m0 + TM - 1 of [M][np_in][2] --
+    //  and are fetched as such, 16 bytes a thread with consecutive threads on consecutive addresses, instead of eight
+    //  8-byte loads per row thread at a 48-byte stride; np_in is even (launch_gemm_bf16_ln), so the block is whole
+    //  float4s.  One register set of four instead of sixteen.)
+    constexpr int LN_F4 = (TM * 8 * 2 / 4 + TM * WN - 1) / (TM * WN);  // float4s per thread for np_in <= 8
+    f32x4 ln_raw[LN_F4];
     f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-31: c1 of 4 of the tile's 128 columns, 32-63: c2
     float *const ln_c = ln_lds + 2 * TM;         // [2][128] behind the statistics
     if constexpr (epi_ln(EPI)) {
-        const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < TM ? t : 0), M - 1) * ln.np_in;
+        const f32x4 *st = reinterpret_cast<const f32x4 *>(ln.stats_in + (int64_t)m0 * ln.np_in * 2);
+        const int n_valid = min(M - m0, TM) * ln.np_in / 2;  // float4s of the rows that exist
 #pragma unroll
-        for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];  // unconditional: no select, hence no early wait
+        for (int k = 0; k < LN_F4; ++k) ln_raw[k] = st[min(t + k * TM * WN, n_valid - 1)];  // unconditional: no early wait
         ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 32) ? bias : ln.c1) + n0 + (t & 31) * 4);
     }
 
@@ -491,12 +496,23 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 
     // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*(128/WN) + j*16 + fq*4 + r]
     if constexpr (epi_ln(EPI)) {
-        float sm = 0.f, sq = 0.f;
+        // the block of partials through the (idle) staging bytes: parked as fetched, then row t's np_in pairs added in
+        // ascending order by thread t -- the order the per-row loads had
+        __syncthreads();  // every wave is done with its last fragments
+        float *const raw = reinterpret_cast<float *>(smem);
 #pragma unroll
-        for (int p = 0; p < LN_NP; ++p) {
-            asm volatile("" : "+v"(ln_part[p].x), "+v"(ln_part[p].y));  // keep the sums (and their wait) behind the loop
-            sm += p < ln.np_in ? ln_part[p].x : 0.f;
-            sq += p < ln.np_in ? ln_part[p].y : 0.f;
+        for (int k = 0; k < LN_F4; ++k) {
+            asm volatile("" : "+v"(ln_raw[k]));  // keep the wait for them behind the loop
+            const int idx = t + k * TM * WN;
+            if (idx < TM * ln.np_in / 2) *reinterpret_cast<f32x4 *>(raw + 4 * idx) = ln_raw[k];
+        }
+        __syncthreads();
+        float sm = 0.f, sq = 0.f;
+        if (t < TM) {
+            for (int p = 0; p < ln.np_in; ++p) {
+                sm += raw[(t * ln.np_in + p) * 2];
+                sq += raw[(t * ln.np_in + p) * 2 + 1];
+            }
         }
         if (t < TM) {
             const float mean = sm * ln.inv_dim;
@@ -757,15 +773,15 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
         for (int i = 0; i < 8; ++i) acc[i][j] = bv;
     }
     float *const ln_lds = reinterpret_cast<float *>(smem + 2 * T256_STAGE);  // [256][2] row statistics
-    constexpr int LN_NP = 8;  // as in gemm_glds: requested now, first touched behind the K loop
-    float2 ln_part[LN_NP];
+    f32x4 ln_raw[2];  // as in gemm_glds: the tile's 256 x np_in partial pairs as one block, two float4s a thread
     f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-63: c1 of 4 of the tile's 256 columns, 64-127: c2
     float *const ln_c = ln_lds + 2 * 256;        // [2][256] behind the statistics
     if constexpr (epi_ln(EPI)) {
         ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 64) ? bias : ln.c1) + n0 + (t & 63) * 4);
-        const float2 *st = reinterpret_cast<const float2 *>(ln.stats_in) + (int64_t)min(m0 + (t < 256 ? t : 0), M - 1) * ln.np_in;
+        const f32x4 *st = reinterpret_cast<const f32x4 *>(ln.stats_in + (int64_t)m0 * ln.np_in * 2);
+        const int n_valid = min(M - m0, 256) * ln.np_in / 2;
 #pragma unroll
-        for (int p = 0; p < LN_NP; ++p) ln_part[p] = st[min(p, ln.np_in - 1)];
+        for (int k = 0; k < 2; ++k) ln_raw[k] = st[min(t + k * 512, n_valid - 1)];
     }
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
     const int a_frag = wr * T256_HALF + frag0;                                        // + i * 2048, i = 0..7
@@ -850,12 +866,21 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
     static_assert(!epi_stats(EPI), "the statistics epilogue lives in gemm_glds (N = hidden width shapes)");
     if constexpr (epi_ln(EPI)) {
-        float sm = 0.f, sq = 0.f;
+        __syncthreads();  // every wave is done with its last fragments
+        float *const raw = reinterpret_cast<float *>(smem);
 #pragma unroll
-        for (int p = 0; p < LN_NP; ++p) {
-            asm volatile("" : "+v"(ln_part[p].x), "+v"(ln_part[p].y));
-            sm += p < ln.np_in ? ln_part[p].x : 0.f;
-            sq += p < ln.np_in ? ln_part[p].y : 0.f;
+        for (int k = 0; k < 2; ++k) {
+            asm volatile("" : "+v"(ln_raw[k]));
+            const int idx = t + k * 512;
+            if (idx < 256 * ln.np_in / 2) *reinterpret_cast<f32x4 *>(raw + 4 * idx) = ln_raw[k];
+        }
+        __syncthreads();
+        float sm = 0.f, sq = 0.f;
+        if (t < 256) {
+            for (int p = 0; p < ln.np_in; ++p) {
+                sm += raw[(t * ln.np_in + p) * 2];
+                sq += raw[(t * ln.np_in + p) * 2 + 1];
+            }
         }
         if (t < 256) {
             const float mean = sm * ln.inv_dim;
@@ -1045,8 +1070,8 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t s, const void *A_, const voi
     switch (epi) {
         case EPI_BF16_LN:
         case EPI_BF16_LN_GELU:
-            if (!ln.stats_in || !ln.c1 || !bias || ln.np_in <= 0 || ln.np_in > 8) {
-                set_error("gemm_bf16_ln: the LayerNorm-folded product needs statistics, c1 and c2");
+            if (!ln.stats_in || !ln.c1 || !bias || ln.np_in <= 0 || ln.np_in > 8 || (ln.np_in & 1)) {
+                set_error("gemm_bf16_ln: the LayerNorm-folded product needs statistics (an even number of partial pairs, <= 8), c1 and c2");
                 return SSW_ERR_INVALID;
             }
             return epi == EPI_BF16_LN ? launch_epi_ln<EPI_BF16_LN>(s, A, W, bias, res, C, M, N, K, ln)
