@@ -59,3 +59,32 @@ def test_batch_tx_is_clip_normalisation():
     assert x.shape == (2, 3, 224, 224) and x.dtype == np.float32
     ref = (d.tile.values[1].astype(np.float32)[5, 7, 2] / np.float32(255.0) - np.float32(0.40821073)) / np.float32(0.27577711)
     assert x[1, 2, 5, 7] == np.float32(ref)
+
+
+def test_inference_actor_hands_over_1024_tiles_a_call_and_keeps_the_order():
+    """the reference's InferenceActor is called with 200-tile batches (multiscale_tools.py:205-221); here a call takes up
+    to 1024 tiles -- a throughput choice, a tile's vector does not depend on its call -- and row i of the result belongs
+    to tile i whatever the split"""
+    import pandas as pd
+    from seesaw_amd.indices.multiscale.multiscale_tools import InferenceActor
+
+    class Fake:
+        def __init__(self):
+            self.calls = []
+
+        def embed_tiles_u8(self, tiles, normalize=True):
+            self.calls.append(tiles.shape[0])
+            out = np.zeros((tiles.shape[0], 512), np.float32)
+            out[:, 0] = tiles[:, 0, 0, 0]  # the tile's tag
+            return out
+
+    tiles = [np.full((2, 2, 3), i % 251, np.uint8) for i in range(2500)]
+    df = pd.DataFrame({"dbidx": np.arange(2500), "tile": tiles})
+    fake = Fake()
+    out = InferenceActor(fake)(df)
+    assert fake.calls == [1024, 1024, 452]
+    assert "tile" not in out.columns and out.shape[0] == 2500
+    assert [int(v[0]) for v in out.vectors.values] == [i % 251 for i in range(2500)]
+    fake = Fake()
+    InferenceActor(fake, batch_size=200)(df.iloc[:450])
+    assert fake.calls == [200, 200, 50]
