@@ -1,0 +1,367 @@
+// Attention and the out-projection of a ViT-B/32 layer in one launch (round 4): a workgroup per image.
+//
+// The tile path ran attention (one workgroup per (image, head): 15.6 us a layer at B = 200) and then the
+// out-projection as a [B*50, 768] x [768, 768] product (21 us: 11.8 GFLOP, mostly ramp, prologue and the exposed
+// +residual epilogue of a single round of tiles), with the attention output -- 15 MB a layer -- written to memory and
+// read back in between.  Here the image's 50 token rows (padded to 64) never leave the CU:
+//   phase 1  attention, two heads at a time: the pair's Q / K / V rows come in coalesced (16 bytes a thread, the next
+//            pair's requested before this pair is computed), go to LDS in attention_rows64's layouts, wave
+//            (head of the pair, query tile) runs the same fragments through the same MFMAs (identical bf16 output),
+//            and the 16 x 64 output tile lands in sO [64 rows][768] (LDS, 96 KB);
+//   phase 2  out = sO Wo^T + bo: wave w owns output columns [96 w, 96 w + 96) of all 64 rows -- 4 x 6 accumulator tiles
+//            -- its A fragments come from sO (ds_read_b128, conflict-free through a 16-chunk XOR by row), its Wo
+//            fragments straight from memory (no other wave wants them: no LDS round trip), PD K-steps ahead; k ascends
+//            exactly as in the tile GEMM, so the products are the GEMM's bit for bit;
+//   epilogue the residual row is added and the new row written back 16 bytes a lane through LDS, with the row's
+//            LayerNorm partial sums for the fc1 product (two partial pairs a row: columns [0, 384) and [384, 768)).
+// Replaces, like the kernels it fuses, the attention + out_proj of transformers' CLIPEncoderLayer that the reference
+// calls through HGFaceWrapper.forward (seesaw/models/model.py:50-57).
+#include "ssw_common.h"
+
+namespace ssw {
+namespace {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
+
+constexpr int AO_D = 768, AO_H = 12, AO_NW = 8;
+constexpr int AO_NJ = AO_D / AO_NW / 16;           // 6 accumulator column tiles per wave
+constexpr int AO_ROWB = AO_D * 2;                  // bytes of an sO row
+constexpr int AO_SO = 64 * AO_ROWB;                // 98304
+constexpr int AO_SK = AO_SO, AO_SV = AO_SK + 2 * 8192, AO_SQ = AO_SV + 2 * 8192;
+constexpr int AO_LDS = AO_SQ + 2 * 4 * 2048;       // 147456
+// epilogue reuse of the same bytes: per-wave f32 staging of 16 rows x 96 columns (400-byte rows), then the partial sums
+constexpr int AO_EROW = 96 * 4 + 16;
+constexpr int AO_ESTAGE = 16 * AO_EROW;            // 6400 per wave
+constexpr int AO_EPART = AO_NW * AO_ESTAGE;        // partial (sum, sq): [wave][64 rows][12] float2
+static_assert(AO_EPART + AO_NW * 64 * 12 * 8 <= AO_LDS, "epilogue scratch fits");
+
+// byte offset in sO of the 16-byte chunk holding elements [k0, k0 + 8) of row `row` (k0 a multiple of 8): inside each
+// 256-byte window the chunk index is XORed with the row, so the 16 rows a ds_read_b128 lane group touches -- and the 16
+// rows of a ds_write_b64 group -- hit 16 different slots (rows are 1536 B apart: a multiple of the 256-byte bank row)
+__device__ __forceinline__ int so_off(int row, int k0) {
+    const int b = k0 * 2;
+    return row * AO_ROWB + (b & ~255) + ((((b >> 4) & 15) ^ (row & 15)) << 4);
+}
+
+template <bool BF, int PD>
+__global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict__ qkv, const bf16 *__restrict__ Wo,
+                                                          const float *__restrict__ bo, bf16 *__restrict__ xcopy,
+                                                          const float *__restrict__ res_in, float *__restrict__ res_out,
+                                                          float *__restrict__ stats_out, int S, float scale) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    auto g_off = [](int row, int c16) { return row * 64 + ((c16 ^ ((row >> 1) & 7)) << 3); };
+    auto v_off = [](int key, int c32) { return key * 64 + ((c32 ^ (((key >> 1) & 1) | (((key >> 3) & 1) << 1))) << 4); };
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.x;
+    const int64_t row_base = (int64_t)b * S;
+    const int n0 = wave * (AO_NJ * 16);
+
+    // ---- Wo fragments of the first PD K-steps: in flight under the whole of phase 1
+    const bf16 *w_lane = Wo + (int64_t)(n0 + fr) * AO_D + fq * 8;
+    bf16x8 wf[PD][AO_NJ];
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+#pragma unroll
+        for (int j = 0; j < AO_NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8 *>(w_lane + (int64_t)j * 16 * AO_D + s * 32);
+
+    // ---- phase 1: attention, a pair of heads per iteration
+    {
+        const int hh = t >> 8, u = t & 255;           // staging: head of the pair, chunk index inside the head
+        const int r0 = u >> 3, c16 = u & 7;           // rows r0 and r0 + 32, 16-byte chunk c16
+        const bf16 *src0 = qkv + (row_base + r0) * 3 * AO_D + hh * 64 + c16 * 8;
+        const bf16 *src1 = src0 + (int64_t)32 * 3 * AO_D;
+        const bool live0 = r0 < S, live1 = r0 + 32 < S;
+        bf16x8 rq[2], rk[2], rv[2];
+        auto fetch = [&](int p) {
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+            rq[0] = rk[0] = rv[0] = rq[1] = rk[1] = rv[1] = z;
+            if (live0) {
+                rq[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128);
+                rk[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + AO_D);
+                rv[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + 2 * AO_D);
+            }
+            if (live1) {
+                rq[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128);
+                rk[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D);
+                rv[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D);
+            }
+        };
+        fetch(0);
+        const int ah = wave >> 2, qt = wave & 3;      // attention: head of the pair, query tile
+        bf16 *const sK = reinterpret_cast<bf16 *>(smem + AO_SK) + ah * 4096;
+        bf16 *const sV = reinterpret_cast<bf16 *>(smem + AO_SV) + ah * 4096;
+        bf16 *const pt = reinterpret_cast<bf16 *>(smem + AO_SQ) + (ah * 4 + qt) * 1024;
+        bf16 *const stK = reinterpret_cast<bf16 *>(smem + AO_SK) + hh * 4096;
+        bf16 *const stV = reinterpret_cast<bf16 *>(smem + AO_SV) + hh * 4096;
+        bf16 *const stQ = reinterpret_cast<bf16 *>(smem + AO_SQ) + hh * 4096;  // 4 tiles x 16 rows = rows 0 .. 63 in g_off order
+        for (int p = 0; p < AO_H / 2; ++p) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int row = r0 + 32 * c;
+                // (a query tile's 16 rows are 2 KB of their own: tile row / 16, g_off on the row inside the tile -- the row's
+                //  swizzle term (row >> 1) & 7 is the same for row and row % 16)
+                *reinterpret_cast<bf16x8 *>(&stQ[(row >> 4) * 1024 + g_off(row & 15, c16)]) = rq[c];
+                *reinterpret_cast<bf16x8 *>(&stK[g_off(row, c16)]) = rk[c];
+                *reinterpret_cast<bf16x8 *>(&stV[v_off(row, c16 >> 1) + (c16 & 1) * 8]) = rv[c];
+            }
+            __syncthreads();
+            if (p + 1 < AO_H / 2) fetch(p + 1);
+            const int head = 2 * p + ah;
+            if (qt * 16 < S) {  // wave-uniform
+                bf16x8 kf[4][2], qf[2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8 *>(&sK[g_off(j * 16 + fr, ks * 4 + fq)]);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(&pt[g_off(fr, ks * 4 + fq)]);
+                f32x4 sc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], sc[j], 0, 0, 0);
+                }
+                // this lane holds scores[query = 16 qt + fr][key = 16 j + 4 fq + r]
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = j * 16 + fq * 4 + r;
+                        float v = sc[j][r] * scale;
+                        if (key >= S) v = -INFINITY;
+                        sc[j][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __expf(sc[j][r] - mx);
+                        sc[j][r] = e;
+                        sum += e;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.f / sum;
+                // P (bf16) over this tile's Q rows (its fragments are in registers)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16x4 pv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pv[r] = to_bf16(sc[j][r] * inv);
+                    *reinterpret_cast<bf16x4 *>(&pt[g_off(fr, j * 2 + (fq >> 1)) + (fq & 1) * 4]) = pv;
+                }
+                // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&pt[g_off(fr, ks * 4 + fq)]);
+                    const int kq = ks * 32 + 8 * fq + (fr >> 2), dp = (fr & 3) * 4;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        typedef __attribute__((ext_vector_type(4))) short s16x4;
+                        typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+                        typedef __attribute__((ext_vector_type(8))) short s16x8;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sV[v_off(kq, dt) + dp]));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sV[v_off(kq + 4, dt) + dp]));
+                        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, both), pa, o[dt], 0, 0, 0);
+                    }
+                }
+                // the tile into sO: row = query, k = head * 64 + d; a lane's 4 consecutive d are 8 bytes
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = to_bf16(o[dt][r]);
+                    const int k = head * 64 + dt * 16 + fq * 4;
+                    *reinterpret_cast<bf16x4 *>(smem + so_off(qt * 16 + fr, k & ~7) + (k & 4) * 2) = ov;
+                }
+            } else {  // no live query in this tile: rows nobody stores, kept finite
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x4 z;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = (bf16)0.f;
+                    const int k = head * 64 + dt * 16 + fq * 4;
+                    *reinterpret_cast<bf16x4 *>(smem + so_off(qt * 16 + fr, k & ~7) + (k & 4) * 2) = z;
+                }
+            }
+            __syncthreads();  // every wave is done with the pair's staging bytes (and, after the last pair, sO is whole)
+        }
+    }
+
+    // ---- phase 2: out = sO Wo^T + bo, K = 768 in 24 steps of 32; acc[i][j][r] = out[16 i + fr][n0 + 16 j + 4 fq + r]
+    f32x4 acc[4][AO_NJ];
+#pragma unroll
+    for (int j = 0; j < AO_NJ; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(bo + n0 + j * 16 + fq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = bv;
+    }
+    constexpr int NKS = AO_D / 32;
+    static_assert(NKS % PD == 0, "the Wo ring is indexed statically");
+    for (int ks0 = 0; ks0 < NKS; ks0 += PD) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            const int ks = ks0 + s;
+            bf16x8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + so_off(i * 16 + fr, ks * 32 + fq * 8));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < AO_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], a[i], acc[i][j], 0, 0, 0);
+            if (ks + PD < NKS) {
+#pragma unroll
+                for (int j = 0; j < AO_NJ; ++j)
+                    wf[s][j] = *reinterpret_cast<const bf16x8 *>(w_lane + (int64_t)j * 16 * AO_D + (ks + PD) * 32);
+            }
+        }
+    }
+
+    // ---- epilogue: + residual row, new row out (16 bytes a lane), partial LayerNorm sums of the row as stored
+    __syncthreads();  // every wave has read its last sO fragments: the bytes become staging
+    unsigned char *const wl = smem + wave * AO_ESTAGE;
+    float *const part = reinterpret_cast<float *>(smem + AO_EPART) + (int64_t)wave * 64 * 12 * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // chunk c = lane + 64 it of the block's 16 rows x 12 chunks of 8 columns
+        bf16x8 rb[3];
+        f32x4 rf[3][2];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
+            const int row = min(i * 16 + rl, S - 1);
+            const int64_t off = (row_base + row) * AO_D + n0 + cc * 8;
+            if constexpr (BF) {
+                rb[it] = *reinterpret_cast<const bf16x8 *>(xcopy + off);
+            } else {
+                rf[it][0] = *reinterpret_cast<const f32x4 *>(res_in + off);
+                rf[it][1] = *reinterpret_cast<const f32x4 *>(res_in + off + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AO_NJ; ++j) *reinterpret_cast<f32x4 *>(wl + fr * AO_EROW + j * 64 + fq * 16) = acc[i][j];
+        // (same wave writes and reads: LDS operations of a wave complete in order)
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
+            f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + rl * AO_EROW + cc * 32);
+            f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + rl * AO_EROW + cc * 32 + 16);
+            bf16x8 o;
+            float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (BF) {
+                    lo[r] += (float)rb[it][r];
+                    hi[r] += (float)rb[it][4 + r];
+                } else {
+                    lo[r] += rf[it][0][r];
+                    hi[r] += rf[it][1][r];
+                }
+                o[r] = to_bf16(lo[r]);
+                o[4 + r] = to_bf16(hi[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = BF ? (float)o[r] : lo[r], y = BF ? (float)o[4 + r] : hi[r];
+                ssum += x;
+                ssq += x * x;
+                ssum += y;
+                ssq += y * y;
+            }
+            const int row = i * 16 + rl;
+            if (row < S) {
+                const int64_t off = (row_base + row) * AO_D + n0 + cc * 8;
+                *reinterpret_cast<bf16x8 *>(xcopy + off) = o;
+                if constexpr (!BF) {
+                    *reinterpret_cast<f32x4 *>(res_out + off) = lo;
+                    *reinterpret_cast<f32x4 *>(res_out + off + 4) = hi;
+                }
+            }
+            part[(row * 12 + cc) * 2] = ssum;
+            part[(row * 12 + cc) * 2 + 1] = ssq;
+        }
+    }
+    __syncthreads();
+    if (t < 128) {  // row t & 63, column half t >> 6: its four waves in order, each wave's twelve chunks in order
+        const int row = t & 63, half = t >> 6;
+        if (row < S) {
+            float sm = 0.f, sq = 0.f;
+            const float *pp = reinterpret_cast<const float *>(smem + AO_EPART);
+            for (int w = half * 4; w < half * 4 + 4; ++w)
+                for (int cc = 0; cc < 12; ++cc) {
+                    sm += pp[((w * 64 + row) * 12 + cc) * 2];
+                    sq += pp[((w * 64 + row) * 12 + cc) * 2 + 1];
+                }
+            float *o = stats_out + ((row_base + row) * 2 + half) * 2;
+            o[0] = sm;
+            o[1] = sq;
+        }
+    }
+}
+
+int g_ao_pd = 3;
+
+template <bool BF, int PD>
+ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float *bo, bf16 *xcopy, const float *res_in,
+                     float *res_out, float *stats_out, int B, int S, float scale) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    SSW_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_outproj_image<BF, PD>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((attn_outproj_image<BF, PD>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in, res_out,
+                       stats_out, S, scale);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace
+
+bool attn_outproj_supports(int S, int D, int H) { return D == AO_D && H == AO_H && S >= 1 && S <= 64; }
+void tune_attn_outproj(int pd) { g_ao_pd = pd; }
+
+// qkv [B*S, 3*768] bf16; Wo [768, 768] bf16 (out x in); bo [768].  bf16 stream (res_in == nullptr): xcopy [B*S, 768] is read,
+// added to and written back in place.  f32 stream: res_in -> res_out f32 rows, xcopy receives the bf16 copy.
+// stats_out [B*S][2][2]: partial (sum, sum of squares) of the new row's columns [0, 384) and [384, 768).
+ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, const float *bo, void *xcopy,
+                               const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
+                               float scale) {
+    if (!attn_outproj_supports(S, D, H) || B < 1) {
+        set_error("attn_outproj: S=%d D=%d H=%d unsupported (ViT-B/32: S <= 64, D = 768, H = 12)", S, D, H);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    const bf16 *q = static_cast<const bf16 *>(qkv), *w = static_cast<const bf16 *>(Wo);
+    bf16 *x = static_cast<bf16 *>(xcopy);
+    const bool bf = res_in == nullptr;
+    if (g_ao_pd == 4)
+        return bf ? launch_ao<true, 4>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
+                  : launch_ao<false, 4>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
+    if (g_ao_pd == 2)
+        return bf ? launch_ao<true, 2>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
+                  : launch_ao<false, 2>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
+    return bf ? launch_ao<true, 3>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
+              : launch_ao<false, 3>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
+}
+
+}  // namespace ssw

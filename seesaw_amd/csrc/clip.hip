@@ -1215,8 +1215,9 @@ bool skinny_rows(int R, int D, int M) {
 }
 
 // ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's,
-// bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too
-int g_clip_flags = getenv("SSW_CLIP_F32_STREAM") ? 1 : 0;
+// bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
+// bit 3 = attention and out-projection as two launches (round 3's layer) where attn_out.hip's one launch applies
+int g_clip_flags = (getenv("SSW_CLIP_F32_STREAM") ? 1 : 0) | (getenv("SSW_CLIP_UNFUSED_ATTN") ? 8 : 0);
 bool unfused_ln_forced() {
     static const bool v = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
     return v;
@@ -1284,6 +1285,25 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         }
         const int n_heads = B * tw.H;
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
+        // round 4: attention + out-projection + residual + statistics of the image tower in one launch, a workgroup per
+        // image (attn_out.hip); the fc1 product then reads two partial pairs a row instead of D / 128
+        const bool fused_attn = !unfused_ln && D % 256 == 0 && !causal && (g_clip_flags & 8) == 0 &&
+                                attn_outproj_supports(S, D, tw.H);
+        if (fused_attn) {
+            if (bf16_stream) c->stream_in_xn = true;
+            SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
+                                        att_scale));
+            cons.stats_in = st_h2;
+            cons.c1 = ly.c1fc1;
+            cons.np_in = 2;
+            SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->xn, ly.w1_ln, ly.c2fc1, nullptr, c->h1, R, M, D, cons));
+            prod.stats_out = st_h;
+            if (bf16_stream)
+                SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_STREAM_STATS, s, c->h1, ly.w2, ly.b2, nullptr, nullptr, R, D, M, prod));
+            else
+                SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
+            continue;
+        }
         static const bool one_tile_waves = getenv("SSW_CLIP_ATTN_TPW1") != nullptr;  // A/B: the four-wave form
         // (one wave per pair with four tiles, attention_mfma<4, 4>: 21.6 us per layer against 17.1 -- measured, not kept)
         static const bool direct_env = getenv("SSW_CLIP_ATTN_DIRECT") != nullptr;  // A/B: fragments straight from memory

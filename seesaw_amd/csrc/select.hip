@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_hist(const float *__restrict__ values, 
 // one block of 1024 threads: find the bin that holds the kk-th largest element.
 template <int LEVEL>
 __global__ __launch_bounds__(1024) void k_pick(const uint32_t *__restrict__ hist,
-                                               uint32_t *__restrict__ state, int k) {
+                                               uint32_t *__restrict__ state, int k, uint32_t scale) {
     __shared__ uint32_t sums[1024];
     const int t = threadIdx.x;
     uint32_t kk = (uint32_t)k;  // LEVEL 0 (deep path): k is already the rank inside the prefix
@@ -210,12 +210,15 @@ __global__ __launch_bounds__(1024) void k_pick(const uint32_t *__restrict__ hist
             state[ST_B1] = b;
             state[ST_ABOVE1] = above;
             state[ST_CNT1] = cnt;
-            state[ST_MODE] = (above + cnt > (uint32_t)LEVEL2_FROM) ? 1u : 0u;
+            // `scale` = SAMPLE_R when the histogram is that of a sample: its counts stand for scale times as many values
+            // (a 12-bit prefix that holds 24 of the sample holds ~1536 of the values, not 24), so the decision is taken on
+            // the scaled count -- in sampled mode the second level always runs and the candidates stay near rank x scale
+            state[ST_MODE] = ((uint64_t)(above + cnt) * scale > (uint64_t)LEVEL2_FROM) ? 1u : 0u;
         } else {
             state[ST_B2] = b;
             state[ST_ABOVE2] = above;
             state[ST_CNT2] = cnt;
-            if (state[ST_ABOVE1] + above + cnt > (uint32_t)FINAL_CAP) state[ST_OVERFLOW] = 1u;
+            if ((uint64_t)(state[ST_ABOVE1] + above + cnt) * scale > (uint64_t)FINAL_CAP) state[ST_OVERFLOW] = 1u;
         }
     }
 }
@@ -721,6 +724,16 @@ static ssw_status final_lds_ready() {
     return SSW_OK;
 }
 
+// With an exchange target attached (ssw_index_set_exchange_target) k_final writes k keys -- and k best rows from slot
+// k_max on -- into the rank's message: a k beyond k_max would run over the count word and past the send buffer.
+static ssw_status exchange_fits(const SelectWorkspace &ws, int32_t k) {
+    if (ws.xchg.msg_out != nullptr && k > ws.xchg.k_max) {
+        set_error("topk: k=%d exceeds the exchange target's k_max=%d", k, ws.xchg.k_max);
+        return SSW_ERR_INVALID;
+    }
+    return SSW_OK;
+}
+
 ssw_status launch_select_small(SelectWorkspace &ws, const float *row_scores, const int64_t *row_start_or_null,
                                int64_t n_images, const int64_t *excl_ids_mapped, int64_t n_excl, int32_t k,
                                unsigned char *packed_mapped, unsigned seq, hipStream_t stream) {
@@ -728,6 +741,7 @@ ssw_status launch_select_small(SelectWorkspace &ws, const float *row_scores, con
         set_error("select_small: n_images=%lld k=%d outside the one-launch path", (long long)n_images, k);
         return SSW_ERR_INVALID;
     }
+    SSW_TRY(exchange_fits(ws, k));
     FinalExchange x = ws.xchg;
     x.values_all = row_scores;
     x.m_all = n_images;
@@ -757,6 +771,7 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
         set_error("topk: %lld images exceed the 32-bit id space of one shard", (long long)m);
         return SSW_ERR_UNSUPPORTED;
     }
+    SSW_TRY(exchange_fits(ws, k));
     const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
     unsigned char *packed = ws.host_packed ? ws.host_packed : ws.packed;
     FinalExchange xg = ws.xchg;
@@ -788,9 +803,9 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
     const int gs = sampled ? grid_for(m / sr, device) : g;
     xg.sampled = sampled ? 1 : 0;
     hipLaunchKernelGGL(k_hist<1>, dim3(gs), dim3(256), 0, stream, values, m, excl, ws.hist1, ws.state, sr);
-    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, rank);
+    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, rank, (uint32_t)sr);
     hipLaunchKernelGGL(k_hist<2>, dim3(gs), dim3(256), 0, stream, values, m, excl, ws.hist2, ws.state, sr);
-    hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, rank);
+    hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, stream, ws.hist2, ws.state, rank, (uint32_t)sr);
     hipLaunchKernelGGL(k_collect, dim3(g), dim3(256), 0, stream, values, m, excl, ws.state, ws.cand);
     SSW_TRY(final_lds_ready());
     hipLaunchKernelGGL(k_final, dim3(1), dim3(1024), FINAL_LDS_BYTES, stream, ws.cand,
@@ -804,6 +819,11 @@ ssw_status launch_select_topk(SelectWorkspace &ws, const float *values, int64_t 
 ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int64_t m,
                                    const uint32_t *best_rows_or_null, int32_t k, int device,
                                    hipStream_t stream) {
+    if (k < 1 || k > SSW_MAX_TOPK) {
+        set_error("topk: k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+        return SSW_ERR_INVALID;
+    }
+    SSW_TRY(exchange_fits(ws, k));
     const uint32_t *excl = ws.excl_dirty ? ws.excl_bits : nullptr;
     const int g = grid_for(m, device);
     static const int digit_shift[6] = {52, 40, 32, 20, 8, 0};
@@ -817,7 +837,7 @@ ssw_status launch_select_topk_deep(SelectWorkspace &ws, const float *values, int
         hipLaunchKernelGGL(k_hist_deep, dim3(g), dim3(256), 0, stream, values, m, excl, ws.hist1,
                            prefix, prefix_shift, digit_shift[lvl],
                            (uint32_t)((1u << digit_bits[lvl]) - 1u));
-        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, (int)kk);
+        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, stream, ws.hist1, ws.state, (int)kk, 1u);
         SSW_HIP_TRY(hipGetLastError());
         uint32_t st[ST_WORDS];
         SSW_HIP_TRY(hipMemcpyAsync(st, ws.state, sizeof(st), hipMemcpyDeviceToHost, stream));

@@ -141,6 +141,12 @@ struct GemmLn {
 };
 ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K, const GemmLn &ln);
+// attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image
+bool attn_outproj_supports(int S, int D, int H);
+void tune_attn_outproj(int prefetch_depth);
+ssw_status launch_attn_outproj(hipStream_t stream, const void *qkv, const void *Wo, const float *bo, void *xcopy,
+                               const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
+                               float scale);
 // gemm_pw4.hip: the persistent four-wave kernel (256 x bn tiles, bn = 256 / 192 / 128, 0 = choose); N % 128, K % 128
 bool gemm_pw4_supports(int M, int N, int K);
 void gemm_pw4_set_mode(int mode);  // diagnostics of tools/perf_gemm.py (0 = the kernel)

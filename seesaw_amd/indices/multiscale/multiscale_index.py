@@ -429,6 +429,12 @@ class BoxFeedbackQuery(InteractiveQuery):
                         iou = np.where(inter > 0, inter / union, 0.0)
                     miou = iou.max(axis=1)
                 hit = cache[key] = (rows, miou)
+                # one live entry per (image, description): the entry under the image's previous stamp can never hit again
+                latest = self.__dict__.setdefault("_match_latest", {})
+                old = latest.get((int(dbidx), target_description))
+                if old is not None and old != key:
+                    cache.pop(old, None)
+                latest[(int(dbidx), target_description)] = key
             rows_all.append(hit[0])
             iou_all.append(hit[1])
         if not rows_all:

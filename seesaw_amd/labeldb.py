@@ -23,9 +23,14 @@ class LabelDB:
         self._serial = 0
 
     def put(self, dbidx: int, boxes: Optional[List[Box]]):
-        self.ldata[int(dbidx)] = boxes
-        self._serial += 1
-        self.stamp[int(dbidx)] = self._serial
+        dbidx = int(dbidx)
+        # the web protocol (Session.update_state) writes every image of every batch again each round: an unchanged
+        # label keeps its stamp, so whatever is cached per (image, stamp) -- the index's matched-tile table -- still hits
+        unchanged = dbidx in self.ldata and self.ldata[dbidx] == boxes and (self.ldata[dbidx] is None) == (boxes is None)
+        self.ldata[dbidx] = boxes
+        if not unchanged:
+            self._serial += 1
+            self.stamp[dbidx] = self._serial
 
     def get_seen(self) -> BitMap:
         return BitMap(self.ldata.keys())

@@ -60,9 +60,11 @@ class Session:
     def action_log(self):
         """the reference's list of LogEntry (seesaw_session.py:56-62), materialised on demand: five pydantic objects a
         round were a tenth of a `plain` round at LVIS-subset size"""
-        return [e if not isinstance(e, tuple) else
-                LogEntry.model_construct(logger="server", time=e[0], message=e[1], seen=e[2], accepted=e[3])
-                for e in self._log_raw]
+        raw = self._log_raw  # materialised in place and returned itself: a client's `session.action_log.append(...)` stays
+        for i, e in enumerate(raw):
+            if isinstance(e, tuple):
+                raw[i] = LogEntry.model_construct(logger="server", time=e[0], message=e[1], seen=e[2], accepted=e[3])
+        return raw
 
     @action_log.setter
     def action_log(self, entries):  # update_state: the client hands the log back with its own entries in it
@@ -94,7 +96,12 @@ class Session:
         """take the client's view of the session (labels drawn on the returned images) as the new truth"""
         self._update_labeldb(state)
         self._log("update_state.end")
-        if self._check_reversals():
+        reversal = self._check_reversals()
+        # update_last_batch() keeps this state incrementally; a session may mix both entry points (a client un-accepting
+        # an earlier image goes through here), so the full walk refreshes it
+        shown = [int(i) for b in self.acc_indices for i in np.asarray(b).reshape(-1)]
+        self._rev = [any(i not in self.accepted for i in shown), reversal or self._reversal_ignoring_totals(shown)]
+        if reversal:
             self.loop.set_reversals()
 
     # ---- the last batch only ---------------------------------------------------------------------------------
@@ -134,6 +141,17 @@ class Session:
         self._log("update_state.end")
         if self.__dict__.get("_rev", [False, False])[1] and len(accepted) != 0 and len(accepted) != len(seen):
             self.loop.set_reversals()
+
+    def _reversal_ignoring_totals(self, shown):
+        """an accepted image shown after a rejected one, without _check_reversals()'s all / none shortcuts (those are
+        re-applied by update_last_batch each round, on the totals of that round)"""
+        rejected_before = False
+        for i in shown:
+            if i not in self.accepted:
+                rejected_before = True
+            elif rejected_before:
+                return True
+        return False
 
     def _check_reversals(self):
         """a reversal = some rejected image shown before an accepted one."""

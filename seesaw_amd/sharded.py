@@ -138,6 +138,8 @@ class ShardedTopK:
         unpacked by the merge kernel) -> (out_keys, out_count).  Two launches + one collective, nothing else."""
         torch = self.torch
         assert getattr(self, "_attached", None) is not None, "attach(dev_index) first"
+        if not 1 <= k <= self.k_max:
+            raise ValueError(f"k={k} outside [1, k_max={self.k_max}] of this exchange")
         stream_ptr = torch.cuda.current_stream().cuda_stream
         if getattr(self, "_comm", None):
             _lib.call("ssw_topk_allgather", self._comm, ctypes.c_void_p(stream_ptr), ctypes.c_void_p(self.send_buf.data_ptr()),
@@ -266,6 +268,8 @@ class ShardedSyntheticIndex:
     def topk_async(self, q_dev_ptr: int, k: int):
         """scan + local select + all-gather + merge, all enqueued on the current stream.  The overflow flags
         travel with the message; check `xchg.assert_no_overflow_seen()` after synchronising."""
+        if not 1 <= k <= self.xchg.k_max:  # ahead of the selection, which writes k words of the message
+            raise ValueError(f"k={k} outside [1, k_max={self.xchg.k_max}] of this index's exchange")
         self.local.topk_dev(q_dev_ptr, k)
         return self.xchg.exchange_fused(k)
 

@@ -144,3 +144,38 @@ def test_sampled_threshold_selection_is_exact(DeviceIndex, shape):
     finally:
         _lib.call("ssw_tune_topk", 3)
         idx.close()
+
+
+def test_sampled_threshold_at_the_bottom_of_a_level1_bin_takes_level2(DeviceIndex):
+    """in sampled mode (m >= 2^24) the level-2 decision was taken on the SAMPLE's counts, which stand for 64
+    times as many values.  Here ~19 000 values fill one 12-bit bin above everything else: the sample holds ~300 of them
+    (below the 1024 that used to trigger level 2), so the 12-bit prefix alone collected all 19 000 -- beyond the 8192
+    the final selection takes: overflow word raised, deep rerun on every query.  With the decision on the scaled count
+    the second level runs, a few thousand candidates come out and nothing overflows."""
+    import torch
+    from seesaw_amd.sharded import _DevArray
+    n = (1 << 24) + 4097
+    free, _total = torch.cuda.mem_get_info(0)
+    if free < n * 2048 + (8 << 30):
+        pytest.skip("needs 40 GB of device memory")
+    rng = np.random.default_rng(5)
+    s = (rng.random(n) * 0.12).astype(np.float32)                       # bins below
+    top = rng.choice(n, 19000, replace=False)
+    s[top] = (0.125 + rng.random(19000) * 0.015).astype(np.float32)     # inside the bin [0.125, 0.140625)
+    idx = DeviceIndex.synthetic(n, 512, seed=1)
+    try:
+        idx.load_scores(s)
+        _, count_ptr, _ = idx.result_ptrs()
+        count = torch.as_tensor(_DevArray(count_ptr, (2,), "<i4"), device=torch.device("cuda", 0))
+        for k in (50, 100, 1024):
+            idx.topk_dev(0, k)
+            idx.sync()
+            c, ovf = (int(v) for v in count.cpu())
+            assert (c, ovf) == (k, 0), (k, c, ovf)
+            imgs, scores, _ = idx.topk_fetch(k)
+            part = np.argpartition(-s, k + 64)[: k + 64]
+            order = part[np.lexsort((part, -s[part]))][:k]
+            assert np.array_equal(imgs, order)
+            assert np.array_equal(bits(scores), bits(s[order]))
+    finally:
+        idx.close()

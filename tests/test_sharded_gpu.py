@@ -239,3 +239,36 @@ def test_bench_with_two_ranks_on_one_gpu_returns_the_single_gpu_answer():
     a, b = line(one.stdout), line(two.stdout)
     assert b["n_gpus"] == 2 and b["config"]["rows_per_gpu"] == 1500000
     assert a["top1"] == b["top1"], (a["top1"], b["top1"])
+
+
+def test_k_beyond_the_exchange_targets_k_max_is_refused_and_writes_nothing():
+    """with an exchange target attached the selection's last kernel writes k words of the message; k > k_max
+    used to run over the count word and past send_buf before the merge reported it.  Now the selection itself refuses
+    (all three forms: one-launch small index, histogram path, deep path) and the buffers stay as they were."""
+    import torch
+    from oracle import seesaw_oracle as orc
+    from seesaw_amd import _lib
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.sharded import ShardedTopK
+    dev = torch.device("cuda", 0)
+    q_dev = torch.from_numpy(orc.synth_query(6)).cuda()
+    for n in (3000, 40000):  # one-launch form / histogram form
+        idx = DeviceIndex.synthetic(n, 512, seed=3)
+        idx.set_stream(torch.cuda.current_stream().cuda_stream)
+        x = ShardedTopK(rank=0, world=1, device=dev, image_offset=0, k_max=16, with_best=True)
+        guard = torch.full((x.msg_len + 64,), 0x5A5A5A5A, dtype=torch.int64, device=dev)
+        x.send_buf = guard[:x.msg_len]  # the message sits inside a larger buffer whose tail must stay untouched
+        x.attach(idx)
+        idx.topk_dev(q_dev.data_ptr(), 16)
+        torch.cuda.synchronize()
+        before = guard.clone()
+        assert int(before[x.msg_len - 1].item()) & 0xFFFFFFFF == 16
+        with pytest.raises(_lib.SeesawHipError, match="k_max"):
+            idx.topk_dev(q_dev.data_ptr(), 17)
+        with pytest.raises(_lib.SeesawHipError, match="k_max"):
+            idx.select_deep_dev(17)
+        with pytest.raises(ValueError, match="k_max"):
+            x.exchange_fused(17)
+        torch.cuda.synchronize()
+        assert torch.equal(guard, before)
+        idx.close()
