@@ -17,6 +17,7 @@
 // Replaces, like the kernels it fuses, the attention + out_proj of transformers' CLIPEncoderLayer that the reference
 // calls through HGFaceWrapper.forward (seesaw/models/model.py:50-57).
 #include "ssw_common.h"
+#include <cstdlib>
 
 namespace ssw {
 namespace {
@@ -47,7 +48,12 @@ __device__ __forceinline__ int so_off(int row, int k0) {
     return row * AO_ROWB + (b & ~255) + ((((b >> 4) & 15) ^ (row & 15)) << 4);
 }
 
-template <bool BF, int PD>
+// diagnostic build of the kernel (SSW_AO_STAMPS=1): s_memtime at the phase boundaries, wave 0 of every workgroup
+__device__ unsigned long long g_ao_stamps[1024 * 8];
+#define AO_STAMP(slot)                                                                                   \
+    if (STAMP && t == 0 && blockIdx.x < 1024) g_ao_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+
+template <bool BF, int PD, bool STAMP = false>
 __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict__ qkv, const bf16 *__restrict__ Wo,
                                                           const float *__restrict__ bo, bf16 *__restrict__ xcopy,
                                                           const float *__restrict__ res_in, float *__restrict__ res_out,
@@ -61,40 +67,44 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
     const int b = blockIdx.x;
     const int64_t row_base = (int64_t)b * S;
     const int n0 = wave * (AO_NJ * 16);
+    AO_STAMP(0)
 
-    // ---- Wo fragments of the first PD K-steps: in flight under the whole of phase 1
-    const bf16 *w_lane = Wo + (int64_t)(n0 + fr) * AO_D + fq * 8;
-    bf16x8 wf[PD][AO_NJ];
+    // ---- Wo fragments of the first PD K-steps (64 deep), in flight under phase 1.  Wo arrives PACKED (pack_wo below):
+    // the 1 KB a wave-instruction loads for one fragment is contiguous in lane order -- 8 whole 128-byte lines.  Straight
+    // from the [out][in] matrix a fragment is 16 rows x 64 B, and the CU's L1 took 58 k cycles to look up the 18 k
+    // half-lines of a workgroup's 1.18 MB (20 B per clock; in-kernel stamps), three times what the MFMAs need.
+    const bf16 *w_lane = Wo + ((int64_t)wave * (AO_D / 64) * AO_NJ * 2 * 64 + lane) * 8;
+    constexpr int W_STEP = AO_NJ * 2 * 64 * 8;  // elements per (wave, K-step)
+    bf16x8 wf[PD][AO_NJ][2];
 #pragma unroll
     for (int s = 0; s < PD; ++s)
 #pragma unroll
-        for (int j = 0; j < AO_NJ; ++j) wf[s][j] = *reinterpret_cast<const bf16x8 *>(w_lane + (int64_t)j * 16 * AO_D + s * 32);
+        for (int j = 0; j < AO_NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) wf[s][j][h] = *reinterpret_cast<const bf16x8 *>(w_lane + s * W_STEP + (j * 2 + h) * 512);
 
     // ---- phase 1: attention, a pair of heads per iteration
     {
         const int hh = t >> 8, u = t & 255;           // staging: head of the pair, chunk index inside the head
         const int r0 = u >> 3, c16 = u & 7;           // rows r0 and r0 + 32, 16-byte chunk c16
-        const bf16 *src0 = qkv + (row_base + r0) * 3 * AO_D + hh * 64 + c16 * 8;
-        const bf16 *src1 = src0 + (int64_t)32 * 3 * AO_D;
-        const bool live0 = r0 < S, live1 = r0 + 32 < S;
-        bf16x8 rq[2], rk[2], rv[2];
+        // rows beyond S read row S - 1: finite numbers that never reach a stored value (as keys they are masked, their
+        // probabilities are exactly 0; as queries their rows are not stored)
+        const bf16 *src0 = qkv + (row_base + min(r0, S - 1)) * 3 * AO_D + hh * 64 + c16 * 8;
+        const bf16 *src1 = qkv + (row_base + min(r0 + 32, S - 1)) * 3 * AO_D + hh * 64 + c16 * 8;
+        // A CU takes in ~11 B per clock with one pair (48 KB) in flight -- 38 k cycles for the image's 288 KB in a first
+        // version; four pairs are requested up front, the other two as register sets come free
+        bf16x8 rr[AO_H / 2][6];
         auto fetch = [&](int p) {
-            bf16x8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
-            rq[0] = rk[0] = rv[0] = rq[1] = rk[1] = rv[1] = z;
-            if (live0) {
-                rq[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128);
-                rk[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + AO_D);
-                rv[0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + 2 * AO_D);
-            }
-            if (live1) {
-                rq[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128);
-                rk[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D);
-                rv[1] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D);
-            }
+            rr[p][0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128);
+            rr[p][1] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + AO_D);
+            rr[p][2] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + 2 * AO_D);
+            rr[p][3] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128);
+            rr[p][4] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D);
+            rr[p][5] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D);
         };
-        fetch(0);
+        constexpr int AHEAD = 4;
+#pragma unroll
+        for (int p = 0; p < AHEAD; ++p) fetch(p);
         const int ah = wave >> 2, qt = wave & 3;      // attention: head of the pair, query tile
         bf16 *const sK = reinterpret_cast<bf16 *>(smem + AO_SK) + ah * 4096;
         bf16 *const sV = reinterpret_cast<bf16 *>(smem + AO_SV) + ah * 4096;
@@ -102,18 +112,19 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
         bf16 *const stK = reinterpret_cast<bf16 *>(smem + AO_SK) + hh * 4096;
         bf16 *const stV = reinterpret_cast<bf16 *>(smem + AO_SV) + hh * 4096;
         bf16 *const stQ = reinterpret_cast<bf16 *>(smem + AO_SQ) + hh * 4096;  // 4 tiles x 16 rows = rows 0 .. 63 in g_off order
+#pragma unroll
         for (int p = 0; p < AO_H / 2; ++p) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int row = r0 + 32 * c;
                 // (a query tile's 16 rows are 2 KB of their own: tile row / 16, g_off on the row inside the tile -- the row's
                 //  swizzle term (row >> 1) & 7 is the same for row and row % 16)
-                *reinterpret_cast<bf16x8 *>(&stQ[(row >> 4) * 1024 + g_off(row & 15, c16)]) = rq[c];
-                *reinterpret_cast<bf16x8 *>(&stK[g_off(row, c16)]) = rk[c];
-                *reinterpret_cast<bf16x8 *>(&stV[v_off(row, c16 >> 1) + (c16 & 1) * 8]) = rv[c];
+                *reinterpret_cast<bf16x8 *>(&stQ[(row >> 4) * 1024 + g_off(row & 15, c16)]) = rr[p][3 * c];
+                *reinterpret_cast<bf16x8 *>(&stK[g_off(row, c16)]) = rr[p][3 * c + 1];
+                *reinterpret_cast<bf16x8 *>(&stV[v_off(row, c16 >> 1) + (c16 & 1) * 8]) = rr[p][3 * c + 2];
             }
             __syncthreads();
-            if (p + 1 < AO_H / 2) fetch(p + 1);
+            if (p + AHEAD < AO_H / 2) fetch(p + AHEAD);
             const int head = 2 * p + ah;
             if (qt * 16 < S) {  // wave-uniform
                 bf16x8 kf[4][2], qf[2];
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
         }
     }
 
+    AO_STAMP(1)
     // ---- phase 2: out = sO Wo^T + bo, K = 768 in 24 steps of 32; acc[i][j][r] = out[16 i + fr][n0 + 16 j + 4 fq + r]
     f32x4 acc[4][AO_NJ];
 #pragma unroll
@@ -214,27 +226,47 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = bv;
     }
-    constexpr int NKS = AO_D / 32;
+    // bf16 stream: the image's residual rows (this wave's 96 columns: 12 chunks of 16 bytes a lane) are requested now and
+    // used behind the K loop -- requested there, 16 rows at a time, they were four exposed round trips (7.5 us of stores
+    // phase in a first version)
+    bf16x8 rb[4][3];
+    if constexpr (BF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
+                rb[i][it] = *reinterpret_cast<const bf16x8 *>(xcopy + (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8);
+            }
+    }
+    constexpr int NKS = AO_D / 64;
     static_assert(NKS % PD == 0, "the Wo ring is indexed statically");
     for (int ks0 = 0; ks0 < NKS; ks0 += PD) {
 #pragma unroll
         for (int s = 0; s < PD; ++s) {
             const int ks = ks0 + s;
-            bf16x8 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + so_off(i * 16 + fr, ks * 32 + fq * 8));
+            for (int h = 0; h < 2; ++h) {  // k ascends in steps of 32 as in the tile GEMM
+                bf16x8 a[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + so_off(i * 16 + fr, ks * 64 + h * 32 + fq * 8));
 #pragma unroll
-                for (int j = 0; j < AO_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < AO_NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][j][h], a[i], acc[i][j], 0, 0, 0);
+            }
             if (ks + PD < NKS) {
 #pragma unroll
                 for (int j = 0; j < AO_NJ; ++j)
-                    wf[s][j] = *reinterpret_cast<const bf16x8 *>(w_lane + (int64_t)j * 16 * AO_D + (ks + PD) * 32);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        wf[s][j][h] = *reinterpret_cast<const bf16x8 *>(w_lane + (ks + PD) * W_STEP + (j * 2 + h) * 512);
             }
         }
     }
 
+    AO_STAMP(2)
     // ---- epilogue: + residual row, new row out (16 bytes a lane), partial LayerNorm sums of the row as stored
     __syncthreads();  // every wave has read its last sO fragments: the bytes become staging
     unsigned char *const wl = smem + wave * AO_ESTAGE;
@@ -242,16 +274,12 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         // chunk c = lane + 64 it of the block's 16 rows x 12 chunks of 8 columns
-        bf16x8 rb[3];
         f32x4 rf[3][2];
+        if constexpr (!BF) {
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
-            const int row = min(i * 16 + rl, S - 1);
-            const int64_t off = (row_base + row) * AO_D + n0 + cc * 8;
-            if constexpr (BF) {
-                rb[it] = *reinterpret_cast<const bf16x8 *>(xcopy + off);
-            } else {
+            for (int it = 0; it < 3; ++it) {
+                const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
+                const int64_t off = (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8;
                 rf[it][0] = *reinterpret_cast<const f32x4 *>(res_in + off);
                 rf[it][1] = *reinterpret_cast<const f32x4 *>(res_in + off + 4);
             }
@@ -269,8 +297,8 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (BF) {
-                    lo[r] += (float)rb[it][r];
-                    hi[r] += (float)rb[it][4 + r];
+                    lo[r] += (float)rb[i][it][r];
+                    hi[r] += (float)rb[i][it][4 + r];
                 } else {
                     lo[r] += rf[it][0][r];
                     hi[r] += rf[it][1][r];
@@ -299,25 +327,43 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
             part[(row * 12 + cc) * 2 + 1] = ssq;
         }
     }
+    AO_STAMP(3)
     __syncthreads();
-    if (t < 128) {  // row t & 63, column half t >> 6: its four waves in order, each wave's twelve chunks in order
-        const int row = t & 63, half = t >> 6;
-        if (row < S) {
-            float sm = 0.f, sq = 0.f;
-            const float *pp = reinterpret_cast<const float *>(smem + AO_EPART);
-            for (int w = half * 4; w < half * 4 + 4; ++w)
-                for (int cc = 0; cc < 12; ++cc) {
-                    sm += pp[((w * 64 + row) * 12 + cc) * 2];
-                    sq += pp[((w * 64 + row) * 12 + cc) * 2 + 1];
-                }
+    {   // (row, column half) = t >> 2: lane t & 3 adds one wave's twelve chunks in order, then the four waves pair up
+        const int pair = t >> 2, sub = t & 3, row = pair & 63, half = pair >> 6;
+        const float *pp = reinterpret_cast<const float *>(smem + AO_EPART) + (int64_t)((half * 4 + sub) * 64 + row) * 24;
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 12; ++cc) {
+            sm += pp[cc * 2];
+            sq += pp[cc * 2 + 1];
+        }
+        sm += __shfl_xor(sm, 1, 64);
+        sq += __shfl_xor(sq, 1, 64);
+        sm += __shfl_xor(sm, 2, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        if (sub == 0 && row < S) {
             float *o = stats_out + ((row_base + row) * 2 + half) * 2;
             o[0] = sm;
             o[1] = sq;
         }
     }
+    AO_STAMP(4)
 }
 
-int g_ao_pd = 3;
+// Wo [768][768] (out x in) -> the order the product's waves load it in: fragment (wave w, K-step ks of 64, column tile j,
+// half h) is 1 KB, lane (fr, fq) holding Wo[96 w + 16 j + fr][64 ks + 32 h + 8 fq ..+8]
+__global__ void k_pack_wo(const bf16 *__restrict__ Wo, bf16 *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte chunk
+    if (idx >= AO_D * AO_D / 8) return;
+    const int lane = idx & 63, f = idx >> 6;
+    const int h = f & 1, j = (f >> 1) % AO_NJ, ks = (f / (2 * AO_NJ)) % (AO_D / 64), w = f / (2 * AO_NJ * (AO_D / 64));
+    const int fr = lane & 15, fq = lane >> 4;
+    *reinterpret_cast<bf16x8 *>(out + (int64_t)idx * 8) =
+        *reinterpret_cast<const bf16x8 *>(Wo + (int64_t)(w * 96 + j * 16 + fr) * AO_D + ks * 64 + h * 32 + fq * 8);
+}
+
+int g_ao_pd = getenv("SSW_AO_PD") ? atoi(getenv("SSW_AO_PD")) : 1;
 
 template <bool BF, int PD>
 ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float *bo, bf16 *xcopy, const float *res_in,
@@ -330,6 +376,15 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
                                         hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
+    static const bool stamps = getenv("SSW_AO_STAMPS") != nullptr;
+    if (stamps) {
+        SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_outproj_image<BF, PD, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
+        hipLaunchKernelGGL((attn_outproj_image<BF, PD, true>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in,
+                           res_out, stats_out, S, scale);
+        SSW_HIP_TRY(hipGetLastError());
+        return SSW_OK;
+    }
     hipLaunchKernelGGL((attn_outproj_image<BF, PD>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in, res_out,
                        stats_out, S, scale);
     SSW_HIP_TRY(hipGetLastError());
@@ -338,10 +393,19 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
 
 }  // namespace
 
+ssw_status read_ao_stamps(uint64_t *out, int n_words) {
+    SSW_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ao_stamps), (size_t)n_words * 8));
+    return SSW_OK;
+}
+ssw_status pack_attn_outproj_weight(hipStream_t s, const void *Wo, void *out) {
+    hipLaunchKernelGGL(k_pack_wo, dim3(AO_D * AO_D / 8 / 256), dim3(256), 0, s, static_cast<const bf16 *>(Wo), static_cast<bf16 *>(out));
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
 bool attn_outproj_supports(int S, int D, int H) { return D == AO_D && H == AO_H && S >= 1 && S <= 64; }
 void tune_attn_outproj(int pd) { g_ao_pd = pd; }
 
-// qkv [B*S, 3*768] bf16; Wo [768, 768] bf16 (out x in); bo [768].  bf16 stream (res_in == nullptr): xcopy [B*S, 768] is read,
+// qkv [B*S, 3*768] bf16; Wo: the [768, 768] out-projection weight PACKED by pack_attn_outproj_weight; bo [768].  bf16 stream (res_in == nullptr): xcopy [B*S, 768] is read,
 // added to and written back in place.  f32 stream: res_in -> res_out f32 rows, xcopy receives the bf16 copy.
 // stats_out [B*S][2][2]: partial (sum, sum of squares) of the new row's columns [0, 384) and [384, 768).
 ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, const float *bo, void *xcopy,
@@ -354,14 +418,16 @@ ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, c
     const bf16 *q = static_cast<const bf16 *>(qkv), *w = static_cast<const bf16 *>(Wo);
     bf16 *x = static_cast<bf16 *>(xcopy);
     const bool bf = res_in == nullptr;
-    if (g_ao_pd == 4)
-        return bf ? launch_ao<true, 4>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
-                  : launch_ao<false, 4>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
-    if (g_ao_pd == 2)
-        return bf ? launch_ao<true, 2>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
-                  : launch_ao<false, 2>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
-    return bf ? launch_ao<true, 3>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
-              : launch_ao<false, 3>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
+    (void)g_ao_pd;  // (two K-steps of fragments ahead spill at the 256 registers of an eight-wave workgroup, and one is enough:
+                    //  the product waits for the L1's fill rate, not for latency -- 27 k cycles either way)
+    return bf ? launch_ao<true, 1>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
+              : launch_ao<false, 1>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
 }
 
 }  // namespace ssw
+
+// stamps of the last SSW_AO_STAMPS=1 launch: out[wg * 8 + slot], slots 0..4 = start, after attention, after the product,
+// after the stores, end (shader clock)
+extern "C" int ssw_debug_attn_out_stamps(uint64_t *out, int n_words) {
+    return ssw::read_ao_stamps(out, n_words);
+}

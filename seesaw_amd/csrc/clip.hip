@@ -994,6 +994,7 @@ struct Layer {
     // LayerNorm folded into the tile path's QKV / fc1 products (GemmLn, ssw_common.h): W' = gamma (.) W in bf16,
     // c1_n = sum_k W'_nk, c2_n = sum_k beta_k W_nk + b_n
     bf16 *wqkv_ln = nullptr, *w1_ln = nullptr;
+    bf16 *wo_pk = nullptr;  // wo in the fragment order of attn_out.hip (ViT-B/32 shapes only)
     float *c1qkv = nullptr, *c2qkv = nullptr, *c1fc1 = nullptr, *c2fc1 = nullptr;
 };
 
@@ -1128,6 +1129,11 @@ ssw_status load_tower(ssw_clip *c, Tower &tw, const float *&cur, const float *en
         SSW_TRY(upload_f32(c, bc, bc + b.size(), b.size(), &ly.bqkv));
         SSW_TRY(fold_layernorm(c, w.data(), ln1w_h, ln1b_h, b.data(), 3 * D, D, &ly.wqkv_ln, &ly.c1qkv, &ly.c2qkv, scratch));
         SSW_TRY(upload_bf16(c, cur, end, D * D, &ly.wo, scratch));
+        if (attn_outproj_supports(1, (int)D, tw.H)) {
+            SSW_TRY(dmalloc(c, (void **)&ly.wo_pk, D * D * sizeof(bf16)));
+            SSW_TRY(pack_attn_outproj_weight(0, ly.wo, ly.wo_pk));
+            SSW_HIP_TRY(hipDeviceSynchronize());
+        }
         SSW_TRY(upload_f32(c, cur, end, D, &ly.bo));
         const float *ln2w_h = cur, *ln2b_h = cur + D;
         SSW_TRY(upload_f32(c, cur, end, D, &ly.ln2w));
@@ -1288,10 +1294,10 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         // round 4: attention + out-projection + residual + statistics of the image tower in one launch, a workgroup per
         // image (attn_out.hip); the fc1 product then reads two partial pairs a row instead of D / 128
         const bool fused_attn = !unfused_ln && D % 256 == 0 && !causal && (g_clip_flags & 8) == 0 &&
-                                attn_outproj_supports(S, D, tw.H);
+                                attn_outproj_supports(S, D, tw.H) && ly.wo_pk != nullptr;
         if (fused_attn) {
             if (bf16_stream) c->stream_in_xn = true;
-            SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
+            SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo_pk, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
                                         att_scale));
             cons.stats_in = st_h2;
             cons.c1 = ly.c1fc1;

@@ -144,6 +144,7 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const
 // attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image
 bool attn_outproj_supports(int S, int D, int H);
 void tune_attn_outproj(int prefetch_depth);
+ssw_status pack_attn_outproj_weight(hipStream_t stream, const void *Wo_768x768, void *out_same_size);
 ssw_status launch_attn_outproj(hipStream_t stream, const void *qkv, const void *Wo, const float *bo, void *xcopy,
                                const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
                                float scale);

@@ -1,0 +1,21 @@
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from seesaw_amd.models.clip import ClipModel
+from seesaw_amd import _lib
+m = ClipModel.random_init(seed=1234)
+B = 200
+x = torch.randn(B, 3, 224, 224, device="cuda")
+out = torch.empty(B, 512, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    m.embed_image_dev(x.data_ptr(), B, out.data_ptr(), True, s)
+torch.cuda.synchronize()
+lib = _lib.load()
+buf = np.zeros(1024 * 8, dtype=np.uint64)
+lib.ssw_debug_attn_out_stamps(buf.ctypes.data_as(ctypes.c_void_p), 1024 * 8)
+st = buf.reshape(1024, 8)[:B, :5].astype(np.int64)
+d = np.diff(st, axis=1)
+print("median cycles per phase [attention, product, stores, stats]:", np.median(d, axis=0), "total", np.median(st[:, 4] - st[:, 0]))
+print("p10/p90 total", np.percentile(st[:, 4] - st[:, 0], [10, 90]))
+print("start spread (cycles)", st[:, 0].max() - st[:, 0].min(), "end spread", st[:, 4].max() - st[:, 4].min(), "launch span", st[:, 4].max() - st[:, 0].min())
