@@ -338,6 +338,18 @@ def clip_extras(device: int):
     for _ in range(20):
         m.embed_text(one)
     dt1 = (time.perf_counter() - t0) / 20
+    # the other residual-row form (ssw_clip_set_option): bf16 rows -- faster, 4x the score error; the
+    # headline figures above are the default f32 rows
+    m.set_rows(image_bf16=True)
+    for _ in range(2):
+        m.embed_image_dev(x.data_ptr(), B, o.data_ptr(), True, s)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.embed_image_dev(x.data_ptr(), B, o.data_ptr(), True, s)
+    torch.cuda.synchronize(dev)
+    dtb = (time.perf_counter() - t0) / n
+    m.set_rows()
     m.close()
     # CPU side by side: the in-container transformers.CLIPModel, f32, torch-CPU,
     # all host threads, same random-init weights, on a bounded sample of 16 tiles
@@ -354,7 +366,10 @@ def clip_extras(device: int):
            "seconds": dtc}
     return {"cpu_baseline": cpu, "image_batch": B, "image_ms_per_batch": dt * 1e3, "tiles_per_s": B / dt, "tflops": tf,
             "mfma_peak_tflops": 2500.0, "frac_of_bf16_dense_peak": tf / 2500.0,
-            "residual_rows": "bf16 in the image tower's tile path (ssw_tune_clip), f32 in the text tower",
+            "residual_rows": "f32 in both towers (the default; SURVEY 8 a-12's arithmetic)",
+            "image_bf16_rows": {"ms_per_batch": dtb * 1e3, "tiles_per_s": B / dtb, "tflops": B * 8.818 / dtb / 1e3,
+                                "frac_of_bf16_dense_peak": B * 8.818 / dtb / 1e3 / 2500.0,
+                                "note": "ssw_clip_set_option(SSW_CLIP_OPT_IMAGE_ROWS_BF16): max |score delta| 1.5e-3 against 4e-4 with f32 rows"},
             "image_batch_400": bigger[400], "image_batch_1024": bigger[1024],
             "text_batch": 16, "text_len": 77, "text_ms_per_batch_host_io": dtt * 1e3, "texts_per_s": 16 / dtt,
             "single_query_8_tokens_ms_host_io": dt1 * 1e3,

@@ -205,19 +205,6 @@ ssw_status ssw_comm_destroy(ssw_comm *comm);
 ssw_status ssw_topk_allgather(ssw_comm *comm, void *hip_stream, const uint64_t *dev_send, uint64_t *dev_recv,
                               int32_t msg_len);
 
-/* tuning hook (tools/sweep_scan.py): pick the scan kernel's schedule variant for dim=512
- * (0 u4, 1 u4+nt, 2 u8, 3 u8+nt, 4 u2+nt; -1 = default) and cap its resident blocks per CU
- * (0 = no cap, -1 = default).  Indexes under 65 536 rows run a latency-shaped kernel (8 rows in flight per wave, query
- * through LDS) unless a variant is named; -2 = the default streaming variant at every size.  All produce identical bits. */
-ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu);
-
-/* ssw_index_topk on an index of <= 8192 images / 65536 rows and <= 8192 excluded ids runs as three launches (query staged
- * through a kernel argument; scan; per-image max + exclusion + selection in one workgroup) with the ids and the result in
- * pinned memory the device maps -- no copies, no stream wait (flag bit 0).  From 2^24 values on and k <= 2048 the selection's threshold comes from a
- * 1-in-16 sample instead of two full histogram passes (flag bit 1; exact all the same: a sample that leaves fewer than k
- * candidates raises the overflow word and the deep path runs).  Default 3; tests switch the forms off to compare. */
-ssw_status ssw_tune_topk(int32_t flags);
-
 /* per-launch device time of the dominant (scan) kernel, measured with HIP events
  * on the handle's stream.  enable=1 starts recording one event pair per scan
  * launch (up to 4096 launches); ssw_index_profile_read synchronises and returns
@@ -478,28 +465,20 @@ ssw_status ssw_clip_embed_text(ssw_clip *clip, const int32_t *ids_host, int32_t 
                                int32_t normalize, float *out_host);
 ssw_status ssw_clip_sync(ssw_clip *clip);
 
-/* Kernel A/B harness for the towers' bf16 GEMM (C[M,N] = A[M,K] W[N,K]^T + epilogue `epi`, see
- * csrc/gemm_bf16.hip): runs `variant` on seeded operands, reports ms per launch over `iters`
- * launches and the max |difference| to variant 0.  Not part of the reference's interface. */
-ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
-                          float *out_ms, float *out_maxdiff);
-/* Selects the GEMM variant the towers use (0 register-staged, 2 LDS-DMA ring with 4 waves per tile,
- * 14 the same with 8 waves per tile, 7 256-row pipelined, 9 the 8-wave 256 x 256 tile, 20-23 the persistent
- * four-wave kernel of csrc/gemm_pw4.hip with its column tile chosen / 256 / 192 / 128). */
-ssw_status ssw_tune_gemm(int32_t variant);
-/* Residual stream of the towers' tile path (csrc/clip.hip, run_tower).  Default 0: the image tower keeps its residual
- * rows in bf16 (the out-projection / fc2 epilogues add into them in place), the text tower in f32.
- * bit 0: f32 rows for the image tower too (the round-2 arithmetic); bit 1: bf16 rows for the text tower too;
- * bit 2: the image tower's attention in its earlier form (fragments fetched straight from memory; same bits out).
- * Not part of the reference's interface. */
-ssw_status ssw_tune_clip(int32_t flags);
-/* Diagnostics of csrc/gemm_pw4.hip for tools/perf_gemm.py: mode 0 the kernel, 1 cycle stamps (out6 = cycles in the
- * mid-step wait + barrier, cycles in K-steps, K-steps, waves, s_memtime and s_memrealtime ticks per kernel; read and reset), 2-4 ablations (no LDS-DMA / no MFMA /
- * no fragment reads inside the loop: wrong results, timing only). */
-ssw_status ssw_debug_gemm_pw4_mode(int32_t mode, uint64_t *out6_or_null);
-/* mode 1's per-workgroup record of the last launch: [1024][4] = start, end (100-MHz ticks), HW_ID, XCC_ID; then mode 5's
- * [20] = cycles per interleave group (16), wait + barrier, sub-stages (summed over waves; read and reset) */
-ssw_status ssw_debug_gemm_pw4_wg(uint64_t *out4116);
+/* Per-handle options of the towers' tile path (csrc/clip.hip, run_tower); a handle starts from the environment
+ * (SSW_CLIP_BF16_STREAM=1 sets option 0, SSW_CLIP_UNFUSED_ATTN=1 option 3).  Waits for the handle's stream first.
+ *   SSW_CLIP_OPT_IMAGE_ROWS_BF16 (0): residual rows of the image tower in bf16 instead of the default f32 rows (SURVEY 8
+ *       a-12's arithmetic) -- the precision / throughput choice of an ingest job: 6 % more tiles per second for 4x the score
+ *       error (1.5e-3 against 4e-4 on a unit query, tests/test_clip_gpu.py retrieval test); both forms meet the parity bar;
+ *   SSW_CLIP_OPT_TEXT_ROWS_BF16 (1): residual rows of the text tower's batched path in bf16 (default f32);
+ *   SSW_CLIP_OPT_ATTN_DIRECT (2), SSW_CLIP_OPT_ATTN_OUT_UNFUSED (3): earlier kernel forms of the image tower's attention
+ *       (fragments straight from memory; attention and out-projection as two launches) kept for A/B measurements.
+ * Not part of the reference's interface (its precision choice is `.half()` on the whole model, embeddings.py:433-435). */
+#define SSW_CLIP_OPT_IMAGE_ROWS_BF16 0
+#define SSW_CLIP_OPT_TEXT_ROWS_BF16 1
+#define SSW_CLIP_OPT_ATTN_DIRECT 2
+#define SSW_CLIP_OPT_ATTN_OUT_UNFUSED 3
+ssw_status ssw_clip_set_option(ssw_clip *clip, int32_t option, int32_t value);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,9 @@ import re
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libseesaw_hip.so")
+DEBUG_LIB_PATH = os.path.join(_PKG_DIR, "libseesaw_hip_debug.so")  # the lab build: same sources + include/seesaw_hip_debug.h
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip.h")
+DEBUG_HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip_debug.h")
 
 SSW_OK = 0
 SSW_ERR_INVALID, SSW_ERR_HIP, SSW_ERR_NOMEM, SSW_ERR_UNSUPPORTED, SSW_ERR_NUMERIC = -1, -2, -3, -4, -5
@@ -115,9 +117,7 @@ _SIGNATURES = {
     "ssw_clip_embed_text": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p]),
     "ssw_clip_embed_tiles_u8": (c_i32, [c_void_p, c_void_p, c_i32, c_i32, c_void_p]),
     "ssw_clip_sync": (c_i32, [c_void_p]),
-    "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
-    "ssw_tune_gemm": (c_i32, [c_i32]),
-    "ssw_tune_clip": (c_i32, [c_i32]),
+    "ssw_clip_set_option": (c_i32, [c_void_p, c_i32, c_i32]),
     "ssw_wm_build_symmetric": (c_i32, [c_i32, c_i64, c_i64, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_i64)]),
     "ssw_wm_fetch": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_wm_destroy": (c_i32, [c_void_p]),
@@ -128,14 +128,27 @@ _SIGNATURES = {
     "ssw_comm_create": (c_i32, [c_i32, c_void_p, c_i32, c_i32, ctypes.POINTER(c_void_p)]),
     "ssw_comm_destroy": (c_i32, [c_void_p]),
     "ssw_topk_allgather": (c_i32, [c_void_p, c_void_p, c_void_p, c_void_p, c_i32]),
-    "ssw_debug_gemm_pw4_mode": (c_i32, [c_i32, c_void_p]),
-    "ssw_debug_gemm_pw4_wg": (c_i32, [c_void_p]),
-    "ssw_tune_scan": (c_i32, [c_i32, c_i32]),
-    "ssw_tune_topk": (c_i32, [c_i32]),
     "ssw_index_profile": (c_i32, [c_void_p, c_i32]),
     "ssw_index_profile_read": (c_i32, [c_void_p, c_void_p, c_i32, c_i32_p]),
 }
 
+
+# include/seesaw_hip_debug.h: the lab build's extra entry points (libseesaw_hip_debug.so only)
+_DEBUG_SIGNATURES = {
+    "ssw_tune_scan": (c_i32, [c_i32, c_i32]),
+    "ssw_tune_topk": (c_i32, [c_i32]),
+    "ssw_tune_gemm": (c_i32, [c_i32]),
+    "ssw_debug_gemm": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "ssw_debug_gemm_pw4_mode": (c_i32, [c_i32, c_void_p]),
+    "ssw_debug_gemm_pw4_wg": (c_i32, [c_void_p]),
+    "ssw_debug_gemm_run": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_i32, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]),
+    "ssw_debug_attn_out_run": (c_i32, [c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       ctypes.c_float]),
+    "ssw_debug_attn_out_stamps": (c_i32, [c_void_p, c_i32]),
+    "ssw_clip_debug_tap": (c_i32, [c_void_p, c_i32, c_i32]),
+    "ssw_clip_debug_tap_read": (c_i32, [c_void_p, c_void_p, c_i64, c_i64_p, c_i32_p]),
+}
 
 
 class FbObjective(ctypes.Structure):
@@ -151,6 +164,8 @@ SSW_FB_LOSS_CE, SSW_FB_LOSS_PAIRWISE_HINGE, SSW_FB_LOSS_PAIRWISE_LOGISTIC = 0, 1
 SSW_FB_REG_NONE, SSW_FB_REG_VECTOR, SSW_FB_REG_NORM, SSW_FB_REG_NORM1 = 0, 1, 2, 3
 
 _lib = None
+_product_lib = None
+_debug_lib = None
 
 
 def declared_symbols(header_path: str = HEADER_PATH):
@@ -160,11 +175,7 @@ def declared_symbols(header_path: str = HEADER_PATH):
     return sorted(set(re.findall(r"\b(ssw_[a-z0-9_]+)\s*\(", text)))
 
 
-def load(path: str = LIB_PATH):
-    """dlopen the HIP library and install the argument types.  Fails loudly."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def _open(path: str, signatures):
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -178,12 +189,49 @@ def load(path: str = LIB_PATH):
     except ImportError:
         pass
     lib = ctypes.CDLL(path)
-    for name, (restype, argtypes) in _SIGNATURES.items():
+    for name, (restype, argtypes) in signatures.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
     return lib
+
+
+def load(path: str = LIB_PATH):
+    """dlopen the HIP library (the product build) and install the argument types.  Fails loudly.  Inside a
+    `debug_hooks()` block this returns the lab build instead."""
+    global _lib, _product_lib
+    if _lib is not None:
+        return _lib
+    _product_lib = _open(path, _SIGNATURES)
+    _lib = _product_lib
+    return _lib
+
+
+def load_debug(path: str = DEBUG_LIB_PATH):
+    """the lab build (libseesaw_hip_debug.so): everything the product exports plus include/seesaw_hip_debug.h"""
+    global _debug_lib
+    if _debug_lib is None:
+        _debug_lib = _open(path, {**_SIGNATURES, **_DEBUG_SIGNATURES})
+    return _debug_lib
+
+
+class debug_hooks:
+    """`with _lib.debug_hooks() as lib:` -- every `_lib.call` / `_lib.load()` inside the block goes to the lab build, so
+    kernel variants can be flipped (ssw_tune_*) and single kernels driven (ssw_debug_*).  Handles are plain heap objects
+    of identical layout in both builds, but create and use them inside the block; tests and tools only -- product code
+    never enters it."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self._prev = _lib
+        _lib = load_debug()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 def last_error() -> str:

@@ -48,10 +48,14 @@ __device__ __forceinline__ int so_off(int row, int k0) {
     return row * AO_ROWB + (b & ~255) + ((((b >> 4) & 15) ^ (row & 15)) << 4);
 }
 
-// diagnostic build of the kernel (SSW_AO_STAMPS=1): s_memtime at the phase boundaries, wave 0 of every workgroup
+// lab build (SSW_DEBUG_HOOKS, SSW_AO_STAMPS=1): s_memtime at the phase boundaries, wave 0 of every workgroup
+#ifdef SSW_DEBUG_HOOKS
 __device__ unsigned long long g_ao_stamps[1024 * 8];
 #define AO_STAMP(slot)                                                                                   \
     if (STAMP && t == 0 && blockIdx.x < 1024) g_ao_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+#else
+#define AO_STAMP(slot)
+#endif
 
 template <bool BF, int PD, bool STAMP = false>
 __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict__ qkv, const bf16 *__restrict__ Wo,
@@ -363,7 +367,6 @@ __global__ void k_pack_wo(const bf16 *__restrict__ Wo, bf16 *__restrict__ out) {
         *reinterpret_cast<const bf16x8 *>(Wo + (int64_t)(w * 96 + j * 16 + fr) * AO_D + ks * 64 + h * 32 + fq * 8);
 }
 
-int g_ao_pd = getenv("SSW_AO_PD") ? atoi(getenv("SSW_AO_PD")) : 1;
 
 template <bool BF, int PD>
 ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float *bo, bf16 *xcopy, const float *res_in,
@@ -376,6 +379,7 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
                                         hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
+#ifdef SSW_DEBUG_HOOKS
     static const bool stamps = getenv("SSW_AO_STAMPS") != nullptr;
     if (stamps) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_outproj_image<BF, PD, true>),
@@ -385,6 +389,7 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
         SSW_HIP_TRY(hipGetLastError());
         return SSW_OK;
     }
+#endif
     hipLaunchKernelGGL((attn_outproj_image<BF, PD>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in, res_out,
                        stats_out, S, scale);
     SSW_HIP_TRY(hipGetLastError());
@@ -393,17 +398,18 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
 
 }  // namespace
 
+#ifdef SSW_DEBUG_HOOKS
 ssw_status read_ao_stamps(uint64_t *out, int n_words) {
     SSW_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ao_stamps), (size_t)n_words * 8));
     return SSW_OK;
 }
+#endif
 ssw_status pack_attn_outproj_weight(hipStream_t s, const void *Wo, void *out) {
     hipLaunchKernelGGL(k_pack_wo, dim3(AO_D * AO_D / 8 / 256), dim3(256), 0, s, static_cast<const bf16 *>(Wo), static_cast<bf16 *>(out));
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
 bool attn_outproj_supports(int S, int D, int H) { return D == AO_D && H == AO_H && S >= 1 && S <= 64; }
-void tune_attn_outproj(int pd) { g_ao_pd = pd; }
 
 // qkv [B*S, 3*768] bf16; Wo: the [768, 768] out-projection weight PACKED by pack_attn_outproj_weight; bo [768].  bf16 stream (res_in == nullptr): xcopy [B*S, 768] is read,
 // added to and written back in place.  f32 stream: res_in -> res_out f32 rows, xcopy receives the bf16 copy.
@@ -418,16 +424,10 @@ ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, c
     const bf16 *q = static_cast<const bf16 *>(qkv), *w = static_cast<const bf16 *>(Wo);
     bf16 *x = static_cast<bf16 *>(xcopy);
     const bool bf = res_in == nullptr;
-    (void)g_ao_pd;  // (two K-steps of fragments ahead spill at the 256 registers of an eight-wave workgroup, and one is enough:
+    // (two K-steps of fragments ahead spill at the 256 registers of an eight-wave workgroup, and one is enough:
                     //  the product waits for the L1's fill rate, not for latency -- 27 k cycles either way)
     return bf ? launch_ao<true, 1>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
               : launch_ao<false, 1>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
 }
 
 }  // namespace ssw
-
-// stamps of the last SSW_AO_STAMPS=1 launch: out[wg * 8 + slot], slots 0..4 = start, after attention, after the product,
-// after the stores, end (shader clock)
-extern "C" int ssw_debug_attn_out_stamps(uint64_t *out, int n_words) {
-    return ssw::read_ao_stamps(out, n_words);
-}

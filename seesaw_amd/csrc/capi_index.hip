@@ -712,7 +712,7 @@ ssw_status ssw_index_topk_fetch(ssw_index *idx, int32_t k, int64_t *out_images, 
 constexpr int64_t SMALL_EXCL_CAP = 8192;
 constexpr int64_t SMALL_ROWS = 65536;  // the small scan kernel's range (scan.hip)
 
-static bool g_small_path = true;  // ssw_tune_topk
+static SSW_TUNABLE bool g_small_path = true;  // ssw_tune_topk
 
 static bool small_path_ok(const ssw_index *idx, int64_t n_excluded) {
     return g_small_path && idx->n_images >= 1 && idx->n_images <= SELECT_SMALL_IMAGES && idx->n <= SMALL_ROWS &&
@@ -946,6 +946,7 @@ ssw_status ssw_topk_merge_msgs_dev(int32_t device, void *hip_stream, const uint6
                              reinterpret_cast<long long *>(dev_flags_seen_or_null), (hipStream_t)hip_stream);
 }
 
+#ifdef SSW_DEBUG_HOOKS
 ssw_status ssw_tune_topk(int32_t flags) {
     g_small_path = (flags & 1) != 0;
     tune_select((flags & 2) != 0);
@@ -956,6 +957,7 @@ ssw_status ssw_tune_scan(int32_t variant, int32_t blocks_per_cu) {
     tune_scan(variant, blocks_per_cu);
     return SSW_OK;
 }
+#endif
 
 ssw_status ssw_index_profile(ssw_index *idx, int32_t enable) {
     SSW_REQUIRE(idx != nullptr, "idx is NULL");

@@ -1035,6 +1035,15 @@ struct ssw_clip {
     float *stats_a = nullptr, *stats_b = nullptr;  // [rows][D / 128][2] partial LayerNorm statistics of hidden / hidden2
     float *pixels = nullptr, *out = nullptr;
     int *ids = nullptr, *rows = nullptr;
+    // ssw_clip_set_option: bit 0 = bf16 residual rows in the image tower's tile path, bit 1 = bf16 rows in the text tower's,
+    // bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
+    // bit 3 = attention and out-projection as two launches (round 3's layer) where attn_out.hip's one launch applies
+    int flags = 0;
+#ifdef SSW_DEBUG_HOOKS
+    int tap_layer = -1, tap_tower = 0;  // ssw_clip_debug_tap: the residual rows behind this layer of this tower (0 image, 1 text) ...
+    float *tap_buf = nullptr;           // ... as f32 [tap_rows][tap_dim]
+    int64_t tap_rows = 0, tap_dim = 0, tap_cap = 0;
+#endif
 };
 
 namespace {
@@ -1220,18 +1229,41 @@ bool skinny_rows(int R, int D, int M) {
     return !off && R <= SK_MAX_ROWS && D == 512 && (M == 512 || M == 1024 || M == 2048);  // (head dim 64: 8 heads)
 }
 
-// ssw_tune_clip: bit 0 = f32 residual stream in the image tower's tile path, bit 1 = bf16 stream in the text tower's,
-// bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
-// bit 3 = attention and out-projection as two launches (round 3's layer) where attn_out.hip's one launch applies
-int g_clip_flags = (getenv("SSW_CLIP_F32_STREAM") ? 1 : 0) | (getenv("SSW_CLIP_UNFUSED_ATTN") ? 8 : 0);
+// a handle's option word (ssw_clip::flags) starts from the environment
+int clip_flags_from_env() { return (getenv("SSW_CLIP_BF16_STREAM") ? 1 : 0) | (getenv("SSW_CLIP_UNFUSED_ATTN") ? 8 : 0); }
 bool unfused_ln_forced() {
     static const bool v = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
     return v;
 }
 // does this tower's tile path keep its residual rows in bf16?
-bool bf16_rows(const Tower &tw, int causal) {
-    return !unfused_ln_forced() && tw.D % 256 == 0 && (causal ? (g_clip_flags & 2) != 0 : (g_clip_flags & 1) == 0);
+bool bf16_rows(const ssw_clip *c, const Tower &tw, int causal) {
+    return !unfused_ln_forced() && tw.D % 256 == 0 && (causal ? (c->flags & 2) != 0 : (c->flags & 1) != 0);
 }
+
+#ifdef SSW_DEBUG_HOOKS
+__global__ void k_tap_widen(const bf16 *__restrict__ x, int64_t n, float *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (float)x[i];
+}
+// lab build: keep the residual rows behind layer l (f32 copy) when the handle asks for them
+ssw_status tap_layer_rows(ssw_clip *c, const Tower &tw, int l, int causal, int64_t R, const float *rows_f32, const bf16 *rows_bf16) {
+    if (c->tap_layer != l || c->tap_tower != (causal ? 1 : 0)) return SSW_OK;
+    const int64_t n = R * tw.D;
+    if (n > c->tap_cap) {
+        if (c->tap_buf) (void)hipFree(c->tap_buf);
+        c->tap_buf = nullptr;
+        SSW_HIP_TRY(hipMalloc((void **)&c->tap_buf, (size_t)n * sizeof(float)));
+        c->tap_cap = n;
+    }
+    if (rows_bf16) hipLaunchKernelGGL(k_tap_widen, dim3(1024), dim3(256), 0, c->stream, rows_bf16, n, c->tap_buf);
+    else SSW_HIP_TRY(hipMemcpyAsync(c->tap_buf, rows_f32, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    c->tap_rows = R;
+    c->tap_dim = tw.D;
+    return SSW_OK;
+}
+#define SSW_TAP(l, f32p, bf16p) SSW_TRY(tap_layer_rows(c, tw, (l), causal, R, (f32p), (bf16p)))
+#else
+#define SSW_TAP(l, f32p, bf16p)
+#endif
 
 ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     hipStream_t s = c->stream;
@@ -1258,6 +1290,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         }
         launch_skinny<SK_BF16_BIAS_GELU, true>(s, h2, nullptr, ly.ln2w, ly.ln2b, eps, ly.w1, ly.b1, nullptr, c->h1, R, M, D);
         launch_skinny<SK_F32_BIAS_RESIDUAL, false>(s, c->h1, nullptr, nullptr, nullptr, eps, ly.w2, ly.b2, h2, h, R, D, M);
+        SSW_TAP(l, h, nullptr);
     }
     // ---- tile path: five launches a layer.  Both LayerNorms are folded into the products that consume them (GemmLn,
     // ssw_common.h): the out-projection / fc2 epilogues leave, next to the f32 residual row, its bf16 copy (c->xn) and
@@ -1269,7 +1302,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     // Measured against transformers' f32 towers (tools/clip_stream_error.py, 26 images): min cosine 0.999994 -> 0.999952,
     // max |delta| of a unit vector's component 5.0e-4 -> 1.5e-3 (bar: 0.999 / 5e-3); B = 200 forward 2.91 -> 2.75 ms.
     // On for the image tower (the batch path); the text tower -- the query side -- keeps its f32 rows.
-    const bool bf16_stream = bf16_rows(tw, causal);
+    const bool bf16_stream = bf16_rows(c, tw, causal);
     c->stream_in_xn = false;
     const int np = D / 128;
     float *st_h = c->stats_a, *st_h2 = c->stats_b;
@@ -1293,7 +1326,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
         // round 4: attention + out-projection + residual + statistics of the image tower in one launch, a workgroup per
         // image (attn_out.hip); the fc1 product then reads two partial pairs a row instead of D / 128
-        const bool fused_attn = !unfused_ln && D % 256 == 0 && !causal && (g_clip_flags & 8) == 0 &&
+        const bool fused_attn = !unfused_ln && D % 256 == 0 && !causal && (c->flags & 8) == 0 &&
                                 attn_outproj_supports(S, D, tw.H) && ly.wo_pk != nullptr;
         if (fused_attn) {
             if (bf16_stream) c->stream_in_xn = true;
@@ -1308,12 +1341,13 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
                 SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_STREAM_STATS, s, c->h1, ly.w2, ly.b2, nullptr, nullptr, R, D, M, prod));
             else
                 SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
+            SSW_TAP(l, bf16_stream ? nullptr : h, bf16_stream ? c->xn : nullptr);
             continue;
         }
         static const bool one_tile_waves = getenv("SSW_CLIP_ATTN_TPW1") != nullptr;  // A/B: the four-wave form
         // (one wave per pair with four tiles, attention_mfma<4, 4>: 21.6 us per layer against 17.1 -- measured, not kept)
         static const bool direct_env = getenv("SSW_CLIP_ATTN_DIRECT") != nullptr;  // A/B: fragments straight from memory
-        const bool direct_frags = direct_env || (g_clip_flags & 4) != 0;
+        const bool direct_frags = direct_env || (c->flags & 4) != 0;
         if (S <= 64 && !one_tile_waves && !direct_frags)
             hipLaunchKernelGGL(attention_rows64, dim3(n_heads), dim3(128), 0, s, c->qkv, c->att, S, D, tw.H, att_scale, causal);
         else if (S <= 64 && !one_tile_waves)
@@ -1349,6 +1383,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             prod.stats_out = st_h;
             SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
         }
+        SSW_TAP(l, c->stream_in_xn ? nullptr : h, c->stream_in_xn ? c->xn : nullptr);
     }
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
@@ -1395,7 +1430,7 @@ ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *
     // statistics for layer 0's QKV, and the f32 row into c->hidden unless the stack keeps its rows in bf16
     // (round 3: putting the rows together was a launch and a 30-MB round trip of its own at B = 200)
     hipLaunchKernelGGL(stack_input_rows<true>, dim3((B * T + 3) / 4), dim3(256), 0, s, c->patch_out, B * T, D, c->pre_w,
-                       c->pre_b, h.ln_eps, bf16_rows(c->vis, 0) ? (float *)nullptr : c->hidden, c->xn, c->stats_a,
+                       c->pre_b, h.ln_eps, bf16_rows(c, c->vis, 0) ? (float *)nullptr : c->hidden, c->xn, c->stats_a,
                        D / 128 > 0 ? D / 128 : 1, c->cls, c->vpos, T);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
     hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
@@ -1437,14 +1472,39 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
 
 extern "C" {
 
-ssw_status ssw_tune_clip(int32_t flags) {
-    if (flags < 0 || flags > 7) {
-        ssw::set_error("ssw_tune_clip: flags %d unknown (bit 0 f32 stream for images, bit 1 bf16 stream for text, bit 2 direct attention fragments)", flags);
-        return SSW_ERR_INVALID;
-    }
-    g_clip_flags = flags;
+ssw_status ssw_clip_set_option(ssw_clip *c, int32_t option, int32_t value) {
+    SSW_REQUIRE(c != nullptr, "clip is NULL");
+    SSW_REQUIRE(option >= 0 && option <= 3, "ssw_clip_set_option: option %d unknown (SSW_CLIP_OPT_*)", option);
+    DeviceGuard guard(c->device);
+    SSW_HIP_TRY(hipStreamSynchronize(c->stream));  // a forward in flight keeps the form it started with
+    if (value) c->flags |= 1 << option;
+    else c->flags &= ~(1 << option);
     return SSW_OK;
 }
+
+#ifdef SSW_DEBUG_HOOKS
+ssw_status ssw_clip_debug_tap(ssw_clip *c, int32_t tower, int32_t layer) {
+    SSW_REQUIRE(c != nullptr, "clip is NULL");
+    c->tap_tower = tower;
+    c->tap_layer = layer;
+    c->tap_rows = c->tap_dim = 0;
+    return SSW_OK;
+}
+
+ssw_status ssw_clip_debug_tap_read(ssw_clip *c, float *out_host, int64_t cap_floats, int64_t *out_rows, int32_t *out_dim) {
+    SSW_REQUIRE(c != nullptr && out_rows && out_dim, "NULL argument");
+    DeviceGuard guard(c->device);
+    SSW_HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_rows = c->tap_rows;
+    *out_dim = (int32_t)c->tap_dim;
+    if (out_host && c->tap_rows * c->tap_dim > 0) {
+        SSW_REQUIRE(cap_floats >= c->tap_rows * c->tap_dim, "tap: %lld floats, buffer holds %lld",
+                    (long long)(c->tap_rows * c->tap_dim), (long long)cap_floats);
+        SSW_HIP_TRY(hipMemcpy(out_host, c->tap_buf, (size_t)(c->tap_rows * c->tap_dim) * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return SSW_OK;
+}
+#endif
 
 ssw_status ssw_clip_destroy(ssw_clip *c) {
     if (!c) return SSW_OK;
@@ -1455,6 +1515,9 @@ ssw_status ssw_clip_destroy(ssw_clip *c) {
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
                     (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
         (void)hipFree(p);
+#ifdef SSW_DEBUG_HOOKS
+    if (c->tap_buf) (void)hipFree(c->tap_buf);
+#endif
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SSW_OK;
@@ -1484,6 +1547,7 @@ ssw_status ssw_clip_create(int32_t device, const void *weight_blob, size_t bytes
     if (!c) return SSW_ERR_NOMEM;
     c->device = device;
     c->hdr = h;
+    c->flags = clip_flags_from_env();
     auto bail = [&](ssw_status s) {
         ssw_clip_destroy(c);
         return s;

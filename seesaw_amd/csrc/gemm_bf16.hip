@@ -958,7 +958,7 @@ ssw_status launch_256(hipStream_t s, const bf16 *A, const bf16 *W, const float *
 //  CU -- a quarter less L2->LDS traffic per flop and operands requested two K-steps ahead.  fc2 886 vs 880 TFLOP/s,
 //  out-proj 522 vs 523, patch 940 vs 926; qkv 651 vs 722, fc1 650 vs 700.  Not kept.)
 
-int g_gemm_variant = 14;
+SSW_TUNABLE int g_gemm_variant = 14;  // ssw_tune_gemm (lab build only)
 
 template <int EPI, int DEPTH, int TM, bool PIPE = false, int WN = 2>
 ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C,
@@ -1035,7 +1035,10 @@ ssw_status launch_epi_ln(hipStream_t s, const bf16 *A, const bf16 *W, const floa
 
 }  // namespace
 
+#ifdef SSW_DEBUG_HOOKS
 void tune_gemm(int variant) { g_gemm_variant = variant; }
+int gemm_variant() { return g_gemm_variant; }
+#endif
 
 ssw_status launch_gemm_bf16_nt(int epi, hipStream_t s, const void *A_, const void *W_, const float *bias,
                                const float *res, void *C, int M, int N, int K) {
@@ -1043,12 +1046,14 @@ ssw_status launch_gemm_bf16_nt(int epi, hipStream_t s, const void *A_, const voi
         set_error("gemm_bf16_nt: shape M=%d N=%d K=%d unsupported (N %% 128, K %% 64)", M, N, K);
         return SSW_ERR_UNSUPPORTED;
     }
+#ifdef SSW_DEBUG_HOOKS  // the four-wave experiment (gemm_pw4.hip) is part of the lab build only
     if (g_gemm_variant >= 20 && g_gemm_variant <= 23 && gemm_pw4_supports(M, N, K)) {
         static const int bn_of[4] = {0, 256, 192, 128};
         int bn = bn_of[g_gemm_variant - 20];
         if (bn != 0 && N % bn != 0) bn = 0;
         return launch_gemm_pw4(epi, s, A_, W_, bias, res, C, M, N, K, bn);
     }
+#endif
     const bf16 *A = static_cast<const bf16 *>(A_), *W = static_cast<const bf16 *>(W_);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(s, A, W, bias, res, C, M, N, K);
@@ -1095,125 +1100,3 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t s, const void *A_, const voi
 
 }  // namespace ssw
 
-// ---------------------------------------------------------------------------------------
-// A/B harness (tools/perf_gemm.py): time one variant on seeded operands and compare its
-// output with variant 0 in the same process.
-// ---------------------------------------------------------------------------------------
-namespace {
-__global__ void k_debug_fill(ssw::bf16 *x, int64_t n, uint32_t seed, float scale) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t h = (uint32_t)i * 2654435761u + seed;
-        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-        x[i] = (ssw::bf16)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
-    }
-}
-__global__ void k_debug_fill_f32(float *x, int64_t n, uint32_t seed, float scale) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t h = (uint32_t)i * 2654435761u + seed;
-        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-        x[i] = ((int)(h & 0xffff) - 32768) * (scale / 32768.f);
-    }
-}
-template <typename T>
-__global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
-    float m = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float d = fabsf((float)a[i] - (float)b[i]);
-        m = fmaxf(m, d == d ? d : 3.0e38f);
-    }
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int *>(out), __float_as_int(m));
-}
-}  // namespace
-
-extern "C" int ssw_tune_gemm(int variant) {
-    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15 &&
-        !(variant >= 20 && variant <= 23)) {
-        ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
-        return SSW_ERR_INVALID;
-    }
-    ssw::tune_gemm(variant);
-    return SSW_OK;
-}
-
-// diagnostics of the persistent kernel (gemm_pw4.hip): mode 1 accumulates cycle stamps, read back here as
-// out4 = {cycles in the mid-step wait + barrier, cycles in K-steps, K-steps, waves}; modes 2-4 are ablations
-extern "C" int ssw_debug_gemm_pw4_mode(int32_t mode, uint64_t *out6_or_null) {
-    ssw::gemm_pw4_set_mode(mode);
-    if (out6_or_null) return ssw::gemm_pw4_read_diag(reinterpret_cast<unsigned long long *>(out6_or_null), true);
-    return SSW_OK;
-}
-
-extern "C" int ssw_debug_gemm_pw4_wg(uint64_t *out4096) {
-    return ssw::gemm_pw4_read_wg(reinterpret_cast<unsigned long long *>(out4096));
-}
-
-extern "C" int ssw_debug_gemm(int M, int N, int K, int epi, int variant, int iters, float *out_ms,
-                              float *out_maxdiff) {
-    using namespace ssw;
-    if (M <= 0 || iters <= 0 || epi < 0 || epi > 3) {
-        set_error("ssw_debug_gemm: bad arguments");
-        return SSW_ERR_INVALID;
-    }
-    const bool out_bf16 = (epi == 1 || epi == 2);
-    const size_t out_bytes = (size_t)M * N * (out_bf16 ? 2 : 4);
-    bf16 *A = nullptr, *W = nullptr;
-    float *bias = nullptr, *res = nullptr, *diff = nullptr;
-    void *c_ref = nullptr, *c_var = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int rc = SSW_OK;
-    auto cleanup = [&]() {
-        for (void *p : {(void *)A, (void *)W, (void *)bias, (void *)res, (void *)diff, c_ref, c_var}) (void)hipFree(p);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    };
-#define SSW_DBG_TRY(expr)                                                      \
-    if (hipError_t _e = (expr); _e != hipSuccess) {                            \
-        set_error("%s failed: %s", #expr, hipGetErrorString(_e));              \
-        cleanup();                                                             \
-        return SSW_ERR_HIP;                                                    \
-    }
-    SSW_DBG_TRY(hipMalloc(&A, (size_t)M * K * 2));
-    SSW_DBG_TRY(hipMalloc(&W, (size_t)N * K * 2));
-    SSW_DBG_TRY(hipMalloc(&bias, (size_t)N * 4));
-    SSW_DBG_TRY(hipMalloc(&res, (size_t)M * N * 4));
-    SSW_DBG_TRY(hipMalloc(&diff, 4));
-    SSW_DBG_TRY(hipMalloc(&c_ref, out_bytes));
-    SSW_DBG_TRY(hipMalloc(&c_var, out_bytes));
-    hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, A, (int64_t)M * K, 0x1234u, 1.0f);
-    hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, W, (int64_t)N * K, 0x9876u, 0.05f);
-    hipLaunchKernelGGL(k_debug_fill_f32, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 0x4242u, 0.5f);
-    hipLaunchKernelGGL(k_debug_fill_f32, dim3(2048), dim3(256), 0, 0, res, (int64_t)M * N, 0x7777u, 1.0f);
-    SSW_DBG_TRY(hipMemsetAsync(diff, 0, 4, 0));
-    SSW_DBG_TRY(hipEventCreate(&e0));
-    SSW_DBG_TRY(hipEventCreate(&e1));
-    const int keep = g_gemm_variant;
-    tune_gemm(0);
-    rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_ref, M, N, K);
-    tune_gemm(variant);
-    if (rc == SSW_OK) rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_var, M, N, K);  // warm-up + checked run
-    if (rc == SSW_OK) {
-        if (out_bf16)
-            hipLaunchKernelGGL(k_debug_maxdiff<bf16>, dim3(1024), dim3(256), 0, 0, (const bf16 *)c_ref,
-                               (const bf16 *)c_var, (int64_t)M * N, diff);
-        else
-            hipLaunchKernelGGL(k_debug_maxdiff<float>, dim3(1024), dim3(256), 0, 0, (const float *)c_ref,
-                               (const float *)c_var, (int64_t)M * N, diff);
-        (void)hipEventRecord(e0, 0);
-        for (int i = 0; i < iters && rc == SSW_OK; ++i) rc = launch_gemm_bf16_nt(epi, 0, A, W, bias, res, c_var, M, N, K);
-        (void)hipEventRecord(e1, 0);
-    }
-    tune_gemm(keep);
-    if (rc != SSW_OK) {
-        cleanup();
-        return rc;
-    }
-    SSW_DBG_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    SSW_DBG_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (out_ms) *out_ms = ms / iters;
-    if (out_maxdiff) SSW_DBG_TRY(hipMemcpy(out_maxdiff, diff, 4, hipMemcpyDeviceToHost));
-#undef SSW_DBG_TRY
-    cleanup();
-    return SSW_OK;
-}

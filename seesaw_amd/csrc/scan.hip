@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
 // at 100 M rows u2+nt with one block per CU reads 6.70 TB/s, u4 (default policy, 8 waves/SIMD)
 // 6.17 TB/s; 1 M rows: 6.66 vs 5.65 TB/s.  All variants produce identical bits.
 constexpr int64_t SCAN_SMALL_ROWS = 65536;  // below: the streaming kernel has under one 4-wave workgroup per CU
-bool g_scan_small = true;       // tuning hook (ssw_tune_scan variant -2: streaming kernel at every size)
-int g_scan_variant = -1;        // tuning hook (ssw_tune_scan): -1 = default (u2 + nt)
-int g_scan_blocks_per_cu = -1;  // -1 = default (1 per CU for dim 512), 0 = as many as fit
+SSW_TUNABLE bool g_scan_small = true;       // tuning hook (ssw_tune_scan variant -2: streaming kernel at every size)
+SSW_TUNABLE int g_scan_variant = -1;        // tuning hook (ssw_tune_scan): -1 = default (u2 + nt)
+SSW_TUNABLE int g_scan_blocks_per_cu = -1;  // -1 = default (1 per CU for dim 512), 0 = as many as fit
 
 template <int C, int U, bool NT>
 ssw_status launch_scan_t(const float *X, const float *q, float *scores, int64_t n, int device,
@@ -399,11 +399,13 @@ ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, 
     return SSW_OK;
 }
 
+#ifdef SSW_DEBUG_HOOKS
 void tune_scan(int variant, int blocks_per_cu) {
     g_scan_small = variant == -1;  // an explicit variant (or -2) means the streaming kernel at every size
     if (variant < -1) variant = -1;
     g_scan_variant = variant;
     g_scan_blocks_per_cu = blocks_per_cu;
 }
+#endif
 
 }  // namespace ssw

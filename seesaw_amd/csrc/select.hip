@@ -46,7 +46,7 @@ constexpr int64_t SAMPLE_FROM = (int64_t)1 << 24;
 constexpr int64_t SAMPLE_R = 64;
 constexpr int SAMPLE_RANK = 48;
 constexpr int SAMPLE_MAX_K = 1024;
-bool g_select_sampled = true;  // ssw_tune_topk bit 1
+SSW_TUNABLE bool g_select_sampled = true;  // ssw_tune_topk bit 1
 enum StateSlot : int {
     ST_B1 = 0, ST_ABOVE1, ST_CNT1, ST_B2, ST_ABOVE2, ST_CNT2, ST_MODE, ST_NCAND, ST_OVERFLOW, ST_K,
     ST_WORDS = 16
@@ -619,7 +619,9 @@ int grid_for(int64_t m, int device) {
 
 }  // namespace
 
+#ifdef SSW_DEBUG_HOOKS
 void tune_select(bool sampled) { g_select_sampled = sampled; }
+#endif
 
 ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map) {
     SSW_TRY(dev_alloc(&ws.hist1, 2 * NBINS + ST_WORDS));

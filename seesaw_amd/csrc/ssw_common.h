@@ -9,6 +9,17 @@
 #include <vector>
 
 #include "../../include/seesaw_hip.h"
+#ifdef SSW_DEBUG_HOOKS
+#include "../../include/seesaw_hip_debug.h"
+#endif
+
+// Kernel-selection switches are file-scope constants in the product library; only the lab build (-DSSW_DEBUG_HOOKS ->
+// libseesaw_hip_debug.so, entry points in include/seesaw_hip_debug.h) can change them.
+#ifdef SSW_DEBUG_HOOKS
+#define SSW_TUNABLE
+#else
+#define SSW_TUNABLE const
+#endif
 
 namespace ssw {
 
@@ -115,7 +126,9 @@ ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_
                        int device, hipStream_t stream);
 ssw_status launch_score_rows(const float *X, const float *q_dev, const int64_t *rows_dev, int64_t n,
                              int32_t dim, float *out, hipStream_t stream);
+#ifdef SSW_DEBUG_HOOKS
 void tune_scan(int variant, int blocks_per_cu);
+#endif
 // knn.hip's last stage (lives in scan.hip to share the scan's summation order)
 ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, int r0, int rows, const uint64_t *buf,
                               int cap, const unsigned *cnt, const unsigned char *overflow, int M, const float *norms,
@@ -125,7 +138,9 @@ ssw_status launch_knn_rescore(const float *X, int32_t dim, const int32_t *perm, 
 // epi: 0 f32 | 1 +bias -> bf16 | 2 +bias, quick-GELU -> bf16 | 3 +bias +residual -> f32
 ssw_status launch_gemm_bf16_nt(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K);
+#ifdef SSW_DEBUG_HOOKS
 void tune_gemm(int variant);
+#endif
 // LayerNorm folded into a product (tile path of the CLIP towers; gemm_bf16.hip explains the algebra):
 //   epi 4 / 5 (consumer):  C = rstd * (A W'^T - mean * c1) + c2 [quick-GELU] -> bf16, with A = bf16(x), W' = gamma (.) W,
 //                          c2 passed as `bias`, the rows' statistics as np_in partial (sum, sum of squares) pairs
@@ -143,11 +158,13 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const
                                const float *residual, void *C, int M, int N, int K, const GemmLn &ln);
 // attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image
 bool attn_outproj_supports(int S, int D, int H);
-void tune_attn_outproj(int prefetch_depth);
 ssw_status pack_attn_outproj_weight(hipStream_t stream, const void *Wo_768x768, void *out_same_size);
 ssw_status launch_attn_outproj(hipStream_t stream, const void *qkv, const void *Wo, const float *bo, void *xcopy,
                                const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
                                float scale);
+#ifdef SSW_DEBUG_HOOKS
+ssw_status read_ao_stamps(uint64_t *out, int n_words);
+int gemm_variant();
 // gemm_pw4.hip: the persistent four-wave kernel (256 x bn tiles, bn = 256 / 192 / 128, 0 = choose); N % 128, K % 128
 bool gemm_pw4_supports(int M, int N, int K);
 void gemm_pw4_set_mode(int mode);  // diagnostics of tools/perf_gemm.py (0 = the kernel)
@@ -155,6 +172,7 @@ ssw_status gemm_pw4_read_diag(unsigned long long out[6], bool reset);
 ssw_status gemm_pw4_read_wg(unsigned long long *out);
 ssw_status launch_gemm_pw4(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                            const float *residual, void *C, int M, int N, int K, int bn);
+#endif
 // rng.hip: synthetic unit-norm rows.
 ssw_status launch_fill_random(float *X, int64_t n, int32_t dim, uint64_t seed, int64_t first_row,
                               hipStream_t stream);
@@ -210,7 +228,9 @@ struct SelectWorkspace {
     unsigned host_seq = 0;
 };
 
+#ifdef SSW_DEBUG_HOOKS
 void tune_select(bool sampled);
+#endif
 ssw_status select_alloc(SelectWorkspace &ws, int64_t n_rows, int64_t n_images, bool has_map);
 void select_free(SelectWorkspace &ws);
 // install the excluded set (host ids) into ws.excl_bits; counts distinct ids.

@@ -111,6 +111,17 @@ class ClipModel:
     def sync(self):
         _lib.call("ssw_clip_sync", self._h)
 
+    # ssw_clip_set_option (include/seesaw_hip.h): per-handle form of the towers' tile path
+    OPT_IMAGE_ROWS_BF16, OPT_TEXT_ROWS_BF16, OPT_ATTN_DIRECT, OPT_ATTN_OUT_UNFUSED = 0, 1, 2, 3
+
+    def set_option(self, option: int, value: bool):
+        _lib.call("ssw_clip_set_option", self._h, int(option), int(bool(value)))
+
+    def set_rows(self, image_bf16: bool = False, text_bf16: bool = False):
+        """residual-row precision of the two towers' tile paths (default: f32 rows in both)"""
+        self.set_option(self.OPT_IMAGE_ROWS_BF16, image_bf16)
+        self.set_option(self.OPT_TEXT_ROWS_BF16, text_bf16)
+
     def embed_text(self, input_ids: np.ndarray, normalize: bool = False) -> np.ndarray:
         ids = np.ascontiguousarray(input_ids, dtype=np.int32)
         assert ids.ndim == 2

@@ -17,3 +17,13 @@ def oracle():
     from oracle import seesaw_oracle
     seesaw_oracle.c_lib()
     return seesaw_oracle
+
+
+@pytest.fixture()
+def lab_build():
+    """tests that flip kernel variants (ssw_tune_*) or drive single kernels (ssw_debug_*) run on libseesaw_hip_debug.so --
+    the same sources compiled with -DSSW_DEBUG_HOOKS (include/seesaw_hip_debug.h); everything else in the suite runs on the
+    product library, which has no such switch.  Handles are created and closed inside the test."""
+    from seesaw_amd import _lib
+    with _lib.debug_hooks() as lib:
+        yield lib

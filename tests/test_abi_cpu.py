@@ -31,6 +31,30 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert exported == set(declared), (exported ^ set(declared))
 
 
+def test_lab_build_holds_the_hooks_and_the_product_does_not(lib):
+    """ssw_tune_* / ssw_debug_* live in include/seesaw_hip_debug.h and exist only in
+    libseesaw_hip_debug.so (compiled with -DSSW_DEBUG_HOOKS); the product header declares none of them and the product
+    library exports none of them -- its kernel-selection switches are constants."""
+    product = set(lib.declared_symbols())
+    hooks = set(lib.declared_symbols(lib.DEBUG_HEADER_PATH))
+    assert hooks and not (hooks & product)
+    assert not [n for n in product if n.startswith(("ssw_tune_", "ssw_debug_"))]
+    assert sorted(lib._DEBUG_SIGNATURES) == sorted(hooks), "ctypes table and debug header disagree"
+    nm = subprocess.run(["nm", "-D", "--defined-only", lib.DEBUG_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ssw_[a-z0-9_]+)", nm))
+    assert exported == product | hooks, (exported ^ (product | hooks))
+    dbg = lib.load_debug()
+    for name in product | hooks:
+        assert hasattr(dbg, name)
+    # no mutable tuning word in the product: the switches are `const` there (SSW_TUNABLE), so they are not data symbols
+    nm_all = subprocess.run(["nm", "-C", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for word in ("g_gemm_variant", "g_scan_variant", "g_select_sampled", "g_small_path", "g_clip_flags"):
+        assert not re.search(r" [BbDd] .*" + word, nm_all), word
+    with lib.debug_hooks() as inside:
+        assert inside is dbg and lib.load() is dbg
+    assert lib.load() is not dbg
+
+
 def test_abi_version_and_error_channel(lib):
     h = lib.load()
     assert h.ssw_abi_version() == 1

@@ -48,8 +48,8 @@ def test_image_tower_vs_hf(models):
 
 
 def test_residual_stream_precisions_vs_hf(models):
-    """The tile path holds the image tower's residual rows in bf16 by default and the text tower's in f32
-    (ssw_tune_clip): both arithmetic forms of both towers meet the bar, and the switch is live."""
+    """The tile path holds both towers' residual rows in f32 by default, in bf16 on request
+    (ssw_clip_set_option, per handle): both arithmetic forms of both towers meet the bar, and the switch is live."""
     import torch
     from seesaw_amd import _lib
     hf, ours = models
@@ -66,33 +66,57 @@ def test_residual_stream_precisions_vs_hf(models):
         ref_t = _unit((ref_t.pooler_output if hasattr(ref_t, "pooler_output") else ref_t).numpy())
     got = {}
     try:
-        for flags in (0, 3):  # 0: images bf16 / text f32 (default); 3: images f32 / text bf16
-            _lib.call("ssw_tune_clip", flags)
+        for flags in (0, 3):  # 0: f32 rows in both towers (default); 3: bf16 rows in both
+            ours.set_rows(image_bf16=bool(flags & 1), text_bf16=bool(flags & 2))
             got[flags] = (ours.embed_image(x.numpy(), normalize=True), _unit(ours.embed_text(ids.astype(np.int32), normalize=False)))
     finally:
-        _lib.call("ssw_tune_clip", 0)
+        ours.set_rows()
     for flags, (gi, gt) in got.items():
         assert (gi * ref_i).sum(1).min() >= COS_MIN and (gt * ref_t).sum(1).min() >= COS_MIN, flags
         assert np.abs(gi - ref_i).max() <= ABS_MAX and np.abs(gt - ref_t).max() <= ABS_MAX, flags
     for a, b in zip(got[0], got[3]):
         assert 0 < np.abs(a - b).max() <= 3e-3
     with pytest.raises(_lib.SeesawHipError):
-        _lib.call("ssw_tune_clip", 8)
+        ours.set_option(4, True)
 
 
 def test_image_attention_forms_give_the_same_bits(models):
     """attention_rows64 (K / Q / V rows fetched coalesced, fragments out of LDS, the output tile stored row-major) against
     attention_mfma<4, 2> (fragments straight from memory): same fragments, same MFMA order -- identical embeddings."""
-    from seesaw_amd import _lib
     _, ours = models
     x = np.random.default_rng(21).standard_normal((9, 3, 224, 224), dtype=np.float32)
     try:
+        ours.set_option(ours.OPT_ATTN_OUT_UNFUSED, True)  # both forms are attention launches of their own
         a = ours.embed_image(x, normalize=False)
-        _lib.call("ssw_tune_clip", 4)
+        ours.set_option(ours.OPT_ATTN_DIRECT, True)
         b = ours.embed_image(x, normalize=False)
     finally:
-        _lib.call("ssw_tune_clip", 0)
+        ours.set_option(ours.OPT_ATTN_DIRECT, False)
+        ours.set_option(ours.OPT_ATTN_OUT_UNFUSED, False)
     assert a.tobytes() == b.tobytes()
+
+
+def test_fused_attention_outprojection_against_the_two_launches(models):
+    """round 4: attention + out-projection + residual + statistics in one launch per layer (attn_out.hip).  The attention
+    tiles and the product's MFMA order are those of the two launches; only the grouping of the LayerNorm partial sums
+    differs (two partial pairs a row instead of six), so the embeddings agree to f32 rounding of those sums -- in both
+    residual-row precisions."""
+    _, ours = models
+    x = np.random.default_rng(22).standard_normal((7, 3, 224, 224), dtype=np.float32)
+    try:
+        for f32_rows in (False, True):
+            ours.set_rows(image_bf16=not f32_rows)
+            ours.set_option(ours.OPT_ATTN_OUT_UNFUSED, False)
+            a = ours.embed_image(x, normalize=True)
+            ours.set_option(ours.OPT_ATTN_OUT_UNFUSED, True)
+            b = ours.embed_image(x, normalize=True)
+            # (measured 9e-4 with bf16 rows: a 1e-7 change of a row's mean flips bf16 roundings of later rows, one ulp =
+            #  7.8e-3 at |x| ~ 1.5, and the flips travel; the two text paths sit as far apart, test_single_query_...)
+            assert np.abs(a - b).max() <= 1.5e-3, (f32_rows, np.abs(a - b).max())
+            assert (a * b).sum(1).min() >= 0.99995
+    finally:
+        ours.set_rows()
+        ours.set_option(ours.OPT_ATTN_OUT_UNFUSED, False)
 
 
 @pytest.mark.parametrize("L", [8, 77])
@@ -324,3 +348,200 @@ def test_single_query_path_agrees_with_tile_path_over_random_shapes(models):
         # (1.5e-3: the tile path folds its LayerNorms into the products since round 3 -- bf16(x) times gamma (.) W instead
         #  of bf16(LN(x)) times W -- so the two paths round differently; both are held to the HF bar above)
         assert np.abs(got - tiled).max() <= 1.5e-3, (B, L, np.abs(got - tiled).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 4 (VERDICT r3 #2b, #2c): parity below and above the final embedding
+# ---------------------------------------------------------------------------------------------------------------------
+def _tap(lib, model, tower, layer, run):
+    """residual rows behind `layer` of `tower` (lab build: ssw_clip_debug_tap) during `run()` -> f32 [rows, hidden]"""
+    import ctypes
+    assert lib.ssw_clip_debug_tap(model._h, tower, layer) == 0
+    run()
+    rows, dim = ctypes.c_int64(), ctypes.c_int32()
+    assert lib.ssw_clip_debug_tap_read(model._h, None, 0, ctypes.byref(rows), ctypes.byref(dim)) == 0
+    out = np.empty((rows.value, dim.value), dtype=np.float32)
+    assert lib.ssw_clip_debug_tap_read(model._h, ctypes.c_void_p(out.ctypes.data), out.size, ctypes.byref(rows), ctypes.byref(dim)) == 0
+    lib.ssw_clip_debug_tap(model._h, tower, -1)
+    return out
+
+
+# Per-layer bound: max |ours - HF| over the layer's residual rows, as a fraction of that layer's rms in HF (the rows grow
+# from ~1 to ~3 over the stack), and the rms error the same way; 1.5x what the box measured (printed by the test):
+#                        layer 0 .. layer 11, max|d| / rms            rms(d) / rms
+#   image, bf16 rows     0.027 .. 0.089 (grows with the depth)         0.0037 .. 0.0088
+#   image, f32 rows      0.011 .. 0.014 (flat)                         0.0024 .. 0.0031
+#   text, tile path      0.021 .. 0.029                                0.0048 .. 0.0062
+#   text, single query   0.020 .. 0.025                                0.0048 .. 0.0062
+# f32 rows: the error is that of the bf16 operands of each product and does not accumulate; bf16 rows add a rounding of
+# the stream itself behind every residual add (24 of them), which does.
+LAYER_MAX_FRAC = {"image_bf16_rows": 0.135, "image_f32_rows": 0.022, "text_tile_f32_rows": 0.045, "text_single_query": 0.040}
+LAYER_RMS_FRAC = {"image_bf16_rows": 0.0135, "image_f32_rows": 0.0046, "text_tile_f32_rows": 0.0095, "text_single_query": 0.0095}
+
+
+def test_hidden_states_of_every_layer_vs_hf(lab_build):
+    """VERDICT r3 #2b: the residual rows behind EVERY transformer layer of both towers against transformers'
+    output_hidden_states (f32), for the image tower in both residual-row precisions, the text tower's tile path and its
+    single-query path.  A kernel change that keeps the final cosine but bends a middle layer shows here."""
+    import torch
+    import transformers
+    from seesaw_amd.models.clip import ClipModel
+    lib = lab_build
+    torch.manual_seed(1234)
+    hf = transformers.CLIPModel(transformers.CLIPConfig()).eval()
+    ours = ClipModel.from_hf(hf)  # created inside the lab build: the tap lives there
+    torch.manual_seed(3)
+    x = torch.randn(4, 3, 224, 224)
+    rng = np.random.default_rng(8)
+    ids_b = rng.integers(0, 49405, size=(3, 30)).astype(np.int64)   # 90 rows: tile path
+    ids_q = rng.integers(0, 49405, size=(1, 9)).astype(np.int64)    # 9 rows: the single-query kernels
+    for ids in (ids_b, ids_q):
+        ids[:, 0], ids[:, -1] = 49406, 49407
+    with torch.inference_mode():
+        hs_img = [h.reshape(-1, 768).numpy() for h in hf.vision_model(pixel_values=x, output_hidden_states=True).hidden_states]
+        hs_tb = [h.reshape(-1, 512).numpy() for h in hf.text_model(input_ids=torch.from_numpy(ids_b), output_hidden_states=True).hidden_states]
+        hs_tq = [h.reshape(-1, 512).numpy() for h in hf.text_model(input_ids=torch.from_numpy(ids_q), output_hidden_states=True).hidden_states]
+    cases = [("image_bf16_rows", 0, hs_img, lambda: ours.embed_image(x.numpy()), dict(image_bf16=True)),
+             ("image_f32_rows", 0, hs_img, lambda: ours.embed_image(x.numpy()), dict(image_bf16=False)),
+             ("text_tile_f32_rows", 1, hs_tb, lambda: ours.embed_text(ids_b.astype(np.int32)), {}),
+             ("text_single_query", 1, hs_tq, lambda: ours.embed_text(ids_q.astype(np.int32)), {})]
+    try:
+        for name, tower, hs, run, rows in cases:
+            ours.set_rows(**rows)
+            worst_max = worst_rms = 0.0
+            per_layer = []
+            for layer in range(12):
+                got = _tap(lib, ours, tower, layer, run)
+                ref = hs[layer + 1]  # hidden_states[0] is the stack's input
+                assert got.shape == ref.shape, (name, layer, got.shape, ref.shape)
+                rms = float(np.sqrt((ref * ref).mean()))
+                d = np.abs(got - ref)
+                fmax, frms = float(d.max()) / rms, float(np.sqrt((d * d).mean())) / rms
+                worst_max, worst_rms = max(worst_max, fmax), max(worst_rms, frms)
+                per_layer.append((round(fmax, 4), round(frms, 5)))
+            print(f"{name}: worst layer max|d|/rms {worst_max:.4f}, rms(d)/rms {worst_rms:.5f}; per layer {per_layer}")
+            assert worst_max <= LAYER_MAX_FRAC[name] and worst_rms <= LAYER_RMS_FRAC[name], (name, worst_max, worst_rms)
+    finally:
+        ours.set_rows()
+        ours.close()
+
+
+def _synthetic_tiles(n_images, tiles_per_image, seed):
+    """uint8 HWC tiles with structure: each tile a coarse random colour grid (4 .. 14 cells a side) plus a shared noise
+    layer rolled by the tile number -- images differ from one another far more than white noise tiles would"""
+    rng = np.random.default_rng(seed)
+    n = n_images * tiles_per_image
+    noise = rng.integers(-20, 21, size=(224, 224, 3), dtype=np.int16)
+    out = np.empty((n, 224, 224, 3), dtype=np.uint8)
+    for t in range(n):
+        g = int(rng.integers(4, 15))
+        cell = -(-224 // g)
+        grid = rng.integers(0, 256, size=(g, g, 3), dtype=np.int16)
+        big = np.repeat(np.repeat(grid, cell, axis=0), cell, axis=1)[:224, :224]
+        out[t] = np.clip(big + np.roll(noise, t % 224, axis=0), 0, 255).astype(np.uint8)
+    return out
+
+
+def test_retrieval_level_parity_of_both_residual_forms(models):
+    """VERDICT r3 #2c: an index of C5's shape (1 109 images x 13 tiles, uint8) embedded by the HIP image tower in both
+    residual-row forms and by transformers in f32 (torch on the GPU, TF32 off: the f32 oracle of a floating-point
+    kernel), scanned with the same HF text vector: the score error each form adds on top of the bit-exact scan, and what
+    it does to the top-50 image set.  Numbers are printed and recorded in DESIGN section 4."""
+    import torch
+    hf, ours = models
+    n_images, tpi = 1109, 13
+    tiles = _synthetic_tiles(n_images, tpi, seed=5)
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = torch.device("cuda", 0)
+    import copy
+    hf_dev = copy.deepcopy(hf).to(dev)
+    ref = np.empty((tiles.shape[0], 512), dtype=np.float32)
+    with torch.inference_mode():
+        for lo in range(0, tiles.shape[0], 512):
+            t = torch.from_numpy(tiles[lo:lo + 512]).to(dev).to(torch.float32)
+            px = ((t / 255.0 - torch.from_numpy(mean).to(dev)) / torch.from_numpy(std).to(dev)).permute(0, 3, 1, 2).contiguous()
+            f = hf_dev.get_image_features(pixel_values=px)
+            f = f.pooler_output if hasattr(f, "pooler_output") else f
+            ref[lo:lo + 512] = torch.nn.functional.normalize(f, dim=1).cpu().numpy()
+        ids = np.array([[49406, 320, 1125, 539, 320, 2368, 49407]], dtype=np.int64)
+        q = hf.get_text_features(input_ids=torch.from_numpy(ids))
+        q = _unit((q.pooler_output if hasattr(q, "pooler_output") else q).numpy())[0].astype(np.float32)
+    del hf_dev
+    got = {}
+    try:
+        for name, f32_rows in (("bf16_rows", False), ("f32_rows", True)):
+            ours.set_rows(image_bf16=not f32_rows)
+            got[name] = ours.embed_tiles_u8(tiles, normalize=True)
+    finally:
+        ours.set_rows()
+
+    def top50(E):
+        s = (E @ q).reshape(n_images, tpi).max(1)
+        return set(np.argsort(-s, kind="stable")[:50].tolist()), s
+
+    want, s_ref = top50(ref)
+    kth_gap = float(np.sort(s_ref)[::-1][49] - np.sort(s_ref)[::-1][50])
+    report = {}
+    for name, E in got.items():
+        have, s = top50(E)
+        report[name] = dict(cos_min=float((E * ref).sum(1).min()), max_tile_score_delta=float(np.abs(E @ q - ref @ q).max()),
+                            max_image_score_delta=float(np.abs(s - s_ref).max()), top50_overlap=len(have & want))
+    print(f"retrieval parity vs HF f32 (score spread {float(s_ref.std()):.4f}, gap at rank 50 {kth_gap:.2e}): {report}")
+    for name, r in report.items():
+        assert r["cos_min"] >= COS_MIN, (name, r)
+        assert r["max_tile_score_delta"] <= 2.5e-3, (name, r)       # |delta E| <= 5e-3 per component x a unit query, in practice 10x less
+        assert r["top50_overlap"] >= 46, (name, r)                    # what moves sits inside the score error of rank 50's neighbours
+    # Measured (round 4): f32 rows 49 / 50 and |score delta| 4.0e-4, bf16 rows 48 / 50 and 1.5e-3, on scores whose spread is
+    # 6.1e-3 with 1.4e-4 between ranks 50 and 51.  bf16 rows move the set more than f32 rows do, so f32 rows are the
+    # default (VERDICT r3 #2c) and bf16 rows the option; the f32 form is held to the tighter figures.
+    assert report["f32_rows"]["max_tile_score_delta"] <= 8e-4 and report["f32_rows"]["top50_overlap"] >= 48, report
+    assert report["f32_rows"]["max_tile_score_delta"] < report["bf16_rows"]["max_tile_score_delta"], report
+
+
+def test_trained_like_residual_distribution_both_forms(lab_build):
+    """a random-init CLIP has none of the outlier channels / large mean-to-std ratios of a trained residual
+    stream, which is where bf16 rows and the folded LayerNorm's `x W' - mean c1` cancellation lose the most.  Here the
+    pre-LayerNorm of the image tower (and the token embedding of the text tower) puts values of magnitude 60-300 and a
+    non-zero row mean into a few channels of every residual row; both row precisions must still meet the bar."""
+    import torch
+    import transformers
+    from seesaw_amd.models.clip import ClipModel
+    torch.manual_seed(99)
+    hf = transformers.CLIPModel(transformers.CLIPConfig()).eval()
+    with torch.no_grad():
+        pre = hf.vision_model.pre_layrnorm
+        for ch, (g, b) in {5: (30.0, 150.0), 100: (8.0, -60.0), 391: (50.0, 300.0), 767: (1.0, 90.0)}.items():
+            pre.weight[ch] = g
+            pre.bias[ch] = b
+        emb = hf.text_model.embeddings.position_embedding.weight
+        emb[:, 7] += 120.0
+        emb[:, 300] -= 70.0
+        emb[:, 511] += 250.0
+    ours = ClipModel.from_hf(hf)
+    torch.manual_seed(1)
+    x = torch.randn(5, 3, 224, 224)
+    rng = np.random.default_rng(12)
+    ids = rng.integers(0, 49405, size=(4, 33)).astype(np.int64)
+    ids[:, 0], ids[:, -1] = 49406, 49407
+    with torch.inference_mode():
+        hs = hf.vision_model(pixel_values=x, output_hidden_states=True).hidden_states
+        r0 = hs[1].reshape(-1, 768)
+        assert float(r0.abs().max()) > 150 and float((r0.mean(1).abs() / r0.std(1)).max()) > 0.02  # the stream is what the test is for
+        ref_i = hf.get_image_features(pixel_values=x)
+        ref_i = _unit((ref_i.pooler_output if hasattr(ref_i, "pooler_output") else ref_i).numpy())
+        ref_t = hf.get_text_features(input_ids=torch.from_numpy(ids))
+        ref_t = _unit((ref_t.pooler_output if hasattr(ref_t, "pooler_output") else ref_t).numpy())
+    try:
+        for flags in (0, 3):
+            ours.set_rows(image_bf16=bool(flags & 1), text_bf16=bool(flags & 2))
+            gi = ours.embed_image(x.numpy(), normalize=True)
+            gt = _unit(ours.embed_text(ids.astype(np.int32), normalize=False))
+            ci, ct = float((gi * ref_i).sum(1).min()), float((gt * ref_t).sum(1).min())
+            print(f"outlier-channel stream, rows {'bf16/bf16' if flags else 'f32/f32'} (image/text): cos min {ci:.6f} / {ct:.6f}, "
+                  f"|d| max {np.abs(gi - ref_i).max():.2e} / {np.abs(gt - ref_t).max():.2e}")
+            assert ci >= COS_MIN and ct >= COS_MIN, (flags, ci, ct)
+            assert np.abs(gi - ref_i).max() <= ABS_MAX and np.abs(gt - ref_t).max() <= ABS_MAX, flags
+    finally:
+        ours.close()

@@ -104,7 +104,7 @@ def test_c4_hundred_million_rows_properties(DeviceIndex, oracle):
 
 
 @pytest.mark.parametrize("shape", ["gaussian", "sorted", "clustered", "hidden_from_the_sample", "mostly_excluded"])
-def test_sampled_threshold_selection_is_exact(DeviceIndex, shape):
+def test_sampled_threshold_selection_is_exact(DeviceIndex, lab_build, shape):
     """from 2^24 values on the selection takes its threshold from a 1-in-16 sample (blocks of 16 neighbours); whatever
     the sample sees, the answer is the exact top-k in (score desc, position asc) order -- a sample that misleads
     (here: every large value sits where no sampled block looks) ends in the deep path instead"""

@@ -39,7 +39,7 @@ def test_scores_bit_exact_vs_kernel_order_oracle(DeviceIndex, oracle, n, dim):
 
 
 @pytest.mark.parametrize("n", [5, 129, 14417, 40000])
-def test_small_index_scan_kernel_equals_streaming_kernel(DeviceIndex, oracle, n):
+def test_small_index_scan_kernel_equals_streaming_kernel(DeviceIndex, oracle, lab_build, n):
     """under 65 536 rows the scan is the latency-shaped kernel; ssw_tune_scan(-2) forces the streaming one: same bits"""
     from seesaw_amd import _lib
     X = oracle.synth_rows(8, 3, n, 512)
@@ -112,7 +112,7 @@ def test_topk_ragged_images_and_reuse(DeviceIndex, oracle):
 
 
 @pytest.mark.parametrize("tiles", [1, 13])
-def test_small_index_form_equals_general_path(DeviceIndex, oracle, tiles):
+def test_small_index_form_equals_general_path(DeviceIndex, oracle, lab_build, tiles):
     """an index of <= 8192 images runs ssw_index_topk as two launches with pinned, device-mapped query / ids / result;
     switched off (ssw_tune_topk(0)) the same calls take the general path: identical answers, round after round, with the
     list growing, repeated ids, q=None reuse, k beyond what is left, and everything excluded"""

@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from seesaw_amd.models.clip import ClipModel
 from seesaw_amd import _lib
+_lib.debug_hooks().__enter__()
 m = ClipModel.random_init(seed=1234)
 B = 200
 x = torch.randn(B, 3, 224, 224, device="cuda")

@@ -2,7 +2,7 @@
 
   python tools/clip_stream_error.py
 Prints min cosine and max / rms |delta| of the unit vectors for both residual-stream precisions of the tile path
-(ssw_tune_clip: 0 = images bf16, text f32 -- the default; 3 = images f32, text bf16).
+(ssw_clip_set_option, per handle: images bf16, text f32 -- the default; then images f32, text bf16).
 """
 import os
 import sys
@@ -12,7 +12,6 @@ import torch
 import transformers
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from seesaw_amd import _lib  # noqa: E402
 from seesaw_amd.models.clip import ClipModel  # noqa: E402
 
 
@@ -35,11 +34,11 @@ with torch.inference_mode():
     ref_i = unit((ref_i.pooler_output if hasattr(ref_i, "pooler_output") else ref_i).numpy())
     ref_t = hf.get_text_features(input_ids=torch.from_numpy(ids))
     ref_t = unit((ref_t.pooler_output if hasattr(ref_t, "pooler_output") else ref_t).numpy())
-for flags, names in ((0, ("bf16", "f32")), (3, ("f32", "bf16"))):
-    _lib.call("ssw_tune_clip", flags)
+for flags, names in ((0, ("f32", "f32")), (3, ("bf16", "bf16"))):
+    ours.set_rows(image_bf16=bool(flags & 1), text_bf16=bool(flags & 2))
     for what, ref, got, name in (("image 26", ref_i, unit(ours.embed_image(x.numpy(), normalize=False)), names[0]),
                                  ("text 12x77", ref_t, unit(ours.embed_text(ids.astype(np.int32), normalize=False)), names[1])):
         d = np.abs(got - ref)
         print(f"{what}, {name} residual rows: cos min {(got * ref).sum(1).min():.6f}  |delta| max {d.max():.2e} "
               f"rms {np.sqrt((d ** 2).mean()):.2e}", flush=True)
-_lib.call("ssw_tune_clip", 0)
+ours.set_rows()

@@ -6,15 +6,19 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+from seesaw_amd import _lib
 from seesaw_amd.models.clip import ClipModel
 
+if len(sys.argv) > 2:  # GEMM variants are named: the lab build (ssw_tune_gemm lives there); otherwise the product library
+    _lib.debug_hooks().__enter__()
 m = ClipModel.random_init(seed=1234)
+if os.environ.get("SSW_CLIP_ROWS_BF16"):
+    m.set_rows(image_bf16=True)
 dev = torch.device("cuda", 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 x = torch.randn(B, 3, 224, 224, device=dev)
 out = torch.empty(B, 512, device=dev)
 s = torch.cuda.current_stream().cuda_stream
-from seesaw_amd import _lib
 
 variants = [int(v) for v in sys.argv[2:]] or [-1]
 for v in variants:

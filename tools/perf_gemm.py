@@ -9,6 +9,8 @@ import torch  # noqa: F401  (first: its bundled HIP runtime must be the one the 
 
 from seesaw_amd import _lib
 
+_lib.debug_hooks().__enter__()  # the lab build (libseesaw_hip_debug.so): ssw_tune_* / ssw_debug_* live there
+
 SHAPES = [  # (M, N, K, epi, what)
     (10000, 2304, 768, 1, "qkv"),
     (10000, 768, 768, 3, "attn-out"),

@@ -8,6 +8,8 @@ import torch  # noqa: F401
 
 from seesaw_amd import _lib
 
+_lib.debug_hooks().__enter__()  # the lab build (libseesaw_hip_debug.so): ssw_tune_* / ssw_debug_* live there
+
 M, N, K, epi, variant = (int(v) for v in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 20
 lib = _lib.load()

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 from seesaw_amd import _lib
+_lib.debug_hooks().__enter__()  # the lab build (libseesaw_hip_debug.so): ssw_tune_* / ssw_debug_* live there
 from seesaw_amd.device_index import DeviceIndex
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 32_000_000
