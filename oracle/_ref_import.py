@@ -163,6 +163,19 @@ def install():
         inter = wh[:, :, 0] * wh[:, :, 1]
         return inter, a1[:, None] + a2 - inter
 
+    # torchvision.transforms.Normalize, the one transform batch_tx applies (multiscale_tools.py:167-183), per its documented
+    # semantics: output[c] = (input[c] - mean[c]) / std[c], mean / std as tensors of the input's dtype
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, t):
+            mean = torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+            std = torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+            return t.clone().sub_(mean).div_(std)
+
+    sys.modules["torchvision.transforms"].Normalize = Normalize
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     for modname in ("torchvision.ops", "torchvision.ops.boxes"):
         sys.modules[modname].box_area = box_area
         sys.modules[modname]._box_inter_union = _box_inter_union

@@ -1147,7 +1147,57 @@ def gen_multireg_det():
     save("multireg_det", **out)
 
 
-FAMILIES = {"lknn": gen_lknn, "scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
+TILING_SIZES, tiling_image = orc.TILING_SIZES, orc.tiling_image
+
+
+class _TileFrame:
+    """what batch_tx touches of its DataFrame argument -- `.tile.values` (a ray TensorArray: `to_numpy()`) and
+    `.assign(tile=...)` -- around the stand-in TensorArray of _ref_import (ray's pandas extension type is not in this
+    image; the arithmetic between the two calls is the reference's own)"""
+
+    class _Col:
+        def __init__(self, values):
+            self.values = values
+
+    def __init__(self, tiles):
+        ta = sys.modules["ray.data.extensions"].TensorArray
+        self.tile = self._Col(tiles if isinstance(tiles, ta) else ta(tiles))
+
+    def assign(self, tile):
+        return _TileFrame(tile)
+
+
+def gen_tiling():
+    """VERDICT r3 #4 (row f-3): the reference's tiler and tile normalisation on seeded images --
+    generate_multiscale_tiling (seesaw/indices/multiscale/multiscale_tools.py:96-117: pyramid :16-48, strided_tiling
+    :80-94) and batch_tx (:167-183).  Per image: every tile's box, zoom level, scale factor, patch id, a CRC of its
+    pixels and a CRC of its normalised f32 CHW tensor; for the first image the normalised tensor of two tiles in full."""
+    import zlib
+    import pandas as pd
+    import PIL.Image
+    mt = R.ref("seesaw.indices.multiscale.multiscale_tools")
+    out = {"sizes": np.array(TILING_SIZES, dtype=np.int32)}
+    for i, (w, h) in enumerate(TILING_SIZES):
+        arr = tiling_image(w, h, seed=100 + i)
+        for mts, tag in ((224, f"im{i}"),) + (((112, f"im{i}_min112"),) if i in (0, 6) else ()):
+            df = mt.generate_multiscale_tiling(PIL.Image.fromarray(arr), factor=0.5, tile_size=224, min_tile_size=mts)
+            tiles = np.stack([np.asarray(t) for t in df.tile.values])
+            assert tiles.dtype == np.uint8 and tiles.shape[1:] == (224, 224, 3)
+            norm = np.stack(mt.batch_tx(_TileFrame(tiles)).tile.values.to_numpy())
+            assert norm.dtype == np.float32 and norm.shape[1:] == (3, 224, 224)
+            out[f"{tag}_boxes"] = df[["x1", "y1", "x2", "y2"]].to_numpy(dtype=np.float32)
+            out[f"{tag}_zoom_level"] = df.zoom_level.to_numpy(dtype=np.int16)
+            out[f"{tag}_max_zoom_level"] = df.max_zoom_level.to_numpy(dtype=np.int16)
+            out[f"{tag}_scale_factor"] = df.scale_factor.to_numpy(dtype=np.float32)
+            out[f"{tag}_patch_id"] = df.patch_id.to_numpy(dtype=np.int16)
+            out[f"{tag}_tile_crc"] = np.array([zlib.crc32(t.tobytes()) for t in tiles], dtype=np.uint32)
+            out[f"{tag}_norm_crc"] = np.array([zlib.crc32(np.ascontiguousarray(t).tobytes()) for t in norm], dtype=np.uint32)
+            if i == 0 and mts == 224:
+                out["im0_norm_tiles_0_12"] = norm[[0, 12]]
+    save("tiling", **out)
+
+
+FAMILIES = {"tiling": gen_tiling, "lknn": gen_lknn, "scan_topk": gen_scan_topk, "multiscale_query": gen_multiscale_query, "labelprop": gen_labelprop,
             "rank_loss": gen_rank_loss, "logreg": gen_logreg, "multireg": gen_multireg, "bench_loop": gen_bench_loop,
             "multiregneg": gen_multiregneg, "contweighted": gen_contweighted,
             "c5_sequence": gen_c5_sequence, "multireg_det": gen_multireg_det}

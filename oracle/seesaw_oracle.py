@@ -391,3 +391,16 @@ def lknn_top_sum(numerators, denominators, neighbor_ids_sorted, K):
         with np.errstate(invalid="ignore"):
             out[i] = scores[i] * (1 + e[1]) + (1 - scores[i]) * e[0]
     return out
+
+
+# ---- seeded images of the tiling fixture (tests/golden/tiling.npz; oracle/gen_golden.py gen_tiling) ----------------------
+TILING_SIZES = [(640, 480), (224, 224), (500, 375), (1000, 300), (225, 900), (100, 80), (1344, 896)]  # (width, height)
+
+
+def tiling_image(w, h, seed):
+    """a seeded RGB image with structure at several scales (a resize of pure noise would hide an off-by-one in a box)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx // 16 + yy // 16) % 2) * 255], axis=2)
+    noise = rng.integers(-40, 41, size=(h, w, 3))
+    return np.clip(base + noise, 0, 255).astype(np.uint8)

@@ -545,3 +545,22 @@ def test_trained_like_residual_distribution_both_forms(lab_build):
             assert np.abs(gi - ref_i).max() <= ABS_MAX and np.abs(gt - ref_t).max() <= ABS_MAX, flags
     finally:
         ours.close()
+
+
+def test_u8_tile_path_on_the_reference_normalised_tensors(models):
+    """row f-3: the tiles of the tiling fixture's first image (tests/golden/tiling.npz, cut by OUR tiler, CRC-equal to the
+    reference's) through ssw_clip_embed_tiles_u8, against the REFERENCE's batch_tx output for two of them (stored in
+    full in the fixture) through ssw_clip_embed_image: the fused `/255, -mean, /std` of the patch gather gives the same
+    bf16 patches, hence the same embedding bits."""
+    import os
+    import PIL.Image
+    from oracle import seesaw_oracle as orc
+    from seesaw_amd.indices.multiscale.multiscale_tools import generate_multiscale_tiling
+    _, ours = models
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiling.npz"))
+    w, h = orc.TILING_SIZES[0]
+    d = generate_multiscale_tiling(PIL.Image.fromarray(orc.tiling_image(w, h, seed=100)), factor=0.5, tile_size=224, min_tile_size=224)
+    tiles = np.stack(d.tile.values)[[0, 12]]
+    a = ours.embed_tiles_u8(tiles, normalize=True)
+    b = ours.embed_image(np.ascontiguousarray(g["im0_norm_tiles_0_12"]), normalize=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

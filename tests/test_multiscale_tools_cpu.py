@@ -88,3 +88,39 @@ def test_inference_actor_hands_over_1024_tiles_a_call_and_keeps_the_order():
     fake = Fake()
     InferenceActor(fake, batch_size=200)(df.iloc[:450])
     assert fake.calls == [200, 200, 50]
+
+
+def test_tiler_and_batch_tx_against_the_reference_fixture():
+    """tests/golden/tiling.npz holds the REFERENCE's generate_multiscale_tiling + batch_tx output
+    (seesaw/indices/multiscale/multiscale_tools.py:16-117, 167-183) on seeded images of seven sizes -- COCO 640 x 480, one
+    exact tile, 500 x 375, a wide and a tall strip, an image under the tile size, a three-level pyramid -- and two
+    min_tile_size values.  Ours must give the same boxes (f32 bits), levels, scale factors, patch ids, tile pixels and
+    normalised tensors."""
+    import os
+    import zlib
+    import pandas as pd
+    from oracle import seesaw_oracle as orc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tiling.npz"))
+    assert g["sizes"].tolist() == [list(s) for s in orc.TILING_SIZES]
+    n_checked = 0
+    for i, (w, h) in enumerate(orc.TILING_SIZES):
+        img = PIL.Image.fromarray(orc.tiling_image(w, h, seed=100 + i))
+        for mts, tag in ((224, f"im{i}"),) + (((112, f"im{i}_min112"),) if f"im{i}_min112_boxes" in g.files else ()):
+            d = generate_multiscale_tiling(img, factor=0.5, tile_size=224, min_tile_size=mts)
+            boxes = d[["x1", "y1", "x2", "y2"]].to_numpy(dtype=np.float32)
+            assert boxes.shape == g[f"{tag}_boxes"].shape, (tag, boxes.shape)
+            assert np.array_equal(boxes.view(np.uint32), g[f"{tag}_boxes"].view(np.uint32)), tag
+            assert np.array_equal(d.zoom_level.to_numpy(), g[f"{tag}_zoom_level"]) and d.zoom_level.dtype == np.int16
+            assert np.array_equal(d.max_zoom_level.to_numpy(), g[f"{tag}_max_zoom_level"])
+            assert np.array_equal(d.scale_factor.to_numpy(dtype=np.float32).view(np.uint32), g[f"{tag}_scale_factor"].view(np.uint32))
+            assert np.array_equal(d.patch_id.to_numpy(), g[f"{tag}_patch_id"]) and d.patch_id.dtype == np.int16
+            tiles = np.stack(d.tile.values)
+            assert np.array_equal(np.array([zlib.crc32(t.tobytes()) for t in tiles], dtype=np.uint32), g[f"{tag}_tile_crc"]), tag
+            norm = np.stack(batch_tx(pd.DataFrame({"tile": list(tiles)})).tile.values)
+            assert norm.dtype == np.float32 and norm.shape[1:] == (3, 224, 224)
+            crc = np.array([zlib.crc32(np.ascontiguousarray(t).tobytes()) for t in norm], dtype=np.uint32)
+            assert np.array_equal(crc, g[f"{tag}_norm_crc"]), tag
+            if tag == "im0":
+                assert np.array_equal(norm[[0, 12]].view(np.uint32), g["im0_norm_tiles_0_12"].view(np.uint32))
+            n_checked += tiles.shape[0]
+    assert n_checked >= 100
