@@ -404,6 +404,81 @@ def c2_extras(device: int):
     return out
 
 
+def sharded_step_extras(device: int, k: int = 100):
+    """What one rank of the 8-GPU configuration (C4: 12.5 M rows = 25.6 GB per GPU) does per query, MEASURED on one GPU
+    (VERDICT r3 #5c): scan, selection writing the rank's exchange message, the exchange, the merge of eight messages.  The
+    exchange itself cannot be measured on one GPU; it is replaced (a) by a device copy of the rank's own message into the
+    eight slots of the gathered buffer -- the merge then does the work of the real run -- and (b) by the library's own
+    RCCL entry point at world size 1 (ssw_topk_allgather, SSW_C_COMM=1's path, VERDICT r3 #5d), which prices the
+    collective's launch without a peer.  overhead = step - scan kernel."""
+    import ctypes
+    import numpy as np
+    import torch
+    from seesaw_amd import _lib
+    from seesaw_amd.device_index import DeviceIndex, decode_keys
+    from seesaw_amd.sharded import ShardedTopK
+    n, world = 12_500_000, 8
+    dev = torch.device("cuda", device)
+    idx = DeviceIndex.synthetic(n, 512, seed=2024, device=device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    idx.set_stream(stream)
+    out = {"rows": n, "world_emulated": world}
+    qs = torch.from_numpy(np.stack([synth_query(i) for i in range(30)])).to(dev)
+    for kk in (k, 1024):
+        x = ShardedTopK(rank=0, world=world, device=dev, image_offset=0, k_max=max(128, kk), with_best=False)
+        x.attach(idx)
+
+        def step(i, comm):
+            idx.topk_dev(qs[i].data_ptr(), kk)
+            if comm:   # RCCL all-gather of the message at world size 1 (lands in slot 0), then the other seven slots
+                _lib.call("ssw_topk_allgather", x._comm, ctypes.c_void_p(stream), ctypes.c_void_p(x.send_buf.data_ptr()),
+                          ctypes.c_void_p(x.all_buf.data_ptr()), x.msg_len)
+                x.all_buf[1:] = x.send_buf
+            else:
+                x.all_buf[:] = x.send_buf
+            _lib.call("ssw_topk_merge_msgs_dev", device, ctypes.c_void_p(stream), ctypes.c_void_p(x.all_buf.data_ptr()), world,
+                      x.k_max, 0, kk, ctypes.c_void_p(x.out_keys.data_ptr()), ctypes.c_void_p(x.out_count.data_ptr()),
+                      ctypes.c_void_p(x.flags.data_ptr()), ctypes.c_void_p(x.flags_seen.data_ptr()))
+
+        res = {}
+        for comm in (False, True):
+            if comm:
+                try:
+                    world_keep, x.world = x.world, 1   # the communicator has one rank
+                    x.use_c_comm()
+                    x.world = world_keep
+                except Exception as e:
+                    res["c_comm"] = {"error": f"{type(e).__name__}: {e}"}
+                    continue
+            for i in range(5):
+                step(i, comm)
+            torch.cuda.synchronize(dev)
+            idx.profile(True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5, 30):
+                step(i, comm)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            scan_ms = float(np.mean(idx.profile_read()))
+            idx.profile(False)
+            step_ms = e0.elapsed_time(e1) / 25
+            x.assert_no_overflow_seen()
+            c = int(x.out_count.item())
+            imgs, _ = decode_keys(x.out_keys[:c].cpu().numpy().view(np.uint64))
+            res["c_comm" if comm else "device_copy"] = {
+                "step_ms": step_ms, "scan_kernel_ms": scan_ms, "overhead_ms": step_ms - scan_ms,
+                "scan_GBps": n * ROW_BYTES / (scan_ms * 1e-3) / 1e9, "merged_count": c,
+                "distinct_after_merge_of_8_copies": int(np.unique(imgs).shape[0])}
+        x.close_c_comm()
+        out[f"k{kk}"] = res
+    o = out[f"k{k}"].get("device_copy", {})
+    if o:
+        out["predicted_8gpu_vectors_per_s"] = 8 * n / ((o["step_ms"] + 0.02) * 1e-3)  # + ~20 us for the xGMI all-gather (not measurable here)
+    idx.close()
+    return out
+
+
 def fit_extras(device: int):
     """the feedback update alone (MultiReg ce_loss objective, 200 L-BFGS iterations allowed) on labelled sets the size
     a session reaches: the whole step(closure) as one kernel launch against the same fit driven from the host one
@@ -640,6 +715,7 @@ def main():
         if world == 1 and not args.no_extras:
             extras = {}
             for key, fn in (("c2_one_million_rows", lambda: c2_extras(local_rank)),
+                            ("sharded_step_12p5M_rows", lambda: sharded_step_extras(local_rank, k)),
                             ("feedback_fit", lambda: fit_extras(local_rank)),
                             ("feedback_loop", lambda: feedback_loop_extras(local_rank, args.loop_images)),
                             ("clip", lambda: clip_extras(local_rank))):

@@ -89,18 +89,49 @@ def test_c4_hundred_million_rows_properties(DeviceIndex, oracle):
     nxt_imgs, nxt_scores, _ = idx.topk(None, k, excluded=imgs.tolist())
     assert np.array_equal(imgs2k[:k], imgs) and np.array_equal(imgs2k[k:], nxt_imgs)
     assert np.array_equal(bits(scores2k[k:]), bits(nxt_scores))
+    imgs1k, scores1k, _ = idx.topk(None, 1024)
     idx.close()
     del idx
-    # (5) 8 image-range shards, scanned one after the other, merge to the same answer
+    # (5) 8 image-range shards of 12.5 M rows, scanned one after the other, merge to the same answer -- on the host, and
+    # (6) (VERDICT r3 #5b) through the N > 1 step's own pipeline: every shard's selection writes its exchange message
+    # itself (k_final with an exchange target: keys made global, best rows, count | overflow), the eight REAL messages are
+    # stacked as the all-gather would leave them and ssw_topk_merge_msgs_dev merges them, at k = 100 and k = 1024
+    import ctypes
+    from seesaw_amd import _lib
+    from seesaw_amd.device_index import decode_keys
+    from seesaw_amd.sharded import ShardedTopK
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    q_dev = torch.from_numpy(q).cuda()
     parts = []
     per = n // 8
+    k_max = 1024
+    gathered = {kk: ShardedTopK(rank=0, world=8, device=dev, image_offset=0, k_max=k_max, with_best=True) for kk in (k, 1024)}
     for r in range(8):
         shard = DeviceIndex.synthetic(per, 512, seed=seed, first_row=r * per)
         li, ls, _ = shard.topk(q, k)
         parts.append((li + r * per, ls))
+        shard.set_stream(stream)
+        one = ShardedTopK(rank=r, world=8, device=dev, image_offset=r * per, k_max=k_max, with_best=True)
+        one.attach(shard, row_offset=r * per)
+        for kk in (k, 1024):
+            shard.topk_dev(q_dev.data_ptr() if kk == k else 0, kk)  # (the second selection reuses the resident scores)
+            torch.cuda.synchronize()
+            assert int(one.send_buf[-1].item()) == kk                # count kk, overflow flag clear
+            gathered[kk].all_buf[r] = one.send_buf
         shard.close()
     m_imgs, m_scores = _merge(parts, k)
     assert np.array_equal(m_imgs, imgs) and np.array_equal(bits(m_scores), bits(scores))
+    for kk, want_imgs, want_scores in ((k, imgs, scores), (1024, imgs1k, scores1k)):
+        x = gathered[kk]
+        _lib.call("ssw_topk_merge_msgs_dev", 0, ctypes.c_void_p(stream), ctypes.c_void_p(x.all_buf.data_ptr()), 8, k_max, 1, kk,
+                  ctypes.c_void_p(x.out_keys.data_ptr()), ctypes.c_void_p(x.out_count.data_ptr()),
+                  ctypes.c_void_p(x.flags.data_ptr()), ctypes.c_void_p(x.flags_seen.data_ptr()))
+        torch.cuda.synchronize()
+        assert int(x.out_count.item()) == kk and int(x.flags_seen.item()) == 0
+        got_imgs, got_scores = decode_keys(x.out_keys[:kk].cpu().numpy().view(np.uint64))
+        assert np.array_equal(got_imgs, want_imgs) and np.array_equal(bits(got_scores), bits(want_scores)), kk
+        assert np.array_equal(x.best_rows_of(x.out_keys[:kk].cpu().numpy().view(np.uint64)), want_imgs)  # one row per image
 
 
 @pytest.mark.parametrize("shape", ["gaussian", "sorted", "clustered", "hidden_from_the_sample", "mostly_excluded"])
