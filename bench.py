@@ -714,6 +714,11 @@ def main():
         index.close()
         if world == 1 and not args.no_extras:
             extras = {}
+            # libraries underneath print to the process's stdout (RCCL's version banner at communicator creation): the
+            # job's stdout is this function's one JSON line, so file descriptor 1 points at stderr while the extras run
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
             for key, fn in (("c2_one_million_rows", lambda: c2_extras(local_rank)),
                             ("sharded_step_12p5M_rows", lambda: sharded_step_extras(local_rank, k)),
                             ("feedback_fit", lambda: fit_extras(local_rank)),
@@ -723,6 +728,9 @@ def main():
                     extras[key] = fn()
                 except Exception as e:  # the headline metric above stands on its own
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
             out["extras"] = extras
         if replicas is not None:
             out["extras"] = {"feedback_loop_replicas": aggregate_replicas(replicas, world)}
