@@ -69,8 +69,8 @@ ssw_status ssw_debug_gemm_run(int32_t epi, int32_t variant, int32_t M, int32_t N
 ssw_status ssw_debug_attn_out_run(int32_t B, int32_t S, const uint16_t *qkv_bf16, const uint16_t *Wo_bf16, const float *bo,
                                   uint16_t *xcopy_inout, const float *res_in_or_null, float *res_out_or_null,
                                   float *stats_out, float scale);
-/* s_memtime stamps of the last launch of that kernel under SSW_AO_STAMPS=1: out[wg * 8 + slot], slots 0..4 = start, after
- * attention, after the product, after the stores, end */
+/* s_memtime stamps of the last launch of that kernel under SSW_AO_STAMPS=1: out[wg * 32 + slot], slots 0..4 = start, after
+ * attention, after the product, after the stores, end; 8 + 2p / 9 + 2p = head pair p staged / computed */
 ssw_status ssw_debug_attn_out_stamps(uint64_t *out, int32_t n_words);
 
 /* Keep the residual rows behind transformer layer `layer` of tower `tower` (0 image, 1 text; layer -1 = off) of the

@@ -14,10 +14,20 @@
 //            exactly as in the tile GEMM, so the products are the GEMM's bit for bit;
 //   epilogue the residual row is added and the new row written back 16 bytes a lane through LDS, with the row's
 //            LayerNorm partial sums for the fc1 product (two partial pairs a row: columns [0, 384) and [384, 768)).
+// Measured and not kept (round 4, in-kernel stamps): the two phases interleaved per head pair -- attention of pair p and
+// the product's K-steps of pair p - 1 in one iteration, 32 KB of output tiles instead of 96 -- costs the SUM of the two
+// per iteration whichever way the source orders them (7.2 k cycles sequential: the compiler does not move the product's
+// LDS reads across the attention's LDS writes; 8.5-10 k with the product's steps woven between the attention's stages,
+// 26 spilled registers; 30 k+ with the two wave halves in opposite orders, 740 spilled registers): same 72 k cycles a
+// launch as the phases.  What would overlap them is a second instruction stream (waves specialised by role), which the
+// 96 accumulator registers a product wave needs for its 96 columns do not leave room for at eight waves.
 // Replaces, like the kernels it fuses, the attention + out_proj of transformers' CLIPEncoderLayer that the reference
 // calls through HGFaceWrapper.forward (seesaw/models/model.py:50-57).
 #include "ssw_common.h"
 #include <cstdlib>
+#ifndef SSW_AO_AHEAD
+#define SSW_AO_AHEAD 3  // head pairs of Q / K / V requested ahead: 3 (2 is level) ends phase 1 3 k cycles earlier than 4, whose burst delays the first pair
+#endif
 
 namespace ssw {
 namespace {
@@ -50,9 +60,9 @@ __device__ __forceinline__ int so_off(int row, int k0) {
 
 // lab build (SSW_DEBUG_HOOKS, SSW_AO_STAMPS=1): s_memtime at the phase boundaries, wave 0 of every workgroup
 #ifdef SSW_DEBUG_HOOKS
-__device__ unsigned long long g_ao_stamps[1024 * 8];
+__device__ unsigned long long g_ao_stamps[1024 * 32];
 #define AO_STAMP(slot)                                                                                   \
-    if (STAMP && t == 0 && blockIdx.x < 1024) g_ao_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+    if (STAMP && t == 0 && blockIdx.x < 1024) g_ao_stamps[blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memtime();
 #else
 #define AO_STAMP(slot)
 #endif
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
             rr[p][4] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D);
             rr[p][5] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D);
         };
-        constexpr int AHEAD = 4;
+        constexpr int AHEAD = SSW_AO_AHEAD;
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) fetch(p);
         const int ah = wave >> 2, qt = wave & 3;      // attention: head of the pair, query tile
@@ -128,6 +138,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
                 *reinterpret_cast<bf16x8 *>(&stV[v_off(row, c16 >> 1) + (c16 & 1) * 8]) = rr[p][3 * c + 2];
             }
             __syncthreads();
+            AO_STAMP(8 + 2 * p)
             if (p + AHEAD < AO_H / 2) fetch(p + AHEAD);
             const int head = 2 * p + ah;
             if (qt * 16 < S) {  // wave-uniform
@@ -217,6 +228,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
                     *reinterpret_cast<bf16x4 *>(smem + so_off(qt * 16 + fr, k & ~7) + (k & 4) * 2) = z;
                 }
             }
+            AO_STAMP(9 + 2 * p)
             __syncthreads();  // every wave is done with the pair's staging bytes (and, after the last pair, sO is whole)
         }
     }
@@ -243,6 +255,20 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
                 rb[i][it] = *reinterpret_cast<const bf16x8 *>(xcopy + (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8);
             }
     }
+    // f32 rows: 16 rows (this wave's 96 columns: 3 chunks of 32 bytes a lane) at a time, the first block requested here,
+    // the next while a block is added and stored (requested block by block at its use they were four exposed round
+    // trips: 21 k cycles of stores phase against 14 k)
+    f32x4 rf[2][3][2];
+    auto fetch_rf = [&](int i, int set) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
+            const int64_t off = (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8;
+            rf[set][it][0] = *reinterpret_cast<const f32x4 *>(res_in + off);
+            rf[set][it][1] = *reinterpret_cast<const f32x4 *>(res_in + off + 4);
+        }
+    };
+    if constexpr (!BF) fetch_rf(0, 0);
     constexpr int NKS = AO_D / 64;
     static_assert(NKS % PD == 0, "the Wo ring is indexed statically");
     for (int ks0 = 0; ks0 < NKS; ks0 += PD) {
@@ -278,15 +304,8 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         // chunk c = lane + 64 it of the block's 16 rows x 12 chunks of 8 columns
-        f32x4 rf[3][2];
         if constexpr (!BF) {
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
-                const int64_t off = (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8;
-                rf[it][0] = *reinterpret_cast<const f32x4 *>(res_in + off);
-                rf[it][1] = *reinterpret_cast<const f32x4 *>(res_in + off + 4);
-            }
+            if (i + 1 < 4) fetch_rf(i + 1, (i + 1) & 1);
         }
 #pragma unroll
         for (int j = 0; j < AO_NJ; ++j) *reinterpret_cast<f32x4 *>(wl + fr * AO_EROW + j * 64 + fq * 16) = acc[i][j];
@@ -304,8 +323,8 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
                     lo[r] += (float)rb[i][it][r];
                     hi[r] += (float)rb[i][it][4 + r];
                 } else {
-                    lo[r] += rf[it][0][r];
-                    hi[r] += rf[it][1][r];
+                    lo[r] += rf[i & 1][it][0][r];
+                    hi[r] += rf[i & 1][it][1][r];
                 }
                 o[r] = to_bf16(lo[r]);
                 o[4 + r] = to_bf16(hi[r]);

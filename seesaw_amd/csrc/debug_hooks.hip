@@ -224,6 +224,6 @@ extern "C" ssw_status ssw_debug_attn_out_run(int32_t B, int32_t S, const uint16_
 }
 
 extern "C" ssw_status ssw_debug_attn_out_stamps(uint64_t *out, int32_t n_words) {
-    SSW_REQUIRE(out && n_words > 0 && n_words <= 8 * 1024, "ssw_debug_attn_out_stamps: bad arguments");
+    SSW_REQUIRE(out && n_words > 0 && n_words <= 32 * 1024, "ssw_debug_attn_out_stamps: bad arguments");
     return ssw::read_ao_stamps(out, n_words);
 }

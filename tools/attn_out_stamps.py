@@ -1,3 +1,5 @@
+"""in-kernel phase stamps of the fused attention + out-projection launch (lab build, SSW_AO_STAMPS=1):
+   SSW_AO_STAMPS=1 [SSW_CLIP_BF16_STREAM=1] python tools/attn_out_stamps.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,9 +15,12 @@ for _ in range(3):
     m.embed_image_dev(x.data_ptr(), B, out.data_ptr(), True, s)
 torch.cuda.synchronize()
 lib = _lib.load()
-buf = np.zeros(1024 * 8, dtype=np.uint64)
-lib.ssw_debug_attn_out_stamps(buf.ctypes.data_as(ctypes.c_void_p), 1024 * 8)
-st = buf.reshape(1024, 8)[:B, :5].astype(np.int64)
+buf = np.zeros(1024 * 32, dtype=np.uint64)
+lib.ssw_debug_attn_out_stamps(buf.ctypes.data_as(ctypes.c_void_p), 1024 * 32)
+allst = buf.reshape(1024, 32)[:B].astype(np.int64)
+it = allst[:, 8:20] - allst[:, :1]
+print("head pairs, cycles since start [staged, computed] x 6 (median):", np.median(it, axis=0).astype(int).tolist())
+st = allst[:, :5]
 d = np.diff(st, axis=1)
 print("median cycles per phase [attention, product, stores, stats]:", np.median(d, axis=0), "total", np.median(st[:, 4] - st[:, 0]))
 print("p10/p90 total", np.percentile(st[:, 4] - st[:, 0], [10, 90]))
