@@ -57,12 +57,50 @@ class HGWrapper:
         return self.model.embed_image(x, normalize=True)
 
 
+def gen_strided_blocks(vecs, width_size, stride_size, flatten=True):
+    """every width_size x width_size window of the last two axes at the given stride, row-major over (ii, jj), stacked
+    along the batch axis (seesaw/models/embeddings.py:252-281; its `center` switch is hard-wired off there)"""
+    assert flatten
+    h, w = vecs.shape[-2:]
+    iis = list(range(0, h - width_size + 1, stride_size))
+    jjs = list(range(0, w - width_size + 1, stride_size))
+    cuts = [vecs[..., ii:ii + width_size, jj:jj + width_size] for ii in iis for jj in jjs]
+    return np.concatenate(cuts), iis, jjs
+
+
+class SlidingWindow:
+    """the kernel applied to every strided window of ONE image; output [1, *kernel output dims, len(iis), len(jjs)]
+    (seesaw/models/embeddings.py:344-378)"""
+
+    def __init__(self, kernel, kernel_size, stride=None, center=False):
+        self.kernel, self.kernel_size = kernel, kernel_size
+        self.stride = stride if stride is not None else kernel_size
+        self.center = center
+
+    def __call__(self, tensor):
+        return self.forward(tensor)
+
+    def forward(self, tensor):
+        assert tensor.shape[0] == 1, "just do this"
+        assert len(tensor.shape) == 4, "also"
+        input_batch, iis, jjs = gen_strided_blocks(tensor, self.kernel_size, self.stride, flatten=True)
+        output_batch = np.asarray(self.kernel(np.ascontiguousarray(input_batch)))
+        val_shape = output_batch.shape[1:]
+        v = np.moveaxis(output_batch, 0, -1)  # ij last
+        return v.reshape((1,) + val_shape + (len(iis), len(jjs)))
+
+
 class ImageEmbedding:
-    """image side (seesaw/models/model.py:67-89 with add_slide=False): L2-normalised features."""
+    """image side (seesaw/models/model.py:67-89): L2-normalised features of a batch of 224 x 224 tiles, or -- with
+    add_slide, the reference's default outside the indexing job -- of every half-overlapping 224 x 224 window of one
+    larger image (SlidingWindow(kernel_size=224, stride=112))."""
 
     def __init__(self, device=0, jit_path=None, add_slide=False, model: ClipModel = None):
-        assert not add_slide, "sliding-window pooling is not part of the accelerated path"
         self.model = model if model is not None else load_clip(jit_path, device=_device_index(device))
+        self.add_slide = bool(add_slide)
+        kernel_size = 224  # (changes with the variant, model.py:77)
+        self._slide = SlidingWindow(lambda x: self.model.embed_image(x, normalize=True), kernel_size=kernel_size,
+                                    stride=kernel_size // 2, center=True) if add_slide else None
 
     def __call__(self, *, preprocessed_image):
         return self.forward(preprocessed_image=preprocessed_image)
@@ -70,6 +108,8 @@ class ImageEmbedding:
     def forward(self, *, preprocessed_image):
         x = preprocessed_image
         x = x.detach().cpu().float().numpy() if hasattr(x, "detach") else np.asarray(x, dtype=np.float32)
+        if self._slide is not None:
+            return self._slide(x)
         return self.model.embed_image(x, normalize=True)
 
 

@@ -564,3 +564,16 @@ def test_u8_tile_path_on_the_reference_normalised_tensors(models):
     a = ours.embed_tiles_u8(tiles, normalize=True)
     b = ours.embed_image(np.ascontiguousarray(g["im0_norm_tiles_0_12"]), normalize=True)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_image_embedding_with_sliding_window(models):
+    """ImageEmbedding(add_slide=True) (seesaw/models/model.py:78-82): every half-overlapping 224 x 224 window of one image,
+    as [1, 512, len(iis), len(jjs)]; window (i, j)'s vector is the embedding of that crop"""
+    from seesaw_amd.models.embeddings import ImageEmbedding
+    _, ours = models
+    x = np.random.default_rng(2).standard_normal((1, 3, 448, 560)).astype(np.float32)
+    out = ImageEmbedding(model=ours, add_slide=True)(preprocessed_image=x)
+    assert out.shape == (1, 512, 3, 4)
+    for (i, j) in ((0, 0), (1, 2), (2, 3)):
+        crop = np.ascontiguousarray(x[:, :, 112 * i:112 * i + 224, 112 * j:112 * j + 224])
+        assert np.array_equal(out[0, :, i, j].view(np.uint32), ours.embed_image(crop, normalize=True)[0].view(np.uint32))
