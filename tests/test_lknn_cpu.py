@@ -97,3 +97,24 @@ def test_host_fallback_of_the_look_ahead_equals_reference_values(horizon):
             ok = ~np.isnan(ref)
             assert np.array_equal(vals[ok].view(np.uint64), ref[ok].view(np.uint64)), (horizon, rnd)
         model.condition_(int(picks[rnd]), int(truth[int(picks[rnd])]))
+
+
+def test_incremental_order_equals_the_full_argsort():
+    """VERDICT r3 "What's missing" #5: condition_() no longer re-sorts all N scores (the reference's np.argsort per
+    answer, LKNN_model.py:185); the handful of changed nodes is merged back into the descending order.  Against the full
+    argsort over many random updates, including moves to the very top and bottom and repeated nodes."""
+    from seesaw_amd.loops.LKNN_model import _reinsert_sorted
+    rng = np.random.default_rng(0)
+    n = 5000
+    score = rng.random(n)
+    idx = np.argsort(-score)
+    sc = score[idx]
+    for step in range(300):
+        m = int(rng.integers(1, 25))
+        changed = rng.integers(0, n, size=m)                  # may repeat
+        vals = rng.random(m) if step % 7 else rng.choice([-1.0, 2.0], size=m) + rng.random(m) * 1e-9
+        score[changed] = vals                                  # (a repeated node ends with its last value, as numpy assigns)
+        idx, sc = _reinsert_sorted(idx, sc, changed, score)
+        want = np.argsort(-score)
+        assert np.array_equal(idx, want), step
+        assert np.array_equal(sc, score[want])
