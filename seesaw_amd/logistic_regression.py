@@ -17,10 +17,17 @@ def _default_linear_init(dim: int, fit_intercept: bool):
     logistic_regression.py:71), drawn from torch's global generator so torch.manual_seed
     governs it exactly as in the reference."""
     import torch
-    lin = torch.nn.Linear(dim, 1, bias=fit_intercept)
-    w = lin.weight.detach().numpy().reshape(-1).copy()
-    b = lin.bias.detach().numpy().reshape(-1).copy() if fit_intercept else np.zeros(0, np.float32)
-    return np.concatenate([w, b]).astype(np.float32)
+    # nn.Linear.reset_parameters (torch/nn/modules/linear.py): the same two calls on bare tensors -- the same draws from the
+    # generator without building a Module per fit
+    w = torch.empty(1, dim)
+    torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    out = w.numpy().reshape(-1)
+    if fit_intercept:
+        b = torch.empty(1)
+        bound = 1 / math.sqrt(dim) if dim > 0 else 0
+        torch.nn.init.uniform_(b, -bound, bound)
+        out = np.concatenate([out, b.numpy()])
+    return out.astype(np.float32, copy=True)
 
 
 class LogisticRegressionPT:
@@ -37,7 +44,7 @@ class LogisticRegressionPT:
         self.max_iter = int(max_iter)
         self.lr = float(lr)
         self.kwargs = kwargs
-        self.mu_ = None
+        self._mu = None          # column means of the last fit's rows, fetched from the device when somebody asks (mu_)
         self.coef_ = None        # [dim] (+1 with intercept) f32 -- the fitted parameters
         self.losses_ = None
         self.regularizer_vector = None
@@ -54,6 +61,17 @@ class LogisticRegressionPT:
         self._device = device
         self._engine = None
         self._dim = None
+
+    @property
+    def mu_(self):
+        """the column means the rows were centred by (StandardScaler(with_std=False).mean_, logistic_regression.py:299-300)"""
+        if self._mu is None and self._engine is not None:
+            self._mu = self._engine.mean()
+        return self._mu
+
+    @mu_.setter
+    def mu_(self, value):
+        self._mu = value
 
     # ---- helpers ------------------------------------------------------------------------
     def _objective(self, n_examples: int, pos_weight: float) -> FbObjective:
@@ -93,7 +111,7 @@ class LogisticRegressionPT:
             self._engine.set_data(X, center=center)
         else:
             self._engine.set_data_from_index(index, rows, center=center)
-        self.mu_ = self._engine.mean()
+        self._mu = None  # (a 2-KB copy back and a stream wait per fit; the loops only read get_coeff())
         if self.class_weights == "balanced":
             npos, nneg = int((y == 1).sum()), int((y == 0).sum())
             pos_weight = max(nneg, 1) / max(npos, 1)

@@ -48,7 +48,13 @@ def makeXy_rows(lr, sample_size, drawn=None):
             dev = getattr(getattr(lr, "lp", None), "device", None) if getattr(lr, "scores_on_device", lambda: False)() else None
             drawn = permutation_prefix(lr.is_labeled.shape[0] - rows.shape[0], sample_size, device=dev)
         p = drawn
-        pick = p + np.searchsorted(rows - np.arange(rows.shape[0]), p, side="right")  # == nonzero(~is_labeled)[0][p]
+        # == nonzero(~is_labeled)[0][p]: the p-th unlabelled row sits #{j : rows[j] - j <= p} places further on
+        n_unl = lr.is_labeled.shape[0] - rows.shape[0]
+        if n_unl <= 64 * max(int(p.shape[0]), 1):  # small index: a step table over the unlabelled positions and one gather
+            step = np.bincount(rows - np.arange(rows.shape[0]), minlength=n_unl + 1)[:n_unl + 1]
+            pick = p + np.cumsum(step)[p]
+        else:
+            pick = p + np.searchsorted(rows - np.arange(rows.shape[0]), p, side="right")
     else:
         is_labeled = lr.is_labeled > 0
         rows = np.nonzero(is_labeled)[0]
