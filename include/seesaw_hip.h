@@ -348,6 +348,17 @@ ssw_status ssw_fb_destroy(ssw_fb *fb);
 /* labelled vectors X [n, dim] f32 from the host; center != 0 subtracts the column means
  * (StandardScaler(with_std=False) / X - X.mean(0)). */
 ssw_status ssw_fb_set_data(ssw_fb *fb, const float *X_host, int64_t n, int32_t center);
+/* PseudoLR's training set assembled on the device -- makeXy (seesaw/loops/util.py:4-23) + the weights of
+ * seesaw/loops/pseudo_lr.py:42-44: rows = [the labelled rows, then for every p in `drawn` the p-th unlabelled row
+ * (np.nonzero(~is_labeled)[0][p])], targets = [their labels, then the propagated scores of the drawn rows (f64 -> f32)],
+ * sample weights = [real_weight ..., 1 ...]; the vectors are gathered out of the resident matrix and centred as in
+ * ssw_fb_set_data.  dev_scores: ssw_labelprop_device_scores of the propagation that has just run; `drawn`: the prefix of
+ * np.random.permutation(#unlabelled) (ssw_np_permutation_prefix[_dev]).  Replaces the three host passes and four copies
+ * of the same construction through ssw_labelprop_gather + ssw_fb_set_data_from_device + ssw_fb_set_targets; the targets
+ * exist on the device only, so the set serves the logistic objective (SSW_FB_LOGREG), which reads no target on the host. */
+ssw_status ssw_fb_set_pseudo_sample(ssw_fb *fb, const float *dev_matrix, int64_t n_matrix_rows, const double *dev_scores,
+                                    const int64_t *labelled_rows_sorted, const float *labelled_y, int64_t n_lab,
+                                    const int64_t *drawn, int64_t n_drawn, float real_weight, int32_t center);
 /* same, but the rows are gathered on the device out of a resident matrix (e.g. the index:
  * ssw_index_device_ptrs) -- `index.vectors[matchdf.index.values]`, multi_reg.py:204. */
 ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int64_t n_matrix_rows,

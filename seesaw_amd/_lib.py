@@ -82,6 +82,8 @@ _SIGNATURES = {
     "ssw_fb_set_data": (c_i32, [c_void_p, c_void_p, c_i64, c_i32]),
     "ssw_fb_set_data_from_device": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i32]),
     "ssw_fb_set_targets": (c_i32, [c_void_p, c_void_p, c_void_p]),
+    "ssw_fb_set_pseudo_sample": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64,
+                                         ctypes.c_float, c_i32]),
     "ssw_fb_set_query": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_set_prior": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_run_resident": (c_i32, [c_void_p, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, c_i32, c_void_p, c_void_p]),

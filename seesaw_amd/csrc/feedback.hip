@@ -93,6 +93,27 @@ __global__ void k_fb_subtract_mean(float *__restrict__ X, int64_t n, int dim, co
     }
 }
 
+// PseudoLR's sample on the device (ssw_fb_set_pseudo_sample): thread i takes the p-th unlabelled row for p = drawn[i] --
+// p + #{j : th[j] <= p} with th[j] = labelled[j] - j, found by bisection (== np.nonzero(~is_labeled)[0][p]) -- and that row's
+// propagated score as its target; rows / y / row ids land behind the n_lab labelled entries
+__global__ void k_fb_pseudo_rows(const int64_t *__restrict__ th, int n_lab, const int64_t *__restrict__ drawn, int64_t n_drawn,
+                                 const double *__restrict__ scores, int64_t n_scores, int64_t *__restrict__ rows_out,
+                                 float *__restrict__ y_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_drawn) return;
+    const int64_t p = drawn[i];
+    int lo = 0, hi = n_lab;  // first j with th[j] > p
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (th[mid] <= p) lo = mid + 1;
+        else hi = mid;
+    }
+    int64_t pick = p + lo;
+    if (pick >= n_scores) pick = n_scores - 1;  // (the host checked p < #unlabelled: cannot happen)
+    rows_out[n_lab + i] = pick;
+    y_out[n_lab + i] = (float)scores[pick];
+}
+
 // ---- per-evaluation kernels -----------------------------------------------------------
 // Parameters of one closure evaluation, passed BY VALUE in the kernel-argument segment: the driver
 // changes them every evaluation, and a separate 2-KB host-to-device copy per evaluation costs more
@@ -1428,7 +1449,10 @@ struct ssw_fb {
     std::vector<float> y_host, sw_host;
     // pinned staging of the per-round uploads (row ids, targets, query): queued on the stream without a wait -- the fit
     // that follows is stream-ordered behind them (a refine spent ~35 us in three synchronisations here)
-    PinnedStage rows_stage, y_stage, q_stage, coef_stage;
+    PinnedStage rows_stage, y_stage, q_stage, coef_stage, th_stage, drawn_stage;
+    int64_t *th = nullptr, *drawn = nullptr;  // ssw_fb_set_pseudo_sample: labelled[j] - j, the draw
+    int64_t th_cap = 0, drawn_cap = 0;
+    bool targets_on_device = false;           // the targets were formed on the device: y_host holds only the labelled part
     std::vector<float> qhat_host;  // the normalised query (host copy, for the two-output objective's host part)
     // diagnostics of the last fit
     int last_iters = 0, last_evals = 0;
@@ -1496,6 +1520,10 @@ static ssw_status fb_prepare(ssw_fb *fb, const ssw_fb_objective *o, FbObjDev *de
     memset(dev, 0, sizeof(*dev));
     dev->kind = o->kind;
     dev->exact = getenv("SSW_FB_EXACT_LOSS") != nullptr;
+    if (fb->targets_on_device && o->kind != SSW_FB_LOGREG) {
+        set_error("feedback: targets set by ssw_fb_set_pseudo_sample serve the logistic objective only");
+        return SSW_ERR_INVALID;
+    }
     if (o->kind == SSW_FB_LOGREG) {
         // mean over items of weight_i * bce(.; pos_weight)   (logistic_regression.py:98-105)
         for (int64_t i = 0; i < n; ++i) coef[(size_t)i] = fb->sw_host.empty() ? 1.f : fb->sw_host[(size_t)i];
@@ -2054,6 +2082,10 @@ ssw_status ssw_fb_destroy(ssw_fb *fb) {
     if (!fb) return SSW_OK;
     DeviceGuard guard(fb->device);
     if (fb->stream) (void)hipStreamSynchronize(fb->stream);
+    fb->th_stage.release();
+    fb->drawn_stage.release();
+    (void)hipFree(fb->th);
+    (void)hipFree(fb->drawn);
     fb->rows_stage.release();
     fb->y_stage.release();
     fb->q_stage.release();
@@ -2169,10 +2201,76 @@ ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int6
     return SSW_OK;  // no wait: every consumer (the fit, lossgrad, get_mean, scores) is ordered behind this on the stream
 }
 
+ssw_status ssw_fb_set_pseudo_sample(ssw_fb *fb, const float *dev_matrix, int64_t n_matrix_rows, const double *dev_scores,
+                                    const int64_t *labelled_rows_sorted, const float *labelled_y, int64_t n_lab,
+                                    const int64_t *drawn, int64_t n_drawn, float real_weight, int32_t center) {
+    SSW_REQUIRE(fb != nullptr && dev_matrix != nullptr && dev_scores != nullptr && n_lab >= 0 && n_drawn >= 0, "bad argument");
+    SSW_REQUIRE((n_lab == 0 || (labelled_rows_sorted && labelled_y)) && (n_drawn == 0 || drawn), "bad argument");
+    const int64_t n = n_lab + n_drawn, n_unl = n_matrix_rows - n_lab;
+    for (int64_t j = 0; j < n_lab; ++j) {
+        SSW_REQUIRE(labelled_rows_sorted[j] >= 0 && labelled_rows_sorted[j] < n_matrix_rows &&
+                    (j == 0 || labelled_rows_sorted[j] > labelled_rows_sorted[j - 1]), "labelled rows must ascend inside [0, %lld)",
+                    (long long)n_matrix_rows);
+        SSW_REQUIRE(std::isfinite(labelled_y[j]), "target %lld is not finite", (long long)j);
+    }
+    for (int64_t i = 0; i < n_drawn; ++i)
+        SSW_REQUIRE(drawn[i] >= 0 && drawn[i] < n_unl, "draw %lld outside the %lld unlabelled rows", (long long)drawn[i], (long long)n_unl);
+    DeviceGuard guard(fb->device);
+    SSW_TRY(fb_reserve(fb, n));
+    if (n_lab + 1 > fb->th_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+        (void)hipFree(fb->th);
+        fb->th = nullptr;
+        int64_t cap = 1024;
+        while (cap < n_lab + 1) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&fb->th, (size_t)cap * sizeof(int64_t)));
+        fb->th_cap = cap;
+    }
+    if (n_drawn + 1 > fb->drawn_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(fb->stream));
+        (void)hipFree(fb->drawn);
+        fb->drawn = nullptr;
+        int64_t cap = 16384;
+        while (cap < n_drawn + 1) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&fb->drawn, (size_t)cap * sizeof(int64_t)));
+        fb->drawn_cap = cap;
+    }
+    fb->n = n;
+    fb->has_targets2 = false;
+    fb->targets_on_device = true;
+    // host copies for the objective's set-up: the logistic objective reads the weights only
+    fb->y_host.assign((size_t)n, 0.f);
+    fb->sw_host.assign((size_t)n, 1.f);
+    std::vector<int64_t> th((size_t)std::max<int64_t>(n_lab, 1));
+    for (int64_t j = 0; j < n_lab; ++j) {
+        fb->y_host[(size_t)j] = labelled_y[j];
+        fb->sw_host[(size_t)j] = real_weight;
+        th[(size_t)j] = labelled_rows_sorted[j] - j;
+    }
+    if (n > 0) {
+        // labelled part: row ids and targets as ssw_fb_set_data_from_device / ssw_fb_set_targets upload them
+        if (n_lab > 0) {
+            SSW_TRY(fb->rows_stage.push(fb->rows, labelled_rows_sorted, (size_t)n_lab * sizeof(int64_t), fb->stream));
+            SSW_TRY(fb->y_stage.push(fb->y, fb->y_host.data(), (size_t)n_lab * sizeof(float), fb->stream));
+            SSW_TRY(fb->th_stage.push(fb->th, th.data(), (size_t)n_lab * sizeof(int64_t), fb->stream));
+        }
+        if (n_drawn > 0) {
+            SSW_TRY(fb->drawn_stage.push(fb->drawn, drawn, (size_t)n_drawn * sizeof(int64_t), fb->stream));
+            hipLaunchKernelGGL(k_fb_pseudo_rows, dim3((unsigned)((n_drawn + 255) / 256)), dim3(256), 0, fb->stream, fb->th, (int)n_lab,
+                               fb->drawn, n_drawn, dev_scores, n_matrix_rows, fb->rows, fb->y);
+        }
+        hipLaunchKernelGGL(k_fb_gather_rows, dim3((unsigned)n), dim3(128), 0, fb->stream, dev_matrix, fb->rows, n, fb->dim, fb->X);
+        SSW_HIP_TRY(hipGetLastError());
+    }
+    SSW_TRY(fb_center(fb, center));
+    return SSW_OK;  // no wait: the fit is ordered behind this on the stream
+}
+
 ssw_status ssw_fb_set_targets(ssw_fb *fb, const float *y_host, const float *sample_weight_or_null) {
     SSW_REQUIRE(fb != nullptr && (fb->n == 0 || y_host != nullptr), "bad argument");
     DeviceGuard guard(fb->device);
     const int64_t n = fb->n;
+    fb->targets_on_device = false;
     fb->y_host.assign(y_host, y_host + n);
     if (sample_weight_or_null)
         fb->sw_host.assign(sample_weight_or_null, sample_weight_or_null + n);

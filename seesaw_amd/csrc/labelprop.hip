@@ -941,6 +941,11 @@ ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores
         *out_dev_scores = lp->scratch;
         return SSW_OK;
     }
+    {   // the pointer is read by kernels of OTHER handles' streams (the index's re-scoring, the fit's sample): whatever this
+        // handle still has queued -- sweeps turned into no-ops after convergence -- is behind the caller from here on
+        DeviceGuard guard(lp->device);
+        SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    }
     *out_dev_scores = lp->f[lp->last_result];
     return SSW_OK;
 }

@@ -77,6 +77,21 @@ class FeedbackEngine:
         _lib.call("ssw_fb_set_data_from_device", self._h, ctypes.c_void_p(vec_ptr), device_index.n_rows,
                   _p(rows), self.n, int(center))
 
+    def set_pseudo_sample(self, device_index, dev_scores_ptr: int, labelled_rows: np.ndarray, labelled_y: np.ndarray,
+                          drawn: np.ndarray, real_weight: float, center: bool):
+        """PseudoLR's training set put together on the device (ssw_fb_set_pseudo_sample): the labelled rows, then the
+        drawn-th unlabelled rows with their propagated scores as targets; returns the number of rows"""
+        rows = np.ascontiguousarray(labelled_rows, dtype=np.int64)
+        y = np.ascontiguousarray(labelled_y, dtype=np.float32)
+        drawn = np.ascontiguousarray(drawn, dtype=np.int64)
+        assert rows.shape == y.shape
+        vec_ptr, _ = device_index.device_ptrs()
+        self.n = rows.shape[0] + drawn.shape[0]
+        _lib.call("ssw_fb_set_pseudo_sample", self._h, ctypes.c_void_p(vec_ptr), device_index.n_rows,
+                  ctypes.c_void_p(dev_scores_ptr), _p(rows), _p(y), rows.shape[0], _p(drawn), drawn.shape[0],
+                  float(real_weight), int(center))
+        return self.n
+
     def set_targets(self, y: np.ndarray, sample_weight: Optional[np.ndarray] = None):
         y = np.ascontiguousarray(np.asarray(y).reshape(-1), dtype=np.float32)
         assert y.shape[0] == self.n

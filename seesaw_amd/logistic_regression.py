@@ -100,17 +100,23 @@ class LogisticRegressionPT:
                 self._engine.set_query(self.regularizer_vector)
 
     # ---- reference interface ------------------------------------------------------------
-    def fit(self, X, y, sample_weights=None, w0: np.ndarray = None, index=None, rows=None):
-        """X [n, dim] (or `index` + `rows` to gather the vectors on the device), y [n] or [n,1]."""
-        y = np.asarray(y, dtype=np.float64).reshape(-1)
-        n_examples = y.shape[0]
+    def fit(self, X, y, sample_weights=None, w0: np.ndarray = None, index=None, rows=None, pseudo=None):
+        """X [n, dim] (or `index` + `rows` to gather the vectors on the device), y [n] or [n,1].
+        pseudo = (dev_scores_ptr, labelled_rows, labelled_y, drawn, real_weight) with `index`: PseudoLR's set assembled on
+        the device (FeedbackEngine.set_pseudo_sample) -- X, y, sample_weights and rows are not used then."""
         dim = X.shape[1] if X is not None else index.dim
         self._ensure_engine(dim)
         center = self.scale == "centered"
-        if X is not None:
-            self._engine.set_data(X, center=center)
+        if pseudo is not None:
+            assert self.class_weights != "balanced", "the targets of a device-assembled set are not on the host"
+            n_examples = self._engine.set_pseudo_sample(index, *pseudo, center=center)
         else:
-            self._engine.set_data_from_index(index, rows, center=center)
+            y = np.asarray(y, dtype=np.float64).reshape(-1)
+            n_examples = y.shape[0]
+            if X is not None:
+                self._engine.set_data(X, center=center)
+            else:
+                self._engine.set_data_from_index(index, rows, center=center)
         self._mu = None  # (a 2-KB copy back and a stream wait per fit; the loops only read get_coeff())
         if self.class_weights == "balanced":
             npos, nneg = int((y == 1).sum()), int((y == 0).sum())
@@ -122,7 +128,8 @@ class LogisticRegressionPT:
         else:  # warm start, as the reference (which has not implemented it for 'balanced')
             assert self.class_weights != "balanced", "implement this case"
             start = self.coef_
-        self._engine.set_targets(y, sample_weights)
+        if pseudo is None:
+            self._engine.set_targets(y, sample_weights)
         obj = self._objective(n_examples, pos_weight)
         try:
             w, info = self._engine.fit(obj, start, max_iter=self.max_iter, lr=self.lr)

@@ -59,21 +59,33 @@ class PseudoLR(PointBased):
                 drawn = draw_unlabelled(model, self.options["sample_size"], device=lp.device)
             finally:
                 side.result()
-            rows, y, is_real = makeXy_rows(model, sample_size=self.options["sample_size"], drawn=drawn)
         else:
             self.knn_based.refine()
-            rows, y, is_real = makeXy_rows(model, sample_size=self.options["sample_size"])
+            drawn = None
         params = dict(self.log_reg_params)
         params["max_iter"] = int(params.get("max_iter", 100))
-        model = LogisticRegressionPT(regularizer_vector=self.state.tvec, device=getattr(self.index, "device", 0), **params)
-        weights = np.ones_like(y)
-        weights[is_real > 0] = self.real_sample_weight
+        scorer = LogisticRegressionPT(regularizer_vector=self.state.tvec, device=getattr(self.index, "device", 0), **params)
         dev = getattr(self.index, "_dev", None)
-        if dev is not None:
-            model.fit(None, y.reshape(-1, 1), weights.reshape(-1, 1), index=dev, rows=rows)
+        on_device = (dev is not None and lp is not None and getattr(model, "_label_map", None) is not None
+                     and getattr(model, "scores_on_device", lambda: False)() and params.get("class_weights") != "balanced")
+        if on_device:
+            # the training set never exists on the host: labelled rows + labels and the draw go down, the drawn rows'
+            # propagated scores become their targets on the device (ssw_fb_set_pseudo_sample) -- makeXy_rows' values, rows
+            # and order (tests: the reference's pseudo_lr sessions)
+            if drawn is None:
+                drawn = draw_unlabelled(model, self.options["sample_size"], device=lp.device)
+            lab = np.fromiter(sorted(model._label_map), dtype=np.int64, count=len(model._label_map))
+            scorer.fit(None, None, None, index=dev,
+                       pseudo=(lp.device_scores_ptr(), lab, model.labels[lab], drawn, float(self.real_sample_weight)))
         else:
-            model.fit(self.index.vectors[rows], y.reshape(-1, 1), weights.reshape(-1, 1))
-        self.curr_vec = model.get_coeff().reshape(-1)
+            rows, y, is_real = makeXy_rows(model, sample_size=self.options["sample_size"], drawn=drawn)
+            weights = np.ones_like(y)
+            weights[is_real > 0] = self.real_sample_weight
+            if dev is not None:
+                scorer.fit(None, y.reshape(-1, 1), weights.reshape(-1, 1), index=dev, rows=rows)
+            else:
+                scorer.fit(self.index.vectors[rows], y.reshape(-1, 1), weights.reshape(-1, 1))
+        self.curr_vec = scorer.get_coeff().reshape(-1)
 
     def next_batch(self):
         pos, neg = self.q.getXy(get_positions=True)

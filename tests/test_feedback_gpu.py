@@ -370,3 +370,42 @@ def test_single_launch_fit_other_shapes(dim, n):
         assert idev == ihost, (dim, n, idev, ihost)
         assert np.array_equal(wd.view(np.uint32), wh.view(np.uint32)), (dim, n, np.abs(wd - wh).max())
         assert np.isfinite(wd).all()
+
+
+def test_pseudo_sample_assembled_on_the_device_equals_the_host_construction():
+    """round 4: PseudoLR's training set (makeXy, seesaw/loops/util.py:4-23: the labelled rows, then the drawn-th unlabelled
+    rows with their propagated scores as targets; weights of pseudo_lr.py:42-44) put together by ssw_fb_set_pseudo_sample on
+    the device against the same set built on the host and handed over row by row: the fitted coefficients are identical
+    bits -- same rows, same order, same f64 -> f32 rounding of the targets."""
+    import torch
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.logistic_regression import LogisticRegressionPT
+    rng = np.random.default_rng(3)
+    n = 3000
+    X = rng.standard_normal((n, 512)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    idx = DeviceIndex.from_numpy(X)
+    scores = rng.random(n)                                  # the propagated f64 scores, resident on the device
+    dev_scores = torch.from_numpy(scores).cuda()
+    for n_lab, n_draw, first_last in ((1, 10, False), (37, 500, True), (300, 2700, False)):
+        lab = np.sort(rng.choice(n, n_lab, replace=False))
+        if first_last:
+            lab[0], lab[-1] = 0, n - 1                     # labelled rows at both ends of the index
+            lab = np.unique(lab)
+        y_lab = (rng.random(lab.shape[0]) < 0.4).astype(np.float64)
+        drawn = rng.permutation(n - lab.shape[0])[:n_draw].astype(np.int64)
+        unl = np.setdiff1d(np.arange(n), lab)
+        rows = np.concatenate([lab, unl[drawn]])
+        y = np.concatenate([y_lab, scores[unl[drawn]]])
+        w = np.concatenate([np.full(lab.shape[0], 3.0), np.ones(drawn.shape[0])])
+        kw = dict(class_weights=1.0, scale="centered", reg_lambda=1.0, regularizer_vector=None, fit_intercept=False, max_iter=60, lr=1.0)
+        torch.manual_seed(0)
+        a = LogisticRegressionPT(**kw)
+        a.fit(None, y.reshape(-1, 1), w.reshape(-1, 1), index=idx, rows=rows)
+        torch.manual_seed(0)
+        b = LogisticRegressionPT(**kw)
+        b.fit(None, None, None, index=idx, pseudo=(dev_scores.data_ptr(), lab, y_lab, drawn, 3.0))
+        assert a.info_["func_evals"] == b.info_["func_evals"] and a.info_["n_iter"] == b.info_["n_iter"]
+        assert np.array_equal(a.get_coeff().view(np.uint32), b.get_coeff().view(np.uint32)), (n_lab, n_draw)
+        assert np.array_equal(a.mu_.view(np.uint32), b.mu_.view(np.uint32))
+    idx.close()
