@@ -10,7 +10,7 @@ import os
 import re
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libseesaw_hip.so")
+LIB_PATH = os.environ.get("SSW_PRODUCT_LIB") or os.path.join(_PKG_DIR, "libseesaw_hip.so")  # (the override: A/B of builds)
 DEBUG_LIB_PATH = os.environ.get("SSW_DEBUG_LIB") or os.path.join(_PKG_DIR, "libseesaw_hip_debug.so")  # the lab build: same sources + include/seesaw_hip_debug.h
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip.h")
 DEBUG_HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "seesaw_hip_debug.h")

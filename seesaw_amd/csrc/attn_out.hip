@@ -25,6 +25,20 @@
 // calls through HGFaceWrapper.forward (seesaw/models/model.py:50-57).
 #include "ssw_common.h"
 #include <cstdlib>
+#ifndef SSW_AO_NT
+#define SSW_AO_NT 1  // non-temporal: bit 0 the qkv loads (each byte is read once), bit 1 the residual loads, bit 2 the row stores.
+                     // B = 200 forward, f32 rows, two rounds: 0: 2.569 ms, 1: 2.559, 2: 2.63, 3: 2.62, 4: 2.63
+#endif
+template <int BIT, typename V>
+__device__ __forceinline__ V ao_load(const V *p) {
+    if constexpr ((SSW_AO_NT >> BIT) & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int BIT, typename V>
+__device__ __forceinline__ void ao_store(V *p, V v) {
+    if constexpr ((SSW_AO_NT >> BIT) & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 #ifndef SSW_AO_AHEAD
 #define SSW_AO_AHEAD 3  // head pairs of Q / K / V requested ahead: 3 (2 is level) ends phase 1 3 k cycles earlier than 4, whose burst delays the first pair
 #endif
@@ -109,12 +123,12 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
         // version; four pairs are requested up front, the other two as register sets come free
         bf16x8 rr[AO_H / 2][6];
         auto fetch = [&](int p) {
-            rr[p][0] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128);
-            rr[p][1] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + AO_D);
-            rr[p][2] = *reinterpret_cast<const bf16x8 *>(src0 + p * 128 + 2 * AO_D);
-            rr[p][3] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128);
-            rr[p][4] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D);
-            rr[p][5] = *reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D);
+            rr[p][0] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src0 + p * 128));
+            rr[p][1] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src0 + p * 128 + AO_D));
+            rr[p][2] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src0 + p * 128 + 2 * AO_D));
+            rr[p][3] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src1 + p * 128));
+            rr[p][4] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src1 + p * 128 + AO_D));
+            rr[p][5] = ao_load<0>(reinterpret_cast<const bf16x8 *>(src1 + p * 128 + 2 * AO_D));
         };
         constexpr int AHEAD = SSW_AO_AHEAD;
 #pragma unroll
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
                 const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
-                rb[i][it] = *reinterpret_cast<const bf16x8 *>(xcopy + (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8);
+                rb[i][it] = ao_load<1>(reinterpret_cast<const bf16x8 *>(xcopy + (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8));
             }
     }
     // f32 rows: 16 rows (this wave's 96 columns: 3 chunks of 32 bytes a lane) at a time, the first block requested here,
@@ -264,8 +278,8 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
         for (int it = 0; it < 3; ++it) {
             const int c = lane + 64 * it, rl = c / 12, cc = c - rl * 12;
             const int64_t off = (row_base + min(i * 16 + rl, S - 1)) * AO_D + n0 + cc * 8;
-            rf[set][it][0] = *reinterpret_cast<const f32x4 *>(res_in + off);
-            rf[set][it][1] = *reinterpret_cast<const f32x4 *>(res_in + off + 4);
+            rf[set][it][0] = ao_load<1>(reinterpret_cast<const f32x4 *>(res_in + off));
+            rf[set][it][1] = ao_load<1>(reinterpret_cast<const f32x4 *>(res_in + off + 4));
         }
     };
     if constexpr (!BF) fetch_rf(0, 0);
@@ -340,10 +354,10 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
             const int row = i * 16 + rl;
             if (row < S) {
                 const int64_t off = (row_base + row) * AO_D + n0 + cc * 8;
-                *reinterpret_cast<bf16x8 *>(xcopy + off) = o;
+                ao_store<2>(reinterpret_cast<bf16x8 *>(xcopy + off), o);
                 if constexpr (!BF) {
-                    *reinterpret_cast<f32x4 *>(res_out + off) = lo;
-                    *reinterpret_cast<f32x4 *>(res_out + off + 4) = hi;
+                    ao_store<2>(reinterpret_cast<f32x4 *>(res_out + off), lo);
+                    ao_store<2>(reinterpret_cast<f32x4 *>(res_out + off + 4), hi);
                 }
             }
             part[(row * 12 + cc) * 2] = ssum;

@@ -33,6 +33,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
+// epilogue stores, non-temporal or not: bit 0 = the bf16 outputs that leave through LDS (QKV, fc1: 46 / 61 MB that the next
+// kernel reads from whichever XCD it lands on), bit 1 = the producers' residual rows.  Measured at B = 200 (forward, f32 /
+// bf16 rows, same box, two rounds): neither 2.625 / 2.467 ms, bit 0 2.56 / 2.436, bit 1 2.67-2.70 / 2.46, both 2.64 / 2.435.
+#ifndef SSW_NT_STORES
+#define SSW_NT_STORES 1
+#endif
+#ifndef SSW_NT_LOADS
+#define SSW_NT_LOADS 0  // the producers' residual reads non-temporal: measured 2.56 -> 2.64 ms (f32 rows), 2.43 -> 2.45 (bf16): off
+#endif
+template <typename V>
+__device__ __forceinline__ V epi_load(const V *p) {
+    if constexpr (SSW_NT_LOADS != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int BIT, typename V>
+__device__ __forceinline__ void epi_store(V *p, V v) {
+    if constexpr ((SSW_NT_STORES >> BIT) & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // 4 / 5: LayerNorm folded into the product (GemmLn, ssw_common.h) -> bf16 [+ quick-GELU]; 6: +bias +residual -> f32, plus the
 // bf16 copy of the new residual row and its partial LayerNorm statistics for the next product; 7: the same with the
@@ -150,7 +169,7 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x4 (*acc)[NJ], unsig
     for (int it = 0; it < RH * 16 / RPI; ++it) {
         const int row = it * RPI + rr;
         const bf16x8 h = *reinterpret_cast<const bf16x8 *>(wl + row * RB + cc * 16);
-        if (row0 + row < M) *reinterpret_cast<bf16x8 *>(C + (int64_t)(row0 + row) * N + col0 + cc * 8) = h;
+        if (row0 + row < M) epi_store<0>(reinterpret_cast<bf16x8 *>(C + (int64_t)(row0 + row) * N + col0 + cc * 8), h);
     }
 }
 
@@ -552,10 +571,10 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
         for (int it = 0; it < 4; ++it) {  // all four 16-row groups of the stream rows, requested before the LDS round trip
             const int64_t o = (int64_t)min(m0 + wm * 64 + it * 16 + rr, M - 1) * N + col0;
             if constexpr (BF) {
-                resb[it] = *reinterpret_cast<const bf16x8 *>(ln.xcopy + o);
+                resb[it] = epi_load(reinterpret_cast<const bf16x8 *>(ln.xcopy + o));
             } else {
-                resf[it][0] = *reinterpret_cast<const f32x4 *>(residual + o);
-                resf[it][1] = *reinterpret_cast<const f32x4 *>(residual + o + 4);
+                resf[it][0] = epi_load(reinterpret_cast<const f32x4 *>(residual + o));
+                resf[it][1] = epi_load(reinterpret_cast<const f32x4 *>(residual + o + 4));
             }
         }
         __syncthreads();  // another wave may still be reading its last fragments out of these bytes
@@ -596,10 +615,10 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                 }
                 if (m0 + lrow < M) {
                     const int64_t off = (int64_t)(m0 + lrow) * N + col0;
-                    *reinterpret_cast<bf16x8 *>(ln.xcopy + off) = o;
+                    epi_store<1>(reinterpret_cast<bf16x8 *>(ln.xcopy + off), o);
                     if constexpr (!BF) {
-                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off) = lo;
-                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off + 4) = hi;
+                        epi_store<1>(reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off), lo);
+                        epi_store<1>(reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off + 4), hi);
                     }
                 }
                 ssum += __shfl_xor(ssum, 1, 64);
