@@ -39,6 +39,12 @@ __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 #ifndef SSW_NT_STORES
 #define SSW_NT_STORES 1
 #endif
+// the staggered K loop below (waves 4-7 half a K-step behind waves 0-3): bit-identical embeddings, B = 200 forward 2.592 ->
+// 2.603 ms (f32 rows), 2.463 -> 2.476 (bf16 rows), three rounds -- with two workgroups a CU a SIMD's four waves drift apart
+// by themselves; kept behind the switch
+#ifndef SSW_GEMM_STAGGER
+#define SSW_GEMM_STAGGER 0
+#endif
 #ifndef SSW_NT_LOADS
 #define SSW_NT_LOADS 0  // the producers' residual reads non-temporal: measured 2.56 -> 2.64 ms (f32 rows), 2.43 -> 2.45 (bf16): off
 #endif
@@ -486,6 +492,52 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
+    } else if (SSW_GEMM_STAGGER && DEPTH == 2 && NW == 8 && wave >= NW / 2) {
+        // Stagger (MICROARCH guide, "Two waves per SIMD", item 9): waves 4-7 run half a K-step behind waves 0-3 -- the second
+        // 32-deep half of stage kt - 1 is multiplied from registers (its fragments were read before the barrier) while waves
+        // 0-3 read their first fragments of stage kt, and so on in anti-phase: one half's LDS reads beside the other half's
+        // MFMAs instead of both reading, then both queueing on the matrix pipe.  Every accumulator still adds its halves in
+        // the order (kt, 0), (kt, 1), (kt + 1, 0) ...: same bits.
+        SSW_ISSUE(0, 0)
+        int buf = 0, nxt = 1;
+        bf16x8 a1[4], b1[NJ];
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) SSW_ISSUE(kt + 1, nxt)
+            if (kt > 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+            }
+            const unsigned char *sb = smem + buf * STAGE;
+            {
+                bf16x8 a0[4], b0[NJ];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const bf16x8 *>(sb + (a_frag + i * 2048));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b0[j] = *reinterpret_cast<const bf16x8 *>(sb + (w_frag + j * 2048));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bf16x8 *>(sb + ((a_frag + i * 2048) ^ 64));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b1[j] = *reinterpret_cast<const bf16x8 *>(sb + ((w_frag + j * 2048) ^ 64));
+            // the fragments of this stage's second half are in registers before the next barrier lets the stage be restaged
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            asm volatile("" ::: "memory");
+            buf ^= 1;
+            nxt ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s)
