@@ -24,6 +24,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/text_trace" -o tex
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn -- \
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
+# tower GEMM shapes against hipBLASLt (lab build: ssw_debug_gemm), and the fused attention launch's in-kernel phase stamps
+python3 tools/perf_gemm.py 15 14 --lib > "$OUT/gemm_ab.txt" 2> "$OUT/gemm_ab.err" || true
+( echo "# f32 rows (default)"; SSW_AO_STAMPS=1 python3 tools/attn_out_stamps.py; echo "# bf16 rows"; SSW_AO_STAMPS=1 SSW_CLIP_BF16_STREAM=1 python3 tools/attn_out_stamps.py ) 2>/dev/null | grep -v amdgpu > "$OUT/attn_out_stamps.txt" || true
+
 python3 tools/make_traffic_json.py "$OUT" 100000000 > "$OUT/traffic.log" 2>&1   # -> profiles/traffic.json (stamp git locally)
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"   # after the PMC passes: its roofline.traffic reads the file just made
 python3 tools/summarise_pmc.py "$OUT/bench_fetch" scan_scores > "$OUT/fetch_summary.csv"
@@ -36,5 +40,7 @@ cp "$OUT/bench_trace/bench_kernel_stats.csv" "profiles/${R}_bench_100M_kernel_st
 cp "$OUT/clip_trace/clip_kernel_stats.csv" "profiles/${R}_clip_b200_kernel_stats.csv"
 cp "$OUT/knn_trace/knn_kernel_stats.csv" "profiles/${R}_knn_1560k_kernel_stats.csv"
 cp "$OUT/text_trace/text_kernel_stats.csv" "profiles/${R}_clip_text_1x8_kernel_stats.csv"
+cp "$OUT/gemm_ab.txt" "profiles/${R}_gemm_ab.txt"
+cp "$OUT/attn_out_stamps.txt" "profiles/${R}_attn_out_stamps.txt"
 for f in profiles/${R}_*; do cp "$f" "gpurun_out/collect/$(basename "$f")"; done   # the box's profiles/ does not travel back
 echo "summaries copied to gpurun_out/collect/: move them to profiles/ and run tools/make_traffic_json.py --stamp-git"
