@@ -42,6 +42,12 @@ __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 // the staggered K loop below (waves 4-7 half a K-step behind waves 0-3): bit-identical embeddings, B = 200 forward 2.592 ->
 // 2.603 ms (f32 rows), 2.463 -> 2.476 (bf16 rows), three rounds -- with two workgroups a CU a SIMD's four waves drift apart
 // by themselves; kept behind the switch
+// LDS-DMA with the address as SGPR tile base + 32-bit lane offset (saddr form) instead of a 64-bit pointer per lane:
+// identical embeddings, B = 200 forward 2.490 -> 2.486 ms over three rounds (noise); the piece's issue cost is not its
+// address registers.  Kept behind the switch.
+#ifndef SSW_GEMM_SADDR
+#define SSW_GEMM_SADDR 0
+#endif
 #ifndef SSW_GEMM_STAGGER
 #define SSW_GEMM_STAGGER 0
 #endif
@@ -344,6 +350,23 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 
     // staging: a piece is 8 rows x 128 B (one wave-instruction); lane l lands at row l / 8, chunk
     // position l % 8 and therefore fetches chunk (l % 8) ^ swz(row)
+#if SSW_GEMM_SADDR
+    // saddr form: a wave-uniform tile base in SGPRs + a 32-bit byte offset per lane (a tile spans < 2^32 bytes)
+    const bf16 *const a_base = A + (int64_t)m0 * K, *const w_base = W + (int64_t)n0 * K;
+    unsigned a_off[AP], w_off[WP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int row = (wave * AP + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_off[i] = (unsigned)(((int64_t)(min(m0 + row, M - 1) - m0) * K + chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int row = (wave * WP + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)(((int64_t)row * K + chunk * 8) * 2);
+    }
+#else
     const bf16 *a_src[AP];
     const bf16 *w_src[WP];
 #pragma unroll
@@ -358,9 +381,20 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         w_src[i] = W + (int64_t)(n0 + row) * K + chunk * 8;
     }
+#endif
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)smem);
     const unsigned a_dst = lds0 + wave * (AP * 1024);
     const unsigned w_dst = lds0 + AIMG + wave * (WP * 1024);
+#if SSW_GEMM_SADDR
+#define SSW_ISSUE(kt, buf)                                                                 \
+    {                                                                                      \
+        const bf16 *const ab = a_base + (kt) * BK, *const wb = w_base + (kt) * BK;         \
+        _Pragma("unroll") for (int i = 0; i < AP; ++i)                                     \
+            glds16s(a_off[i], ab, a_dst + (buf) * STAGE + i * 1024);                       \
+        _Pragma("unroll") for (int i = 0; i < WP; ++i)                                     \
+            glds16s(w_off[i], wb, w_dst + (buf) * STAGE + i * 1024);                       \
+    }
+#else
 #define SSW_ISSUE(kt, buf)                                                                 \
     {                                                                                      \
         const int k0 = (kt) * BK;                                                          \
@@ -369,6 +403,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
         _Pragma("unroll") for (int i = 0; i < WP; ++i)                                     \
             SSW_GLDS16(w_src[i] + k0, w_dst + (buf) * STAGE + i * 1024);                   \
     }
+#endif
 
     const int fr = lane & 15, fq = lane >> 4;
     // The accumulators start from the bias.  (Starting them from bias + residual as well was measured:
