@@ -2559,6 +2559,7 @@ ssw_status ssw_fb_reset(ssw_fb *fb) {
     fb->n = 0;
     fb->has_q = fb->has_xlx = false;
     fb->has_targets2 = false;
+    fb->targets_on_device = false;
     fb->y_host.clear();
     fb->sw_host.clear();
     fb->last_iters = fb->last_evals = 0;
