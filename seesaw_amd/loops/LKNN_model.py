@@ -3,7 +3,9 @@
 p_i = (gamma_i + sum of the labels of i's labelled neighbours) / (1 + number of labelled neighbours).  The state is
 three host arrays (numerators, denominators, gamma) over the nodes and the CSR neighbour lists; conditioning on a
 label touches one row of neighbours.  What is expensive in the reference -- the look-ahead value of every node,
-an N x (K + 2D) argsort per planning step -- runs on the GPU (`top_sum`, ssw_lknn_top_sum)."""
+an N x (K + 2D) argsort per planning step -- runs on the GPU (`top_sum`, ssw_lknn_top_sum).  The descending order of the
+scores is sorted in full only where the scores are new as a whole (from_dataset, with_gamma: once per text query);
+after an answer (condition_) the handful of changed nodes is merged back into it."""
 from __future__ import annotations
 
 import ctypes
