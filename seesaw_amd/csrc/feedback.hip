@@ -165,6 +165,12 @@ __device__ __forceinline__ double bce_item(double z, double y, double lw, bool e
     return (1.0 - y) * z - (double)weighted;
 }
 
+__device__ __forceinline__ double bce_lw(float pw, double y) { return 1.0 + ((double)pw - 1.0) * y; }  // the item's log-weight
+// d loss / d logit of one BCE item, rounded to f32 like torch's (one body for every site that forms it)
+__device__ __forceinline__ float bce_dz(double z, double y, double c, double lw) {
+    return (float)(c * ((1.0 - y) - lw * sigmoidd(-z)));
+}
+
 // elementwise BCE-with-logits with pos_weight pw and per-item coefficient c_i:
 //   l = c [ (1-y) z + (1 + (pw-1) y) softplus(-z) ],  dl/dz = c [ (1-y) - (1 + (pw-1) y) sigmoid(-z) ]
 __global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__ y,
@@ -173,9 +179,9 @@ __global__ void k_fb_elem(const float *__restrict__ z, const float *__restrict__
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double zi = z[i], yi = y[i], ci = coef[i];
-    const double lw = 1.0 + ((double)pw - 1.0) * yi;
+    const double lw = bce_lw(pw, yi);
     item_loss[i] = ci * bce_item(zi, yi, lw, exact != 0);
-    r[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+    r[i] = bce_dz(zi, yi, ci, lw);
 }
 
 // k_fb_logits with the parameters in the argument segment and, when `elem` is set, k_fb_elem folded in
@@ -221,9 +227,9 @@ __global__ __launch_bounds__(256) void k_fb_logits_arg(const float *__restrict__
         z[row] = zf;
         if (elem) {
             const double zi = zf, yi = y[row], ci = coef[row];
-            const double lw = 1.0 + ((double)pw - 1.0) * yi;
+            const double lw = bce_lw(pw, yi);
             item_loss[row] = ci * bce_item(zi, yi, lw, elem == 2);
-            r[row] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+            r[row] = bce_dz(zi, yi, ci, lw);
         }
     }
 }
@@ -767,6 +773,7 @@ struct FitWgArgs {
     unsigned seqno;
     int n, dim, P;               // P = trainable parameters (dim or dim + 1)
     int label_mode;              // 0 elementwise BCE, 1 pairwise hinge, 2 pairwise logistic, 3 identically zero
+    int onepass;                 // fit_eval_onepass instead of the logits / labels / gradient phases (same bits)
     float pw, margin;
     int max_iter;
     float lr;
@@ -783,14 +790,16 @@ struct FitDriver {  // the L-BFGS / line-search scalars of k_fb_fit_wg's driving
 
 // ---- LDS map of k_fb_fit_wg (the launch sizes the allocation with fit_wg_lds_bytes)
 __host__ __device__ inline size_t fit_wg_vec_stride(int dim) { return dim + 1 <= 9 * 64 ? 9 * 64 : 16 * 64; }  // FIT_EPL * 64
-__host__ __device__ inline size_t fit_wg_stage_floats(int dim) {
+constexpr int FIT_OP_ROWS = 16, FIT_OP_BUFS = 3, FIT_OP_DIM = 512;  // fit_eval_onepass: units of rows staged in LDS
+__host__ __device__ inline size_t fit_wg_stage_floats(int dim, bool onepass) {
     const size_t a = (size_t)FIT_ROUND_SLABS * dim, b = (size_t)3 * FIT_WG_MAX_ROWS;
-    return a > b ? a : b;
+    const size_t c = onepass ? (size_t)FIT_OP_BUFS * FIT_OP_ROWS * FIT_OP_DIM : 0;
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 constexpr size_t FIT_LDS_DOUBLES = 64 + 16 + 2 * FIT_HISTORY + 2 + 2 + 32 + 8 + FIT_WG_MAX_ROWS + 32 /* FitWgArgs */;
-__host__ __device__ inline size_t fit_wg_lds_bytes(int dim) {
+__host__ __device__ inline size_t fit_wg_lds_bytes(int dim, bool onepass) {
     const size_t floats = 1024 /*sw*/ + 1040 /*gout*/ + 4 * FIT_WG_MAX_ROWS /*z r y coef*/ + 1024 /*qhat*/ +
-                          7 * fit_wg_vec_stride(dim) + fit_wg_stage_floats(dim);
+                          7 * fit_wg_vec_stride(dim) + fit_wg_stage_floats(dim, onepass);
     return FIT_LDS_DOUBLES * sizeof(double) + floats * sizeof(float);
 }
 // pointers read back from the LDS copy of the arguments are generic to the compiler (flat loads, 64-bit address
@@ -815,7 +824,7 @@ struct FitLds {
     float *zl, *rl, *yl, *cl;  // [FIT_WG_MAX_ROWS] logits, d loss / d logit, targets, per-item coefficients
     float *qh;          // [dim] unit query
     float *vx, *vd, *vg, *vpg, *vgp, *vb0, *vb1;  // L-BFGS vectors, [FIT_EPL * 64] each, zero beyond element dim
-    float *stage;       // pairwise staging [3 n] / partial gradients [FIT_ROUND_SLABS, dim]
+    float *stage;       // pairwise staging [3 n] / partial gradients [FIT_ROUND_SLABS, dim] / fit_eval_onepass's row units
 };
 __device__ __forceinline__ FitLds fit_lds_map(double *base, int dim) {
     static_assert(sizeof(FitDriver) <= 32 * sizeof(double), "FitDriver outgrew its LDS slot");
@@ -935,9 +944,9 @@ __device__ __noinline__ void fit_eval_labels(double *base, int dim_) {
     if (a.label_mode == 0) {
         for (int i = c; i < n; i += 1024) {
             const double zi = zl[i], yi = yl[i], ci = cl[i];
-            const double lw = 1.0 + ((double)a.pw - 1.0) * yi;
+            const double lw = bce_lw(a.pw, yi);
             item[i] = ci * bce_item(zi, yi, lw, a.obj.exact != 0);
-            rl[i] = (float)(ci * ((1.0 - yi) - lw * sigmoidd(-zi)));
+            rl[i] = bce_dz(zi, yi, ci, lw);
         }
     } else if (a.label_mode == 1) {
         fb_pairwise_body<0>(zl, yl, cl, a.margin, n, item, rl, stage);
@@ -1008,6 +1017,225 @@ __device__ __noinline__ float fit_eval_grad(double *base, int dim_) {
         }
     }
     return gcol;
+}
+
+// The three phases above in ONE pass over the rows (elementwise BCE, dim = 512): the rows are what an evaluation
+// costs -- a CU pulls them from L2 at ~110 GB/s, and the logits and the gradient each walked them once.  Here a
+// unit of 16 rows is loaded once, by the waves that take its logits (lane k the float4s k and k + 64 of a row --
+// fit_eval_logits' assignment, so the fma chain and the butterfly's additions are the same), and copied to LDS on
+// the way for the gradient chain, which needs it two barriers later.  The waves have roles:
+//     stage s :  waves 4-11  loads of unit s + 2 issued; logits of unit s (two rows a wave), its rows to LDS
+//                wave 12     d loss / d logit of unit s - 1 (one f64 exp + divide chain for its 16 rows; on the
+//                            logit waves it was 16 wave-wide chains a stage and three times the rows' time)
+//                waves 0-3   gradient chain of unit s - 2 from LDS, two columns a thread
+// Three row units of 32 KB rotate through LDS.  Every sum keeps its order: a row's logit is the lane chain + xor
+// butterfly (v_permlane32/16_swap and row_ror DPP adds form the butterfly's sums without its six LDS round trips);
+// a column's slab sum is the fma chain over the slab's rows in row order (a thread keeps it across the slab's two
+// units); the slab sums are added in slab order.  The per-item loss values (exp + log1p) are not on the gradient's
+// path and are taken after the last unit for all rows at once.  Returns column threadIdx.x's gradient sum.
+// Measured (390 rows, tools/perf_fit.py): 15.3 us an evaluation for what took 7.3 + 1.4 + 9.5 = 18.2; a stage is
+// ~1260 cycles whatever is taken out of it (no row loads, no f64 chain, no butterfly: 33-35 k cycles a pass each
+// time): each role is a latency chain of 800-1000 cycles -- exp + divide in f64, LDS round trips, the wait for the
+// rows -- and the barrier adds ~250, i.e. 78 cycles a row against the two passes' 112 and the rows' own 45.
+__device__ __forceinline__ float fit_xor_butterfly(float a) {  // a += shfl_xor(a, off), off = 32 ... 1: the same additions
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+        a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    a += dpp_take_f<0x128>(a);  // row_ror 8, 4, 2, 1: the values repeat with that period by then, so a rotation is the xor
+    a += dpp_take_f<0x124>(a);
+    a += dpp_take_f<0x122>(a);
+    a += dpp_take_f<0x121>(a);
+    return a;
+}
+
+#ifndef SSW_FIT_STAMPS
+#define SSW_FIT_STAMPS 0  // diagnostic builds: 1 busy cycles per evaluation of a logit wave, the d loss / d logit wave and a gradient wave; 2 an idle wave's entry -> last stage -> return
+#endif
+__device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
+    long long t_entry = 0;
+    if (SSW_FIT_STAMPS == 2) t_entry = clock64();
+    const FitLds S = fit_lds_map(base, dim_);
+    const FitWgArgs &a = *S.args;
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const int n = a.n;
+    constexpr int D = FIT_OP_DIM, D4 = FIT_OP_DIM / 4;
+    static_assert(FIT_OP_ROWS == 16 && FIT_OP_BUFS == 3 && FB_SLAB == 2 * FIT_OP_ROWS, "roles and rotation below");
+    float *rows = S.stage;  // [FIT_OP_BUFS][FIT_OP_ROWS][D]
+    float *zl = S.zl, *rl = S.rl, *yl = S.yl, *cl = S.cl;
+    // (Spreading the roles over the SIMDs by their VALU cost -- the f64 wave alone with one logit wave -- measured
+    // slower: 429 against 397 us of data phases per fit at 390 rows.)
+    const bool gwave = wave < 4, zwave = wave >= 4 && wave < 12, rwave = wave == 12;
+    const int zslot = wave - 4;
+    const int gi = c;  // a gradient thread takes columns 2 gi, 2 gi + 1
+    const int zrow = 2 * zslot;  // a logit wave's first row inside the unit
+    float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
+    if (zwave) {
+        wa = reinterpret_cast<const float4 *>(S.sw_)[lane];
+        wb = reinterpret_cast<const float4 *>(S.sw_)[lane + 64];
+    }
+    const float bias = a.obj.has_bias ? S.sw_[D] : 0.f;
+    const int H = (n + FIT_OP_ROWS - 1) / FIT_OP_ROWS;
+    const fit_g4ptr X4 = (fit_g4ptr)a.X;
+    long long busy = 0;
+    float g0 = 0.f, g1 = 0.f;
+    // A loop per role, H + 2 barriers each.  (One loop with the roles as branches made the compiler wait for every
+    // load in flight before it issued the next unit's: the row loads must stay two stages ahead.)
+    if (zwave) {
+        // The row loads and their waits are written out (inline asm): left to the compiler, the wait-count pass drained
+        // every load in flight at the loop header -- once per three stages no load was in flight, and the rows' stream
+        // is what bounds a stage.  Four loads a stage, in order; a stage consumes the set issued two stages earlier,
+        // i.e. it waits until at most eight newer loads are outstanding.
+#ifndef SSW_FIT_PF
+#define SSW_FIT_PF 2  // units of rows in flight ahead of the one a stage consumes
+#endif
+        constexpr int PF = SSW_FIT_PF, NS = PF + 1;
+        fit_v4f xl[NS][2], xh[NS][2];
+        auto load = [&](int s, fit_v4f(&lo)[2], fit_v4f(&hi)[2]) {  // s beyond the last unit: the last unit again, unused
+            s = s < H ? s : H - 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int row = FIT_OP_ROWS * s + zrow + u;
+                row = row < n ? row : n - 1;
+                const fit_g4ptr src = X4 + (int64_t)row * D4 + lane;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lo[u]) : "v"(src) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(hi[u]) : "v"(src) : "memory");
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < PF; ++q) load(q, xl[q], xh[q]);
+        for (int s0 = 0; s0 < H; s0 += NS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int s = s0 + j;
+                if (s >= H) break;
+                long long tb = 0;
+                if (SSW_FIT_STAMPS == 1) tb = clock64();
+                load(s + PF, xl[(j + PF) % NS], xh[(j + PF) % NS]);
+                static_assert(PF == 2 || PF == 3, "the wait below names the count");
+                if (PF == 2)
+                    asm volatile("s_waitcnt vmcnt(8)" : "+v"(xl[j][0]), "+v"(xh[j][0]), "+v"(xl[j][1]), "+v"(xh[j][1])::"memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(12)" : "+v"(xl[j][0]), "+v"(xh[j][0]), "+v"(xl[j][1]), "+v"(xh[j][1])::"memory");
+                float acc[2];
+                float *buf = rows + (size_t)(s % 3) * FIT_OP_ROWS * D;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const fit_v4f x0 = xl[j][u], x1 = xh[j][u];
+                    float t = 0.f;
+                    t = fmaf(x0.x, wa.x, t);
+                    t = fmaf(x0.y, wa.y, t);
+                    t = fmaf(x0.z, wa.z, t);
+                    t = fmaf(x0.w, wa.w, t);
+                    t = fmaf(x1.x, wb.x, t);
+                    t = fmaf(x1.y, wb.y, t);
+                    t = fmaf(x1.z, wb.z, t);
+                    t = fmaf(x1.w, wb.w, t);
+                    acc[u] = t;
+                    float *dst = buf + (size_t)(zrow + u) * D;
+                    *reinterpret_cast<fit_v4f *>(dst + 4 * lane) = x0;
+                    *reinterpret_cast<fit_v4f *>(dst + 256 + 4 * lane) = x1;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float z = fit_xor_butterfly(acc[u]) + bias;
+                    const int row = FIT_OP_ROWS * s + zrow + u;
+                    if (lane == 0 && row < n) zl[row] = z;
+                }
+                if (SSW_FIT_STAMPS == 1) busy += clock64() - tb;
+                __syncthreads();
+            }
+        }
+        // the loads still in flight land in registers the compiler would otherwise hand out again
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xl[q][0]), "+v"(xh[q][0]), "+v"(xl[q][1]), "+v"(xh[q][1])::"memory");
+        __syncthreads();
+        __syncthreads();
+    } else if (rwave) {
+        for (int s = 0; s < H + 2; ++s) {
+            long long tb = 0;
+            if (SSW_FIT_STAMPS == 1) tb = clock64();
+            const int row = FIT_OP_ROWS * (s - 1) + lane;
+            if (s >= 1 && s - 1 < H && lane < FIT_OP_ROWS && row < n) {
+                const double yi = yl[row], ci = cl[row];
+                rl[row] = bce_dz((double)zl[row], yi, ci, bce_lw(a.pw, yi));
+            }
+            if (SSW_FIT_STAMPS == 1) busy += clock64() - tb;
+            __syncthreads();
+        }
+    } else if (gwave) {
+        float p0 = 0.f, p1 = 0.f;
+        for (int s = 0; s < H + 2; ++s) {
+            long long tb = 0;
+            if (SSW_FIT_STAMPS == 1) tb = clock64();
+            if (s >= 2) {
+                const int u = s - 2, r0 = FIT_OP_ROWS * u;
+                const float *src = rows + (size_t)(u % 3) * FIT_OP_ROWS * D + 2 * gi;
+                if (r0 + FIT_OP_ROWS <= n) {
+                    float rr[FIT_OP_ROWS];  // the unit's sixteen rows in flight together: one LDS latency, not two
+                    float2 xv[FIT_OP_ROWS];
+#pragma unroll
+                    for (int q = 0; q < FIT_OP_ROWS / 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4 *>(rl + r0 + 4 * q);
+                        rr[4 * q + 0] = t.x;
+                        rr[4 * q + 1] = t.y;
+                        rr[4 * q + 2] = t.z;
+                        rr[4 * q + 3] = t.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < FIT_OP_ROWS; ++i) xv[i] = *reinterpret_cast<const float2 *>(src + (size_t)i * D);
+#pragma unroll
+                    for (int i = 0; i < FIT_OP_ROWS; ++i) {
+                        p0 = fmaf(rr[i], xv[i].x, p0);
+                        p1 = fmaf(rr[i], xv[i].y, p1);
+                    }
+                } else {
+                    for (int i = 0; r0 + i < n; ++i) {
+                        const float2 xv = *reinterpret_cast<const float2 *>(src + (size_t)i * D);
+                        const float ri = rl[r0 + i];
+                        p0 = fmaf(ri, xv.x, p0);
+                        p1 = fmaf(ri, xv.y, p1);
+                    }
+                }
+                if ((u & 1) || u == H - 1) {  // the slab is complete
+                    g0 += p0;
+                    g1 += p1;
+                    p0 = 0.f;
+                    p1 = 0.f;
+                }
+            }
+            if (SSW_FIT_STAMPS == 1) busy += clock64() - tb;
+            __syncthreads();
+        }
+    } else {
+        for (int s = 0; s < H + 2; ++s) __syncthreads();
+    }
+    long long t_loop = 0;
+    if (SSW_FIT_STAMPS == 2) t_loop = clock64();
+    if (SSW_FIT_STAMPS == 1 && lane == 0) {
+        if (wave == 4) S.tk[4] += (unsigned long long)busy;
+        if (wave == 12) S.tk[6] += (unsigned long long)busy;
+        if (wave == 0) S.tk[7] += (unsigned long long)busy;
+    }
+    // columns back to their threads (thread c: column c)
+    if (gwave) *reinterpret_cast<float2 *>(rows + 2 * gi) = make_float2(g0, g1);
+    // the loss values of all rows (exp + log1p: ~1700 cycles a chain -- as a wave's job inside the stages it was the
+    // longest of them and cost 130 us a fit; here all rows' chains run side by side once, ~1 us)
+    for (int i = c; i < n; i += 1024) {
+        const double zi = zl[i], yi = yl[i], ci = cl[i];
+        S.item[i] = ci * bce_item(zi, yi, bce_lw(a.pw, yi), a.obj.exact != 0);
+    }
+    __syncthreads();
+    if (SSW_FIT_STAMPS == 2 && c == 1023) {  // an idle wave's view: entry -> loop end -> return
+        S.tk[4] += (unsigned long long)(t_loop - t_entry);
+        S.tk[6] += (unsigned long long)(clock64() - t_loop);
+    }
+    return c < D ? rows[c] : 0.f;
 }
 
 __device__ __noinline__ void fit_eval_final(double *base, int dim_, float gcol) {
@@ -1375,14 +1603,21 @@ __global__ __launch_bounds__(1024) void k_fb_fit_wg(FitWgArgs a_in, FbW w0v) {
         __syncthreads();  // sw_ and ctl are published
         if (S.ctl[0] != 0.0) break;
         unsigned long long tq0 = wall_clock64();
-        fit_eval_logits(fit_lds, dim);
-        __syncthreads();
-        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
-        fit_eval_labels(fit_lds, dim);
-        __syncthreads();
-        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[1] += q - tq0; tq0 = q; }
-        const float gcol = fit_eval_grad(fit_lds, dim);
-        if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[2] += q - tq0; tq0 = q; }
+        float gcol;
+        if (a_in.onepass) {
+            gcol = fit_eval_onepass(fit_lds, dim);
+            __syncthreads();
+            if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
+        } else {
+            fit_eval_logits(fit_lds, dim);
+            __syncthreads();
+            if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
+            fit_eval_labels(fit_lds, dim);
+            __syncthreads();
+            if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[1] += q - tq0; tq0 = q; }
+            gcol = fit_eval_grad(fit_lds, dim);
+            if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[2] += q - tq0; tq0 = q; }
+        }
         fit_eval_final(fit_lds, dim, gcol);
         __syncthreads();
         if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[3] += q - tq0; tq0 = q; }
@@ -1401,6 +1636,9 @@ __global__ __launch_bounds__(1024) void k_fb_fit_wg(FitWgArgs a_in, FbW w0v) {
             a_in.out_counts[8] = (int)((clock64() - c_kernel0) >> 4);
             a_in.out_counts[9] = 0;
             a_in.out_counts[10] = (int)S.tk[5];
+            a_in.out_counts[11] = (int)(S.tk[4] >> 4);
+            a_in.out_counts[12] = (int)(S.tk[6] >> 4);
+            a_in.out_counts[13] = (int)(S.tk[7] >> 4);
             *a_in.out_loss = D.loss;
         }
         __threadfence_system();
@@ -2146,7 +2384,7 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
         hipMalloc((void **)&fb->hist, (size_t)2 * FIT_HISTORY * 1024 * sizeof(float)) != hipSuccess ||
         hipHostMalloc((void **)&fb->loss_host, sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->out_host, outn * sizeof(float), hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc((void **)&fb->flag_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&fb->flag_host, 128, hipHostMallocMapped) != hipSuccess ||
         hipHostMalloc((void **)&fb->w_host, (size_t)(2 * dim + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("feedback: allocation failed");
         ssw_fb_destroy(fb);
@@ -2154,7 +2392,7 @@ ssw_status ssw_fb_create(int32_t device, int32_t dim, ssw_fb **out) {
     }
     // hipHostMalloc does not zero: a stale completion word equal to the first sequence number would end the
     // first wait before the kernel has written anything
-    memset(fb->flag_host, 0, 64);
+    memset(fb->flag_host, 0, 128);
     memset(fb->out_host, 0, outn * sizeof(float));
     memset(fb->loss_host, 0, sizeof(double));
     if (hipHostGetDevicePointer((void **)&fb->out_host_dev, fb->out_host, 0) != hipSuccess ||
@@ -2393,7 +2631,8 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
             SSW_HIP_TRY(hipMemcpyAsync(fb->w, fb->w_host, (size_t)(fb->dim + 1) * sizeof(float), hipMemcpyHostToDevice, fb->stream));
             a.w0_or_null = fb->w;
         }
-        const size_t lds = fit_wg_lds_bytes(fb->dim);
+        a.onepass = a.label_mode == 0 && fb->dim == FIT_OP_DIM && fb->n >= 1 && !getenv("SSW_FB_TWO_PASS");  // the variable is the tests' A/B switch
+        const size_t lds = fit_wg_lds_bytes(fb->dim, a.onepass != 0);
         auto kern = fb->dim + 1 <= 9 * 64 ? k_fb_fit_wg<9> : k_fb_fit_wg<16>;
         // the attribute is per device: one flag per (device, kernel)
         static bool attr_done[64][2] = {};
@@ -2443,6 +2682,9 @@ ssw_status ssw_fb_fit(ssw_fb *fb, const ssw_fb_objective *obj, float *w_inout, i
                     counts[7] > 0 ? 16.0 * counts[8] / (counts[7] * 0.01) : 0.0);
         if (getenv("SSW_FB_TIMING"))
             fprintf(stderr, "   of the driver: two-loop recursion %.1f us\n", counts[10] * 0.01);
+        if (getenv("SSW_FB_TIMING") && counts[11])
+            fprintf(stderr, "   one pass (SSW_FIT_STAMPS build), cycles per evaluation: %.0f, %.0f, %.0f\n",
+                    16.0 * counts[11] / counts[1], 16.0 * counts[12] / counts[1], 16.0 * counts[13] / counts[1]);
         if (out_iters) *out_iters = counts[0];
         if (out_evals) *out_evals = counts[1];
         if (out_final_loss) *out_final_loss = (float)fb->loss_host[0];

@@ -288,6 +288,43 @@ def test_single_launch_fit_is_the_host_driven_fit_bit_for_bit():
         assert np.array_equal(wd.view(np.uint32), wh.view(np.uint32)), (n, np.abs(wd - wh).max())
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 31, 32, 33, 48, 390, 1000, 1024])
+def test_one_pass_evaluation_is_the_three_phase_evaluation_bit_for_bit(monkeypatch, n):
+    """the BCE objectives at dim 512 take an evaluation's logits, d loss / d logit and gradient in ONE pass over the rows
+    (fit_eval_onepass: units of 16 rows through LDS, wave roles); every sum keeps its order, so the fit is the
+    three-phase fit (SSW_FB_TWO_PASS) and the host-driven fit bit for bit -- ragged last units, half slabs, soft
+    targets, weights, an intercept, the multireg objective"""
+    from seesaw_amd import _lib
+    from seesaw_amd.feedback import FeedbackEngine
+    rng = np.random.default_rng(100 + n)
+    X = rng.standard_normal((n, 512)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    q = X[: min(4, n)].mean(0)
+    y = rng.uniform(0, 1, n)
+    y[: n // 2] = rng.uniform(size=n // 2) > 0.6
+    eng = FeedbackEngine(512)
+    eng.set_data(X, center=n > 1)
+    eng.set_targets(y, rng.uniform(0.5, 2.0, n))
+    eng.set_query(q)
+    objs = [_lib.FbObjective(kind=_lib.SSW_FB_LOGREG, loss_type=0, fit_intercept=1, reg_kind=_lib.SSW_FB_REG_VECTOR,
+                             pos_weight=2.0, reg_weight=1.0 / n, margin=0, reg_norm_lambda=0, reg_data_lambda=0,
+                             reg_query_lambda=0),
+            _multireg_obj("ce_loss", 0.0, 1.0)]
+    for obj in objs:
+        P = 512 + (1 if obj.kind == _lib.SSW_FB_LOGREG else 0)
+        w0 = (rng.standard_normal(P) * 0.05).astype(np.float32) if obj.kind == _lib.SSW_FB_LOGREG else \
+            (q / np.linalg.norm(q)).astype(np.float32)
+        (w1, i1), (wh, ih) = _fit_both_drivers(eng, obj, w0, max_iter=40)
+        monkeypatch.setenv("SSW_FB_TWO_PASS", "1")
+        w2, i2 = eng.fit(obj, w0, 40)
+        monkeypatch.delenv("SSW_FB_TWO_PASS")
+        assert i2.pop("on_device") is True
+        assert i1 == i2 == ih, (n, i1, i2, ih)
+        assert np.array_equal(w1.view(np.uint32), w2.view(np.uint32)), (n, np.abs(w1 - w2).max())
+        assert np.array_equal(w1.view(np.uint32), wh.view(np.uint32)), (n, np.abs(w1 - wh).max())
+        assert i1["func_evals"] >= 2
+
+
 def test_larger_labelled_sets_take_the_host_driven_fit():
     """above 1024 rows (pseudo_lr's 10 000 pseudo-labelled rows) the per-evaluation kernels run, driven from the host"""
     from seesaw_amd import _lib

@@ -15,7 +15,7 @@ eng = FeedbackEngine(512)
 bad = 0
 evals = 0
 for t in range(trials):
-    n = int(rng.integers(0, 400))
+    n = int(rng.integers(0, 400)) if t % 8 else int(rng.integers(400, 1025))
     X = rng.standard_normal((n, 512)).astype(np.float32)
     if n:
         X /= np.linalg.norm(X, axis=1, keepdims=True)
