@@ -85,7 +85,7 @@ class PhaseTimers:
     L-BFGS fit -- and what is left of the iteration latency is host code (session bookkeeping, pandas records)."""
 
     def __init__(self):
-        self.t = {"topk_call": 0.0, "label_prop": 0.0, "fit": 0.0}
+        self.t = {"topk_call": 0.0, "label_prop": 0.0, "fit": 0.0, "sample_draw": 0.0}
         self._saved = []
 
     def _wrap(self, cls, name, key):
@@ -102,7 +102,22 @@ class PhaseTimers:
         self._saved.append((cls, name, orig))
         setattr(cls, name, timed)
 
+    def _wrap_function(self, module, name, key):
+        orig = getattr(module, name)
+        timers = self.t
+
+        def timed(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return orig(*a, **k)
+            finally:
+                timers[key] += time.perf_counter() - t0
+
+        self._saved.append((module, name, orig))
+        setattr(module, name, timed)
+
     def __enter__(self):
+        from seesaw_amd.loops import util as loops_util
         from seesaw_amd.device_index import DeviceIndex
         from seesaw_amd.label_propagation import LabelPropagation
         from seesaw_amd.logistic_regression import LogisticRegressionPT
@@ -112,6 +127,7 @@ class PhaseTimers:
             self._wrap(LabelPropagation, m, "label_prop")
         self._wrap(RegModule, "fit", "fit")
         self._wrap(LogisticRegressionPT, "fit", "fit")
+        self._wrap_function(loops_util, "permutation_prefix", "sample_draw")  # PseudoLR's np.random.permutation(n)[:k], drawn by the library
         return self
 
     def __exit__(self, *exc):
@@ -125,9 +141,9 @@ class PhaseTimers:
         total = 1e3 * float(sum(latencies)) / n
         scan_ms = float(scan.sum()) / n if len(scan) else 0.0
         topk = 1e3 * self.t["topk_call"] / n
-        lp, fit = 1e3 * self.t["label_prop"] / n, 1e3 * self.t["fit"] / n
+        lp, fit, draw = 1e3 * self.t["label_prop"] / n, 1e3 * self.t["fit"] / n, 1e3 * self.t["sample_draw"] / n
         return {"iteration": total, "scan_kernel": scan_ms, "select_and_fetch": max(0.0, topk - scan_ms),
-                "label_prop": lp, "fit": fit, "host_other": max(0.0, total - topk - lp - fit),
+                "label_prop": lp, "fit": fit, "sample_draw": draw, "host_other": max(0.0, total - topk - lp - fit - draw),
                 "note": "ms per iteration of the reported session; scan_kernel by HIP events around the scan launches, the "
                         "other phases by host wall time around the C-ABI calls (they synchronise); the timed session is a "
                         "third one, run after the reported one (the wrappers cost ~1 us per call)"}

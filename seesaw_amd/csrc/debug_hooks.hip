@@ -60,9 +60,53 @@ extern "C" ssw_status ssw_debug_gemm_pw4_wg(uint64_t *out4096) {
 extern "C" ssw_status ssw_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t variant, int32_t iters,
                                      float *out_ms, float *out_maxdiff) {
     using namespace ssw;
-    if (M <= 0 || iters <= 0 || epi < 0 || epi > 3) {
+    if (M <= 0 || iters <= 0 || epi < 0 || epi > 7) {
         set_error("ssw_debug_gemm: bad arguments");
         return SSW_ERR_INVALID;
+    }
+    if (epi >= 4) {  // the LayerNorm-folded consumers (4, 5) and the row producers (6, 7): timing only, filled operands
+        __bf16 *A = nullptr, *W = nullptr, *xc = nullptr;
+        float *bias = nullptr, *c1 = nullptr, *st_in = nullptr, *st_out = nullptr;
+        void *res = nullptr, *C = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const int np_in = K / 128;
+        auto cleanup = [&]() {
+            for (void *p : {(void *)A, (void *)W, (void *)xc, (void *)bias, (void *)c1, (void *)st_in, (void *)st_out, res, C}) (void)hipFree(p);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        };
+        bool ok = hipMalloc(&A, (size_t)M * K * 2) == hipSuccess && hipMalloc(&W, (size_t)N * K * 2) == hipSuccess &&
+                  hipMalloc(&xc, (size_t)M * N * 2) == hipSuccess && hipMalloc(&bias, (size_t)N * 4) == hipSuccess &&
+                  hipMalloc(&c1, (size_t)N * 4) == hipSuccess && hipMalloc(&st_in, (size_t)M * np_in * 8) == hipSuccess &&
+                  hipMalloc(&st_out, (size_t)M * (N / 128 + 1) * 8) == hipSuccess && hipMalloc(&res, (size_t)M * N * 4) == hipSuccess &&
+                  hipMalloc(&C, (size_t)M * N * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        if (!ok) {
+            cleanup();
+            set_error("ssw_debug_gemm: allocation failed");
+            return SSW_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, A, (int64_t)M * K, 0x1234u, 1.0f);
+        hipLaunchKernelGGL(k_debug_fill, dim3(2048), dim3(256), 0, 0, W, (int64_t)N * K, 0x9876u, 0.05f);
+        hipLaunchKernelGGL(k_debug_fill_f32, dim3(64), dim3(256), 0, 0, bias, (int64_t)N, 0x4242u, 0.5f);
+        hipLaunchKernelGGL(k_debug_fill_f32, dim3(64), dim3(256), 0, 0, c1, (int64_t)N, 0x4243u, 0.5f);
+        hipLaunchKernelGGL(k_debug_fill_f32, dim3(2048), dim3(256), 0, 0, (float *)res, (int64_t)M * N, 0x7777u, 1.0f);
+        (void)hipMemsetAsync(st_in, 0, (size_t)M * np_in * 8, 0);  // mean 0, variance 0: rstd = 1 / sqrt(eps)
+        GemmLn ln;
+        ln.stats_in = st_in; ln.np_in = np_in; ln.inv_dim = 1.f / K; ln.eps = 1.f; ln.c1 = c1;
+        ln.xcopy = xc; ln.stats_out = st_out;
+        const int keep = gemm_variant();
+        tune_gemm(variant);
+        int rc = launch_gemm_bf16_ln(epi, 0, A, W, bias, (const float *)res, C, M, N, K, ln);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < iters && rc == SSW_OK; ++i) rc = launch_gemm_bf16_ln(epi, 0, A, W, bias, (const float *)res, C, M, N, K, ln);
+        (void)hipEventRecord(e1, 0);
+        tune_gemm(keep);
+        float ms = 0.f;
+        if (rc == SSW_OK && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)) rc = SSW_ERR_HIP;
+        cleanup();
+        if (out_ms) *out_ms = ms / iters;
+        if (out_maxdiff) *out_maxdiff = 0.f;
+        return (ssw_status)rc;
     }
     const bool out_bf16 = (epi == 1 || epi == 2);
     const size_t out_bytes = (size_t)M * N * (out_bf16 ? 2 : 4);
