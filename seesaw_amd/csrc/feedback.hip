@@ -552,28 +552,48 @@ __device__ __forceinline__ void fb_final_body(float g, const float wc, const dou
         __syncthreads();
         return o;
     };
+    // Waves without a column (c >= dim) or without an item have zeros to sum: their wave totals are +0.0 without the DPP
+    // network, and only the waves that use a total add the 16 wave totals up (every thread did, for all four: 64 f64
+    // additions a thread, four waves deep on every SIMD, ~2000 cycles of this step).  The additions that remain are
+    // the same, in the same order.
+    const bool has_cols = wave * 64 < dim, has_items = (int64_t)wave * 64 < n || n > 1024;
     double ls = 0.0, rs = 0.0;
-    for (int64_t i0 = c; i0 < n; i0 += 8 * 1024) {  // eight of this thread's items in flight; same order of additions
-        double li[8];
-        float ri[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t i = i0 + (int64_t)u * 1024;
-            li[u] = item_loss[i < n ? i : c];
-            ri[u] = r[i < n ? i : c];
+    if (n <= 1024) {  // one item a thread at most
+        if (c < n) {
+            ls += item_loss[c];
+            rs += (double)r[c];
         }
+    } else {
+        for (int64_t i0 = c; i0 < n; i0 += 8 * 1024) {  // eight of this thread's items in flight; same order of additions
+            double li[8];
+            float ri[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (i0 + (int64_t)u * 1024 < n) {
-                ls += li[u];
-                rs += (double)ri[u];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + (int64_t)u * 1024;
+                li[u] = item_loss[i < n ? i : c];
+                ri[u] = r[i < n ? i : c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + (int64_t)u * 1024 < n) {
+                    ls += li[u];
+                    rs += (double)ri[u];
+                }
             }
         }
     }
     double ww, wq, data_loss, rsum;
     {
         const double v0 = act ? (double)wc * wc : 0.0, v1 = act && qhat ? (double)wc * qhat[c] : 0.0;
-        const double s0 = wave_sum_d(v0), s1 = wave_sum_d(v1), s2 = wave_sum_d(ls), s3 = wave_sum_d(rs);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (has_cols) {
+            s0 = wave_sum_d(v0);
+            s1 = wave_sum_d(v1);
+        }
+        if (has_items) {
+            s2 = wave_sum_d(ls);
+            s3 = wave_sum_d(rs);
+        }
         if (lane == 0) {
             red[4 * wave + 0] = s0;
             red[4 * wave + 1] = s1;
@@ -581,13 +601,21 @@ __device__ __forceinline__ void fb_final_body(float g, const float wc, const dou
             red[4 * wave + 3] = s3;
         }
         __syncthreads();
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        double t0 = 1.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // a wave without columns uses none of them (ww = 1 keeps its arithmetic finite)
+        if (has_cols) {
+            t0 = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            t0 += red[4 * w + 0];
-            t1 += red[4 * w + 1];
-            t2 += red[4 * w + 2];
-            t3 += red[4 * w + 3];
+            for (int w = 0; w < 16; ++w) {
+                t0 += red[4 * w + 0];
+                t1 += red[4 * w + 1];
+            }
+        }
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                t2 += red[4 * w + 2];
+                t3 += red[4 * w + 3];
+            }
         }
         ww = t0;
         wq = t1;
