@@ -150,6 +150,41 @@ __device__ __forceinline__ f32x4 epilogue_value(f32x4 v, float mean, float rstd,
     return v;
 }
 
+// LayerNorm statistics of a tile's rows, AHEAD of the K loop (round 4): thread t < rows asks for row m0 + t's np_in
+// partial pairs (np_in even, <= 8: four float4 requests, the last ones repeated when there are fewer), adds them in
+// ascending order -- the order the producing epilogues' partials have always been added in -- and leaves mean / rstd
+// in ln_lds[2 t], [2 t + 1]; the K loop's first barrier publishes them.  The loads go out before the ring's first
+// pieces and are waited for behind them, so the wait is the first stage's own.  (They used to be parked in the idle
+// staging bytes and summed BEHIND the loop: two barriers and an LDS round trip per tile in the exposed epilogue,
+// 1.6 us of QKV's 44.3 and 1.9 of fc1's 62.5 at 10 000 rows.)
+struct LnRowPre {
+    f32x4 v[4];
+};
+__device__ __forceinline__ LnRowPre ln_row_request(const GemmLn &ln, int row) {
+    LnRowPre r;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(ln.stats_in + (int64_t)row * ln.np_in * 2);
+    const int last = ln.np_in / 2 - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = p[min(k, last)];
+    return r;
+}
+__device__ __forceinline__ void ln_row_finish(const GemmLn &ln, const LnRowPre &r, float *dst2) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (2 * k < ln.np_in) {
+            sm += r.v[k][0];
+            sq += r.v[k][1];
+            sm += r.v[k][2];
+            sq += r.v[k][3];
+        }
+    }
+    const float mean = sm * ln.inv_dim;
+    const float var = fmaxf(sq * ln.inv_dim - mean * mean, 0.f);
+    dst2[0] = mean;
+    dst2[1] = rsqrtf(var + ln.eps);
+}
+
 // acc: [RH][NJ] accumulator tiles of this wave (rows row0 + i*16 + fr, columns col0 + j*16 + fq*4 + r); wl: the wave's
 // RH*16 x (NJ*32 + 16) bytes of LDS; ln_rows: statistics of the tile's rows from local row lrow0 on; c1 / c2 at col0
 template <int EPI, int RH, int NJ>
@@ -419,21 +454,12 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     }
     float *const ln_lds = reinterpret_cast<float *>(smem + DEPTH * STAGE);  // [TM][2] statistics / [WN][TM][2] partials
     // LayerNorm-folded variants: thread t < TM requests the partial sums of row m0 + t NOW (ordinary loads, ahead of the
-    // ring's first pieces) and touches them only behind the K loop, where the compiler's vmcnt(0) for them finds every
-    // LDS-DMA piece long landed; in between they cost eight registers and no wait.
-    // (Round 3: the tile's TM x np_in partial pairs are one contiguous block -- rows m0 .. m0 + TM - 1 of [M][np_in][2] --
-    //  and are fetched as such, 16 bytes a thread with consecutive threads on consecutive addresses, instead of eight
-    //  8-byte loads per row thread at a 48-byte stride; np_in is even (launch_gemm_bf16_ln), so the block is whole
-    //  float4s.  One register set of four instead of sixteen.)
-    constexpr int LN_F4 = (TM * 8 * 2 / 4 + TM * WN - 1) / (TM * WN);  // float4s per thread for np_in <= 8
-    f32x4 ln_raw[LN_F4];
+    // ring's first pieces) and turns them into the row's mean / rstd once the first stages are on their way (LnRowPre)
+    LnRowPre ln_pre;
     f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-31: c1 of 4 of the tile's 128 columns, 32-63: c2
     float *const ln_c = ln_lds + 2 * TM;         // [2][128] behind the statistics
     if constexpr (epi_ln(EPI)) {
-        const f32x4 *st = reinterpret_cast<const f32x4 *>(ln.stats_in + (int64_t)m0 * ln.np_in * 2);
-        const int n_valid = min(M - m0, TM) * ln.np_in / 2;  // float4s of the rows that exist
-#pragma unroll
-        for (int k = 0; k < LN_F4; ++k) ln_raw[k] = st[min(t + k * TM * WN, n_valid - 1)];  // unconditional: no early wait
+        if (t < TM) ln_pre = ln_row_request(ln, min(m0 + t, M - 1));
         ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 32) ? bias : ln.c1) + n0 + (t & 31) * 4);
     }
 
@@ -577,6 +603,10 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s)
             if (s < nk) SSW_ISSUE(s, s)
+        if constexpr (epi_ln(EPI)) {  // published by the loop's barriers; read behind the loop
+            if (t < TM) ln_row_finish(ln, ln_pre, ln_lds + 2 * t);
+            if (t < 64) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
+        }
         int buf = 0, nxt = DEPTH - 1;  // ring slots of stage kt and of stage kt + DEPTH - 1
         for (int kt = 0; kt < nk; ++kt) {
             // stage kt has landed once at most the DEPTH-2 younger stages are still in flight
@@ -601,39 +631,10 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #undef SSW_MFMA_BLOCK
 
     // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*(128/WN) + j*16 + fq*4 + r]
-    if constexpr (epi_ln(EPI)) {
-        // the block of partials through the (idle) staging bytes: parked as fetched, then row t's np_in pairs added in
-        // ascending order by thread t -- the order the per-row loads had
-        __syncthreads();  // every wave is done with its last fragments
-        float *const raw = reinterpret_cast<float *>(smem);
-#pragma unroll
-        for (int k = 0; k < LN_F4; ++k) {
-            asm volatile("" : "+v"(ln_raw[k]));  // keep the wait for them behind the loop
-            const int idx = t + k * TM * WN;
-            if (idx < TM * ln.np_in / 2) *reinterpret_cast<f32x4 *>(raw + 4 * idx) = ln_raw[k];
-        }
-        __syncthreads();
-        float sm = 0.f, sq = 0.f;
-        if (t < TM) {
-            for (int p = 0; p < ln.np_in; ++p) {
-                sm += raw[(t * ln.np_in + p) * 2];
-                sq += raw[(t * ln.np_in + p) * 2 + 1];
-            }
-        }
-        if (t < TM) {
-            const float mean = sm * ln.inv_dim;
-            const float var = fmaxf(sq * ln.inv_dim - mean * mean, 0.f);
-            ln_lds[2 * t] = mean;
-            ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
-        }
-        asm volatile("" : "+v"(ln_cpre));
-        if (t < 64) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
-        __syncthreads();
-    }
+    static_assert(!(PIPE && epi_ln(EPI)), "the LayerNorm-folded epilogues run on the two-stage loop");
     if constexpr (epi_bf16_out(EPI) && WN == 4 && TM == 128 && !PIPE) {
-        // (the LayerNorm variants passed a barrier just above; the others need one: another wave may still be reading
-        //  its last fragments out of the bytes this wave is about to overwrite)
-        if constexpr (!epi_ln(EPI)) __syncthreads();
+        // another wave may still be reading its last fragments out of the bytes this wave is about to overwrite
+        __syncthreads();
         store_rows_via_lds<EPI, 4, NJ>(acc, smem + wave * (64 * (NJ * 32 + 16)), lane, m0 + wm * 64, n0 + wn * (128 / WN), M, N,
                                        reinterpret_cast<bf16 *>(Cout), ln_lds + 2 * (wm * 64), ln_c + wn * (128 / WN),
                                        ln_c + 128 + wn * (128 / WN));
@@ -879,15 +880,12 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
         for (int i = 0; i < 8; ++i) acc[i][j] = bv;
     }
     float *const ln_lds = reinterpret_cast<float *>(smem + 2 * T256_STAGE);  // [256][2] row statistics
-    f32x4 ln_raw[2];  // as in gemm_glds: the tile's 256 x np_in partial pairs as one block, two float4s a thread
+    LnRowPre ln_pre;  // as in gemm_glds: row m0 + t's partial pairs, requested now, summed once the first tiles are on their way
     f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-63: c1 of 4 of the tile's 256 columns, 64-127: c2
     float *const ln_c = ln_lds + 2 * 256;        // [2][256] behind the statistics
     if constexpr (epi_ln(EPI)) {
         ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 64) ? bias : ln.c1) + n0 + (t & 63) * 4);
-        const f32x4 *st = reinterpret_cast<const f32x4 *>(ln.stats_in + (int64_t)m0 * ln.np_in * 2);
-        const int n_valid = min(M - m0, 256) * ln.np_in / 2;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) ln_raw[k] = st[min(t + k * 512, n_valid - 1)];
+        if (t < 256) ln_pre = ln_row_request(ln, min(m0 + t, M - 1));
     }
     const int frag0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
     const int a_frag = wr * T256_HALF + frag0;                                        // + i * 2048, i = 0..7
@@ -919,6 +917,10 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
     T256_ISSUE_A0(0, 0) T256_ISSUE_A1(0, 0) T256_ISSUE_W0(0, 0) T256_ISSUE_W1(0, 0)
     if (nk > 1) {
         T256_ISSUE_W0(1, 1) T256_ISSUE_W1(1, 1) T256_ISSUE_A0(1, 1)
+    }
+    if constexpr (epi_ln(EPI)) {  // published by the barrier below; read behind the loop
+        if (t < 256) ln_row_finish(ln, ln_pre, ln_lds + 2 * t);
+        if (t < 128) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
     }
     if (nk > 1) {
         wait_vmcnt<6>();
@@ -971,35 +973,8 @@ __global__ __launch_bounds__(512) void gemm_256(const bf16 *__restrict__ A, cons
 
     // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + fr][n0 + wc*64 + j*16 + fq*4 + r]
     static_assert(!epi_stats(EPI), "the statistics epilogue lives in gemm_glds (N = hidden width shapes)");
-    if constexpr (epi_ln(EPI)) {
-        __syncthreads();  // every wave is done with its last fragments
-        float *const raw = reinterpret_cast<float *>(smem);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            asm volatile("" : "+v"(ln_raw[k]));
-            const int idx = t + k * 512;
-            if (idx < 256 * ln.np_in / 2) *reinterpret_cast<f32x4 *>(raw + 4 * idx) = ln_raw[k];
-        }
-        __syncthreads();
-        float sm = 0.f, sq = 0.f;
-        if (t < 256) {
-            for (int p = 0; p < ln.np_in; ++p) {
-                sm += raw[(t * ln.np_in + p) * 2];
-                sq += raw[(t * ln.np_in + p) * 2 + 1];
-            }
-        }
-        if (t < 256) {
-            const float mean = sm * ln.inv_dim;
-            const float var = fmaxf(sq * ln.inv_dim - mean * mean, 0.f);
-            ln_lds[2 * t] = mean;
-            ln_lds[2 * t + 1] = rsqrtf(var + ln.eps);
-        }
-        asm volatile("" : "+v"(ln_cpre));
-        if (t < 128) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
-        __syncthreads();
-    }
     if constexpr (epi_bf16_out(EPI)) {
-        if constexpr (!epi_ln(EPI)) __syncthreads();  // as in gemm_glds: the staging bytes are about to be reused
+        __syncthreads();  // as in gemm_glds: the staging bytes are about to be reused
 #pragma unroll
         for (int h = 0; h < 2; ++h)  // 64 rows at a time: 9 KB of LDS per wave
             store_rows_via_lds<EPI, 4, 4>(acc + 4 * h, smem + wave * (64 * 144), lane, m0 + wr * 128 + h * 64, n0 + wc * 64, M, N,
