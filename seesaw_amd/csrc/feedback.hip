@@ -1101,12 +1101,6 @@ __device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
     const int zslot = wave - 4;
     const int gi = c;  // a gradient thread takes columns 2 gi, 2 gi + 1
     const int zrow = 2 * zslot;  // a logit wave's first row inside the unit
-    float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
-    if (zwave) {
-        wa = reinterpret_cast<const float4 *>(S.sw_)[lane];
-        wb = reinterpret_cast<const float4 *>(S.sw_)[lane + 64];
-    }
-    const float bias = a.obj.has_bias ? S.sw_[D] : 0.f;
     const int H = (n + FIT_OP_ROWS - 1) / FIT_OP_ROWS;
     const fit_g4ptr X4 = (fit_g4ptr)a.X;
     long long busy = 0;
@@ -1136,6 +1130,17 @@ __device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
         };
 #pragma unroll
         for (int q = 0; q < PF; ++q) load(q, xl[q], xh[q]);
+        // The rows do not depend on the point of the evaluation: the first units are on their way while wave 0 still
+        // drives (the caller enters here without waiting for it).  Behind this barrier sw_ and ctl are published.
+        __syncthreads();
+        if (S.ctl[0] != 0.0) {  // the driver has finished: nothing to evaluate
+#pragma unroll
+            for (int q = 0; q < PF; ++q)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(xl[q][0]), "+v"(xh[q][0]), "+v"(xl[q][1]), "+v"(xh[q][1])::"memory");
+            return 0.f;
+        }
+        const float4 wa = reinterpret_cast<const float4 *>(S.sw_)[lane], wb = reinterpret_cast<const float4 *>(S.sw_)[lane + 64];
+        const float bias = a.obj.has_bias ? S.sw_[D] : 0.f;
         for (int s0 = 0; s0 < H; s0 += NS) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
@@ -1185,6 +1190,8 @@ __device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
         __syncthreads();
         __syncthreads();
     } else if (rwave) {
+        __syncthreads();
+        if (S.ctl[0] != 0.0) return 0.f;
         for (int s = 0; s < H + 2; ++s) {
             long long tb = 0;
             if (SSW_FIT_STAMPS == 1) tb = clock64();
@@ -1197,6 +1204,8 @@ __device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
             __syncthreads();
         }
     } else if (gwave) {
+        __syncthreads();
+        if (S.ctl[0] != 0.0) return 0.f;
         float p0 = 0.f, p1 = 0.f;
         for (int s = 0; s < H + 2; ++s) {
             long long tb = 0;
@@ -1241,6 +1250,8 @@ __device__ __noinline__ float fit_eval_onepass(double *base, int dim_) {
             __syncthreads();
         }
     } else {
+        __syncthreads();
+        if (S.ctl[0] != 0.0) return 0.f;
         for (int s = 0; s < H + 2; ++s) __syncthreads();
     }
     long long t_loop = 0;
@@ -1628,15 +1639,18 @@ __global__ __launch_bounds__(1024) void k_fb_fit_wg(FitWgArgs a_in, FbW w0v) {
     const unsigned long long t_kernel0 = wall_clock64();
     const long long c_kernel0 = clock64();
     for (;;) {
-        __syncthreads();  // sw_ and ctl are published
-        if (S.ctl[0] != 0.0) break;
         unsigned long long tq0 = wall_clock64();
         float gcol;
         if (a_in.onepass) {
+            // the barrier that publishes sw_ / ctl is inside: the logit waves request their first rows ahead of it
             gcol = fit_eval_onepass(fit_lds, dim);
+            if (S.ctl[0] != 0.0) break;
             __syncthreads();
             if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
         } else {
+            __syncthreads();  // sw_ and ctl are published
+            if (S.ctl[0] != 0.0) break;
+            tq0 = wall_clock64();
             fit_eval_logits(fit_lds, dim);
             __syncthreads();
             if (c == 0) { const unsigned long long q = wall_clock64(); S.tk[0] += q - tq0; tq0 = q; }
