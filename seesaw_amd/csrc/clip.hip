@@ -976,6 +976,23 @@ __global__ void widen_rows(const bf16 *__restrict__ x, const int *__restrict__ r
     }
 }
 
+// The pooled (first) row of every image out of the tile path's buffers, compacted: f32 residual row, its bf16 copy and
+// its partial LayerNorm statistics (np pairs a row) -- the last layer's MLP runs on these rows only (run_tower)
+__global__ __launch_bounds__(256) void gather_pooled_rows(const float *__restrict__ x, const bf16 *__restrict__ xb,
+                                                          const float *__restrict__ st, int B, int S, int D, int np,
+                                                          float *__restrict__ x_out, bf16 *__restrict__ xb_out,
+                                                          float *__restrict__ st_out) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int64_t src = (int64_t)b * S;
+    for (int k = threadIdx.x; k < D; k += 256) {
+        const bf16 hb = xb[src * D + k];
+        x_out[(int64_t)b * D + k] = x ? x[src * D + k] : (float)hb;  // bf16 rows: the stream row itself is the residual
+        xb_out[(int64_t)b * D + k] = hb;
+    }
+    if ((int)threadIdx.x < 2 * np) st_out[(int64_t)b * 2 * np + threadIdx.x] = st[src * 2 * np + threadIdx.x];
+}
+
 __global__ void cls_rows(int B, int T, int *__restrict__ rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) rows[b] = b * T;
@@ -1032,6 +1049,7 @@ struct ssw_clip {
     float *hidden = nullptr, *hidden2 = nullptr, *pooled = nullptr, *patch_out = nullptr;
     bf16 *xn = nullptr, *qkv = nullptr, *att = nullptr, *h1 = nullptr, *patches = nullptr;
     bool stream_in_xn = false;  // run_tower left the residual stream in xn (bf16), not in hidden
+    bool pooled_compact = false;  // run_tower left only the pooled rows of the last layer, as rows 0 .. B-1 of hidden
     float *stats_a = nullptr, *stats_b = nullptr;  // [rows][D / 128][2] partial LayerNorm statistics of hidden / hidden2
     float *pixels = nullptr, *out = nullptr;
     int *ids = nullptr, *rows = nullptr;
@@ -1230,7 +1248,9 @@ bool skinny_rows(int R, int D, int M) {
 }
 
 // a handle's option word (ssw_clip::flags) starts from the environment
-int clip_flags_from_env() { return (getenv("SSW_CLIP_BF16_STREAM") ? 1 : 0) | (getenv("SSW_CLIP_UNFUSED_ATTN") ? 8 : 0); }
+int clip_flags_from_env() {
+    return (getenv("SSW_CLIP_BF16_STREAM") ? 1 : 0) | (getenv("SSW_CLIP_UNFUSED_ATTN") ? 8 : 0) | (getenv("SSW_CLIP_FULL_LAST_LAYER") ? 16 : 0);
+}
 bool unfused_ln_forced() {
     static const bool v = getenv("SSW_CLIP_UNFUSED_LN") != nullptr;  // A/B: the round-2 seven-launch layer
     return v;
@@ -1304,6 +1324,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     // On for the image tower (the batch path); the text tower -- the query side -- keeps its f32 rows.
     const bool bf16_stream = bf16_rows(c, tw, causal);
     c->stream_in_xn = false;
+    c->pooled_compact = false;
     const int np = D / 128;
     float *st_h = c->stats_a, *st_h2 = c->stats_b;
     for (int l = 0; l < tw.L && !skinny; ++l) {
@@ -1335,6 +1356,27 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             cons.stats_in = st_h2;
             cons.c1 = ly.c1fc1;
             cons.np_in = 2;
+            // The last layer's MLP on the pooled rows only: the final LayerNorm and the projection read the first row of
+            // every image and nothing else, and a row's MLP does not look at other rows -- 49 of an image's 50 rows of
+            // fc1 / fc2 (113 us of a B = 200 forward) feed nothing.  The rows are compacted (residual row, bf16 copy,
+            // statistics), fc1 runs on them as it is, fc2 -- 12 tiles with 48 K-steps each -- split over K.
+            // (The attention and the out-projection before it still run for every row.)
+            const bool full_last_layer = (c->flags & 16) != 0;  // SSW_CLIP_OPT_FULL_LAST_LAYER
+            bool pooled_only = l == tw.L - 1 && !full_last_layer && S >= 8 && M % 512 == 0;  // (S: the partial products borrow the qkv buffer)
+#ifdef SSW_DEBUG_HOOKS
+            if (c->tap_layer == l && c->tap_tower == 0) pooled_only = false;  // the tap wants every row of this layer
+#endif
+            if (pooled_only) {
+                float *res_p = h + (int64_t)B * D;  // hidden is free behind the out-projection: rows B .. 2B-1 take the residual rows
+                hipLaunchKernelGGL(gather_pooled_rows, dim3(B), dim3(256), 0, s, bf16_stream ? (const float *)nullptr : h2, c->xn, st_h2,
+                                   B, S, D, 2, res_p, c->att, st_h);
+                cons.stats_in = st_h;
+                SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->att, ly.w1_ln, ly.c2fc1, nullptr, c->h1, B, M, D, cons));
+                SSW_TRY(launch_gemm_splitk_f32(s, c->h1, ly.w2, ly.b2, res_p, h, reinterpret_cast<float *>(c->qkv), B, D, M, 8));
+                c->pooled_compact = true;
+                c->stream_in_xn = false;  // the pooled rows are f32 rows of hidden whatever the stream's precision
+                continue;
+            }
             SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->xn, ly.w1_ln, ly.c2fc1, nullptr, c->h1, R, M, D, cons));
             prod.stats_out = st_h;
             if (bf16_stream)
@@ -1433,7 +1475,7 @@ ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *
                        c->pre_b, h.ln_eps, bf16_rows(c, c->vis, 0) ? (float *)nullptr : c->hidden, c->xn, c->stats_a,
                        D / 128 > 0 ? D / 128 : 1, c->cls, c->vpos, T);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
-    hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, T, c->rows);
+    hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, c->pooled_compact ? 1 : T, c->rows);
     return pool_and_project(c, c->vis, B, D, normalize, out_dev);
 }
 
@@ -1474,7 +1516,7 @@ extern "C" {
 
 ssw_status ssw_clip_set_option(ssw_clip *c, int32_t option, int32_t value) {
     SSW_REQUIRE(c != nullptr, "clip is NULL");
-    SSW_REQUIRE(option >= 0 && option <= 3, "ssw_clip_set_option: option %d unknown (SSW_CLIP_OPT_*)", option);
+    SSW_REQUIRE(option >= 0 && option <= 4, "ssw_clip_set_option: option %d unknown (SSW_CLIP_OPT_*)", option);
     DeviceGuard guard(c->device);
     SSW_HIP_TRY(hipStreamSynchronize(c->stream));  // a forward in flight keeps the form it started with
     if (value) c->flags |= 1 << option;

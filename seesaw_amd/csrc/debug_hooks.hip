@@ -198,7 +198,22 @@ extern "C" ssw_status ssw_debug_gemm_run(int32_t epi, int32_t variant, int32_t M
                                          const float *c1_or_null, float inv_dim, float eps, void *C_out_or_null,
                                          float *stats_out_or_null) {
     using namespace ssw;
-    SSW_REQUIRE(epi >= 0 && epi <= 7 && M > 0 && N > 0 && K > 0 && A_bf16 && W_bf16, "ssw_debug_gemm_run: bad arguments");
+    SSW_REQUIRE(epi >= 0 && epi <= 8 && M > 0 && N > 0 && K > 0 && A_bf16 && W_bf16, "ssw_debug_gemm_run: bad arguments");
+    if (epi == 8) {  // the split-K product of few-tile shapes (launch_gemm_splitk_f32): `variant` = number of splits
+        SSW_REQUIRE(bias_or_c2 && C_out_or_null && variant >= 1, "ssw_debug_gemm_run: split-K needs bias, an output and the split count");
+        DevBufs d8;
+        void *A8, *W8, *b8, *r8 = nullptr, *C8, *P8;
+        SSW_TRY(d8.up(A_bf16, (size_t)M * K * 2, &A8));
+        SSW_TRY(d8.up(W_bf16, (size_t)N * K * 2, &W8));
+        SSW_TRY(d8.up(bias_or_c2, (size_t)N * 4, &b8));
+        if (residual_or_null) SSW_TRY(d8.up(residual_or_null, (size_t)M * N * 4, &r8));
+        SSW_TRY(d8.up(nullptr, (size_t)M * N * 4, &C8));
+        SSW_TRY(d8.up(nullptr, (size_t)variant * M * N * 4, &P8));
+        SSW_TRY(launch_gemm_splitk_f32(0, A8, W8, (const float *)b8, (const float *)r8, (float *)C8, (float *)P8, M, N, K, variant));
+        SSW_HIP_TRY(hipDeviceSynchronize());
+        SSW_HIP_TRY(hipMemcpy(C_out_or_null, C8, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        return SSW_OK;
+    }
     const bool c_bf16 = epi == 1 || epi == 2 || epi == 4 || epi == 5, c_f32 = epi == 0 || epi == 3 || epi == 6;
     const size_t mn = (size_t)M * N;
     const int n_tiles = N / 128;

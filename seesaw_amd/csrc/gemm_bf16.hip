@@ -227,11 +227,13 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x4 (*acc)[NJ], unsig
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_STRIDE = BK + 8;  // bf16 elements per staged row (144 B: breaks the 128-B bank period)
 
-template <int EPI>
+// SPLITK (EPI_F32 only): blockIdx.z takes columns [z k_len, (z + 1) k_len) of K and writes its partial products to
+// slab z of Cout ([gridDim.z][M][N] f32) -- launch_gemm_splitk_f32 below.
+template <int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, const bf16 *__restrict__ W,
                                                     const float *__restrict__ bias,
                                                     const float *__restrict__ residual, void *__restrict__ Cout,
-                                                    int M, int N, int K) {
+                                                    int M, int N, int K, int k_len = 0) {
     __shared__ __attribute__((aligned(16))) bf16 sA[2][BM * LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) bf16 sB[2][BN * LDS_STRIDE];
     const int t = threadIdx.x;
@@ -243,11 +245,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
     // row c/8, 8 bf16 at column (c%8)*8); kept in registers across the MFMA block
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     const int srow = t >> 3, scol = (t & 7) * 8;  // chunk i adds 32 rows
-    const bf16 *a_ptr0 = A + (int64_t)min(m0 + srow, M - 1) * K + scol;
-    const bf16 *a_ptr1 = A + (int64_t)min(m0 + srow + 32, M - 1) * K + scol;
-    const bf16 *a_ptr2 = A + (int64_t)min(m0 + srow + 64, M - 1) * K + scol;
-    const bf16 *a_ptr3 = A + (int64_t)min(m0 + srow + 96, M - 1) * K + scol;
-    const bf16 *w_ptr = W + (int64_t)(n0 + srow) * K + scol;
+    static_assert(!SPLITK || EPI == EPI_F32, "partial products are plain f32");
+    const int kb = SPLITK ? (int)blockIdx.z * k_len : 0;  // first column of this workgroup's K range
+    if (SPLITK) Cout = reinterpret_cast<float *>(Cout) + (int64_t)blockIdx.z * M * N;
+    const bf16 *a_ptr0 = A + (int64_t)min(m0 + srow, M - 1) * K + scol + kb;
+    const bf16 *a_ptr1 = A + (int64_t)min(m0 + srow + 32, M - 1) * K + scol + kb;
+    const bf16 *a_ptr2 = A + (int64_t)min(m0 + srow + 64, M - 1) * K + scol + kb;
+    const bf16 *a_ptr3 = A + (int64_t)min(m0 + srow + 96, M - 1) * K + scol + kb;
+    const bf16 *w_ptr = W + (int64_t)(n0 + srow) * K + scol + kb;
     const int64_t w_step = (int64_t)32 * K;
     const int lds_off = srow * LDS_STRIDE + scol;
 #define SSW_LOAD_TILES(k0)                                                   \
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt(const bf16 *__restrict__ A, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    const int nk = (SPLITK ? k_len : K) / BK;
     SSW_LOAD_TILES(0)
     SSW_STORE_TILES(0)
     __syncthreads();
@@ -1177,6 +1182,42 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t s, const void *A_, const voi
     }
     set_error("gemm_bf16_ln: epilogue %d is not a LayerNorm-folded one", epi);
     return SSW_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------------------------------
+// A product that is a fraction of one round of tiles lasts as long as ONE workgroup's K loop (~1 us a 64-wide step
+// whatever the tile): the last layer's fc2 on the 200 pooled rows of a B = 200 call is 12 tiles of 48 steps.  Split over
+// K it is `splits` times as many workgroups with a `splits`-th of the steps each, the partial products (f32) added up
+// in ascending order by a second launch together with bias and residual.
+// ---------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ part, int splits, int64_t mn, int N,
+                                                       const float *__restrict__ bias, const float *__restrict__ residual,
+                                                       float *__restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(part + i);
+    for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (int64_t)z * mn + i);
+    v += *reinterpret_cast<const f32x4 *>(bias + (int)(i % N));
+    if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i);
+    *reinterpret_cast<f32x4 *>(out + i) = v;
+}
+}  // namespace
+
+ssw_status launch_gemm_splitk_f32(hipStream_t s, const void *A, const void *W, const float *bias, const float *residual,
+                                  float *out, float *partials, int M, int N, int K, int splits) {
+    if (N % BN != 0 || M <= 0 || splits < 1 || K % (splits * BK) != 0 || !bias || !partials) {
+        set_error("gemm_splitk: shape M=%d N=%d K=%d in %d splits unsupported (N %% 128, K %% (64 splits))", M, N, K, splits);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt<EPI_F32, true>), dim3(N / BN, (M + BM - 1) / BM, splits), dim3(256), 0, s,
+                       static_cast<const bf16 *>(A), static_cast<const bf16 *>(W), (const float *)nullptr, (const float *)nullptr,
+                       (void *)partials, M, N, K, K / splits);
+    const int64_t mn = (int64_t)M * N;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, s, partials, splits, mn, N, bias,
+                       residual, out);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
 }
 
 }  // namespace ssw

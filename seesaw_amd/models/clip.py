@@ -112,7 +112,7 @@ class ClipModel:
         _lib.call("ssw_clip_sync", self._h)
 
     # ssw_clip_set_option (include/seesaw_hip.h): per-handle form of the towers' tile path
-    OPT_IMAGE_ROWS_BF16, OPT_TEXT_ROWS_BF16, OPT_ATTN_DIRECT, OPT_ATTN_OUT_UNFUSED = 0, 1, 2, 3
+    OPT_IMAGE_ROWS_BF16, OPT_TEXT_ROWS_BF16, OPT_ATTN_DIRECT, OPT_ATTN_OUT_UNFUSED, OPT_FULL_LAST_LAYER = 0, 1, 2, 3, 4
 
     def set_option(self, option: int, value: bool):
         _lib.call("ssw_clip_set_option", self._h, int(option), int(bool(value)))

@@ -77,7 +77,7 @@ def test_residual_stream_precisions_vs_hf(models):
     for a, b in zip(got[0], got[3]):
         assert 0 < np.abs(a - b).max() <= 3e-3
     with pytest.raises(_lib.SeesawHipError):
-        ours.set_option(4, True)
+        ours.set_option(5, True)  # beyond SSW_CLIP_OPT_FULL_LAST_LAYER
 
 
 def test_image_attention_forms_give_the_same_bits(models):
@@ -282,6 +282,27 @@ def test_create_multiscale_index_round_trip(models, tmp_path):
     res = idx.query(vector=idx.string2vec("a photo"), topk=2, shortlist_size=4, agg_method="plain_score",
                     aug_larger="greater", rescore_method="plain")
     assert len(res["dbidxs"]) == 2 and set(res["dbidxs"].tolist()) <= {0, 1, 2, 3}
+
+
+def test_last_layer_on_the_pooled_rows_only_gives_the_full_forward_vectors(models):
+    """by default the image tower's last fc1 / fc2 run on the pooled (first) row of every image only -- the final LayerNorm
+    and the projection read nothing else; SSW_CLIP_OPT_FULL_LAST_LAYER runs them over every row as the reference's model
+    does.  Same vectors up to the products' summation order (fc2's K is split over workgroups on the pooled rows; fc1 on
+    200 rows takes the 128-square kernel where 10 000 rows take the 256-square one, and a bf16 hidden value may round the
+    other way): measured 1.1e-5 on unit vectors at 200 tiles, held to 5e-5 -- an eighth of the tower's 4e-4 against HF --
+    for a handful of tiles, 200 and a call that crosses the device chunk"""
+    _, ours = models
+    rng = np.random.default_rng(123)
+    try:
+        for n in (3, 200, 1030):
+            tiles = rng.integers(0, 256, size=(n, 224, 224, 3), dtype=np.uint8)
+            ours.set_option(ours.OPT_FULL_LAST_LAYER, False)
+            pooled = ours.embed_tiles_u8(tiles, normalize=True)
+            ours.set_option(ours.OPT_FULL_LAST_LAYER, True)
+            full = ours.embed_tiles_u8(tiles, normalize=True)
+            assert np.isfinite(pooled).all() and np.abs(pooled - full).max() <= 5e-5, (n, float(np.abs(pooled - full).max()))
+    finally:
+        ours.set_option(ours.OPT_FULL_LAST_LAYER, False)
 
 
 def test_more_tiles_than_one_device_chunk(models):

@@ -87,6 +87,35 @@ def test_plain_epilogues_against_torch_f32(lab_build, M, variant):
             assert np.isfinite(got).all() and (d <= tol).all(), (M, N, K, epi, variant, float(d.max()))
 
 
+@pytest.mark.parametrize("M", [1, 13, 129, 200, 257])
+def test_split_k_product_against_torch_f32(lab_build, M):
+    """launch_gemm_splitk_f32 (the last layer's fc2 on the pooled rows): K in 1 / 4 / 8 slices, the partial products added
+    in ascending order with bias [+ residual] -- against the f64 product of the same bf16-valued operands, 2e-4 as for the
+    other f32 outputs; a refused shape (K not a multiple of 64 x splits) raises"""
+    lib = lab_build
+    rng = np.random.default_rng(4000 + M)
+    for N, K in [(768, 3072), (512, 2048), (768, 768)]:
+        Ab, A = _bf16_bits(rng.standard_normal((M, K)))
+        Wb, W = _bf16_bits(rng.standard_normal((N, K)) * 0.05)
+        bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+        res = rng.standard_normal((M, N)).astype(np.float32)
+        prod = A.astype(np.float64) @ W.astype(np.float64).T + bias
+        for splits in (1, 4, 8) if K % 512 == 0 else (1, 4):
+            for residual in (None, res):
+                C = np.zeros((M, N), dtype=np.float32)
+                rc = lib.ssw_debug_gemm_run(8, splits, M, N, K, _p(Ab), _p(Wb), _p(bias), _p(residual), None, None, 0, None, 0.0, 0.0,
+                                            _p(C), None)
+                assert rc == 0, lib.ssw_last_error().decode()
+                ref = prod if residual is None else prod + res
+                d = np.abs(C - ref)
+                assert np.isfinite(C).all() and (d <= 2e-4).all(), (M, N, K, splits, float(d.max()))
+    Ab, _ = _bf16_bits(rng.standard_normal((M, 768)))
+    Wb, _ = _bf16_bits(rng.standard_normal((768, 768)))
+    C = np.zeros((M, 768), dtype=np.float32)
+    assert lib.ssw_debug_gemm_run(8, 8, M, 768, 768, _p(Ab), _p(Wb), _p(np.zeros(768, np.float32)), None, None, None, 0, None, 0.0, 0.0,
+                                  _p(C), None) != 0  # 768 is not a multiple of 64 x 8
+
+
 def _ln_case(rng, M, N, K):
     """a residual row block x (f32), LayerNorm parameters and a Linear; what the consumer product needs (GemmLn)"""
     x = (rng.standard_normal((M, K)) * 1.5 + rng.standard_normal((M, 1)) * 0.7).astype(np.float32)
