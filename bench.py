@@ -694,6 +694,13 @@ def main():
     ap.add_argument("--loop-images", type=int, default=120000, help="images of the full-size feedback-loop dataset")
     args = ap.parse_args()
 
+    # The job's stdout is ONE JSON line.  Libraries underneath write to file descriptor 1 whenever they like (RCCL's
+    # version banner at communicator creation, gloo's connection notes): for the whole run descriptor 1 points at
+    # stderr, and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -826,11 +833,6 @@ def main():
         index.close()
         if world == 1 and not args.no_extras:
             extras = {}
-            # libraries underneath print to the process's stdout (RCCL's version banner at communicator creation): the
-            # job's stdout is this function's one JSON line, so file descriptor 1 points at stderr while the extras run
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
             for key, fn in (("c2_one_million_rows", lambda: c2_extras(local_rank)),
                             ("sharded_step_12p5M_rows", lambda: sharded_step_extras(local_rank, k)),
                             ("feedback_fit", lambda: fit_extras(local_rank)),
@@ -840,13 +842,12 @@ def main():
                     extras[key] = fn()
                 except Exception as e:  # the headline metric above stands on its own
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
             out["extras"] = extras
         if replicas is not None:
             out["extras"] = {"feedback_loop_replicas": aggregate_replicas(replicas, world)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     index.close()
     if dist is not None:
         dist.barrier()
