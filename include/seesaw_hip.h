@@ -482,9 +482,12 @@ ssw_status ssw_clip_sync(ssw_clip *clip);
  *       a-12's arithmetic) -- the precision / throughput choice of an ingest job: 6 % more tiles per second for 4x the score
  *       error (1.5e-3 against 4e-4 on a unit query, tests/test_clip_gpu.py retrieval test); both forms meet the parity bar;
  *   SSW_CLIP_OPT_TEXT_ROWS_BF16 (1): residual rows of the text tower's batched path in bf16 (default f32);
- *   SSW_CLIP_OPT_FULL_LAST_LAYER (4): the image tower's last MLP over every row (as the reference's model runs it)
- *   instead of over the pooled rows only -- the embedding reads the first row of an image and nothing else, so the
- *   default leaves the other 49 rows of that fc1 / fc2 out; same vectors to ~1e-6 (fc2's summation order);
+ *   SSW_CLIP_OPT_FULL_LAST_LAYER (4): the image tower's last layer over every row (as the reference's model runs it)
+ *       instead of for the pooled rows only -- the embedding reads the first row of an image and nothing else, so the
+ *       default runs the last attention for row 0's query only (all keys and values), and the out-projection, fc1 and
+ *       fc2 on those B rows.  The vectors differ from the full layer's by 1.1e-5 at most on unit vectors (measured at
+ *       200 tiles; test bar 5e-5): the products on B rows select other tile kernels and split K over workgroups, so
+ *       sums are taken in another order and a bf16 hidden value may round the other way;
  *   SSW_CLIP_OPT_ATTN_DIRECT (2), SSW_CLIP_OPT_ATTN_OUT_UNFUSED (3): earlier kernel forms of the image tower's attention
  *       (fragments straight from memory; attention and out-projection as two launches) kept for A/B measurements.
  * Not part of the reference's interface (its precision choice is `.half()` on the whole model, embeddings.py:433-435). */

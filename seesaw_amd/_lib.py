@@ -220,8 +220,10 @@ def load_debug(path: str = DEBUG_LIB_PATH):
 class debug_hooks:
     """`with _lib.debug_hooks() as lib:` -- every `_lib.call` / `_lib.load()` inside the block goes to the lab build, so
     kernel variants can be flipped (ssw_tune_*) and single kernels driven (ssw_debug_*).  Handles are plain heap objects
-    of identical layout in both builds, but create and use them inside the block; tests and tools only -- product code
-    never enters it."""
+    whose layout is the same in both builds (the only lab-only state, ssw_clip's tap fields, is declared in both and
+    freed by either destroy), so a handle may cross the block's boundary; still, create and use handles inside the
+    block where you can -- the two libraries hold separate copies of every static (kernel-variant words, attribute
+    caches).  Tests and tools only: product code never enters it."""
 
     def __enter__(self):
         global _lib

@@ -39,6 +39,9 @@ __device__ __forceinline__ void ao_store(V *p, V v) {
     if constexpr ((SSW_AO_NT >> BIT) & 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+#ifndef SSW_AO_WO_LATE
+#define SSW_AO_WO_LATE 0  // the first Wo fragments (96 KB a workgroup, L2 hits) requested behind the first Q / K / V pairs instead of ahead of them
+#endif
 #ifndef SSW_AO_AHEAD
 #define SSW_AO_AHEAD 3  // head pairs of Q / K / V requested ahead: 3 (2 is level) ends phase 1 3 k cycles earlier than 4, whose burst delays the first pair
 #endif
@@ -104,12 +107,15 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
     const bf16 *w_lane = Wo + ((int64_t)wave * (AO_D / 64) * AO_NJ * 2 * 64 + lane) * 8;
     constexpr int W_STEP = AO_NJ * 2 * 64 * 8;  // elements per (wave, K-step)
     bf16x8 wf[PD][AO_NJ][2];
+    auto fetch_wf = [&]() {
 #pragma unroll
-    for (int s = 0; s < PD; ++s)
+        for (int s = 0; s < PD; ++s)
 #pragma unroll
-        for (int j = 0; j < AO_NJ; ++j)
+            for (int j = 0; j < AO_NJ; ++j)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) wf[s][j][h] = *reinterpret_cast<const bf16x8 *>(w_lane + s * W_STEP + (j * 2 + h) * 512);
+                for (int h = 0; h < 2; ++h) wf[s][j][h] = *reinterpret_cast<const bf16x8 *>(w_lane + s * W_STEP + (j * 2 + h) * 512);
+    };
+    if constexpr (SSW_AO_WO_LATE == 0) fetch_wf();
 
     // ---- phase 1: attention, a pair of heads per iteration
     {
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict
         constexpr int AHEAD = SSW_AO_AHEAD;
 #pragma unroll
         for (int p = 0; p < AHEAD; ++p) fetch(p);
+        if constexpr (SSW_AO_WO_LATE != 0) fetch_wf();  // behind the first pairs in the memory queue, not ahead of them
         const int ah = wave >> 2, qt = wave & 3;      // attention: head of the pair, query tile
         bf16 *const sK = reinterpret_cast<bf16 *>(smem + AO_SK) + ah * 4096;
         bf16 *const sV = reinterpret_cast<bf16 *>(smem + AO_SV) + ah * 4096;

@@ -993,6 +993,187 @@ __global__ __launch_bounds__(256) void gather_pooled_rows(const float *__restric
     if ((int)threadIdx.x < 2 * np) st_out[(int64_t)b * 2 * np + threadIdx.x] = st[src * 2 * np + threadIdx.x];
 }
 
+// The last layer's attention for the pooled row of an image only (round 5).  The embedding reads row 0 of an image
+// behind the last layer and nothing else (model.py:55-57, transformers' pooling), and attention mixes rows only
+// through the keys and values: row 0's query against the image's S keys is all the last attention has to compute.
+// One wave per (image, head) runs attention_rows64's query tile 0 -- the same fragments through the same MFMAs, the
+// same softmax -- and keeps row 0 of the tile: the bf16 values attn_outproj_image / attention_rows64 leave for that row,
+// bit for bit (a first version with plain f32 dot products differed from the full layer by 1e-4 on unit vectors: one
+// P or output element rounding the other way to bf16 is 0.4 % of it).  Reads K and V once: 2 S D bf16 per image.
+__global__ __launch_bounds__(64) void attn_pooled_rows(const bf16 *__restrict__ qkv, bf16 *__restrict__ out, int S, int D, int H,
+                                                       float scale) {
+    __shared__ __attribute__((aligned(16))) bf16 sKV[64 * 64];  // K rows (GEMM swizzle), later V rows (v_off)
+    __shared__ __attribute__((aligned(16))) bf16 sQP[16 * 64];  // the query tile's Q rows, then P
+    auto g_off = [](int row, int c16) { return row * 64 + ((c16 ^ ((row >> 1) & 7)) << 3); };
+    auto v_off = [](int key, int c32) { return key * 64 + ((c32 ^ (((key >> 1) & 1) | (((key >> 3) & 1) << 1))) << 4); };
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16 *base = qkv + (int64_t)b * S * 3 * D + h * 64;
+    bf16x8 kreg[8], vreg[8], qreg[2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = lane + c * 64, row = ch >> 3, d0 = (ch & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kreg[c][j] = vreg[c][j] = (bf16)0.f;
+        if (row < S) {
+            const bf16 *r = base + (int64_t)row * 3 * D + d0;
+            kreg[c] = *reinterpret_cast<const bf16x8 *>(r + D);
+            vreg[c] = *reinterpret_cast<const bf16x8 *>(r + 2 * D);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = lane + c * 64, row = ch >> 3, d0 = (ch & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qreg[c][j] = (bf16)0.f;
+        if (row < S) qreg[c] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)row * 3 * D + d0);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = lane + c * 64;
+        *reinterpret_cast<bf16x8 *>(&sKV[g_off(ch >> 3, ch & 7)]) = kreg[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = lane + c * 64;
+        *reinterpret_cast<bf16x8 *>(&sQP[g_off(ch >> 3, ch & 7)]) = qreg[c];
+    }
+    __syncthreads();
+    bf16x8 kf[4][2], qf[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) kf[j][ks] = *reinterpret_cast<const bf16x8 *>(&sKV[g_off(j * 16 + fr, ks * 4 + fq)]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(&sQP[g_off(fr, ks * 4 + fq)]);
+    f32x4 sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j][ks], qf[ks], sc[j], 0, 0, 0);
+    }
+    float mx = -INFINITY;  // this lane holds scores[query fr][key = 16 j + 4 fq + r]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = j * 16 + fq * 4 + r;
+            float v = sc[j][r] * scale;
+            if (key >= S) v = -INFINITY;
+            sc[j][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __expf(sc[j][r] - mx);
+            sc[j][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    __syncthreads();  // the Q and K fragments are in registers: P takes Q's bytes, V takes K's
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bf16x4 pv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = to_bf16(sc[j][r] * inv);
+        *reinterpret_cast<bf16x4 *>(&sQP[g_off(fr, j * 2 + (fq >> 1)) + (fq & 1) * 4]) = pv;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = lane + c * 64, key = ch >> 3, c16 = ch & 7;
+        *reinterpret_cast<bf16x8 *>(&sKV[v_off(key, c16 >> 1) + (c16 & 1) * 8]) = vreg[c];
+    }
+    __syncthreads();
+    f32x4 o[4];  // out^T tile = V^T P^T : o[dt][r] = out[query fr][d = 16 dt + 4 fq + r]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pa = *reinterpret_cast<const bf16x8 *>(&sQP[g_off(fr, ks * 4 + fq)]);
+        const int kq = ks * 32 + 8 * fq + (fr >> 2), dp = (fr & 3) * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            typedef __attribute__((ext_vector_type(4))) short s16x4;
+            typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sKV[v_off(kq, dt) + dp]));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&sKV[v_off(kq + 4, dt) + dp]));
+            const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, both), pa, o[dt], 0, 0, 0);
+        }
+    }
+    if (fr == 0) {  // query row 0 of the image
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = to_bf16(o[dt][r]);
+            *reinterpret_cast<bf16x4 *>(out + (int64_t)b * D + h * 64 + dt * 16 + fq * 4) = ov;
+        }
+    }
+}
+
+// ... and its out-projection on those B rows: the split-K partial products of att_p Wo^T (launch_gemm_splitk_partials) added in
+// ascending order, + bias + the residual row (row b S of the stack's rows: f32, or the bf16 stream's row) -> the pooled
+// row of hidden2 (f32), its bf16 copy and the two partial (sum, sum of squares) pairs over columns [0, D/2), [D/2, D)
+// that the fc1 product's folded LayerNorm reads -- what attn_outproj_image + gather_pooled_rows leave for these rows.
+__global__ __launch_bounds__(256) void pooled_outproj_finish(const float *__restrict__ part, int splits, int B, int S, int D,
+                                                             const float *__restrict__ bias, const float *__restrict__ res_f32,
+                                                             const bf16 *__restrict__ res_bf16, float *__restrict__ x_out,
+                                                             bf16 *__restrict__ xb_out, float *__restrict__ st_out) {
+    __shared__ float red[256][2];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int col = t * 4;
+    float sm = 0.f, sq = 0.f;
+    if (col < D) {
+        const int64_t o = (int64_t)b * D + col, mn = (int64_t)B * D;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(part + o);
+        for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (int64_t)z * mn + o);
+        v += *reinterpret_cast<const f32x4 *>(bias + col);
+        const int64_t ro = (int64_t)b * S * D + col;
+        if (res_f32) {
+            v += *reinterpret_cast<const f32x4 *>(res_f32 + ro);
+        } else {
+            const bf16x4 rb = *reinterpret_cast<const bf16x4 *>(res_bf16 + ro);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rb[r];
+        }
+        bf16x4 hb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb[r] = to_bf16(v[r]);
+        if (!res_f32) {  // bf16 stream: the row as stored is the row the statistics describe
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (float)hb[r];
+        }
+        *reinterpret_cast<f32x4 *>(x_out + o) = v;
+        *reinterpret_cast<bf16x4 *>(xb_out + o) = hb;
+        sm = (v[0] + v[1]) + (v[2] + v[3]);
+        sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    red[t][0] = sm;
+    red[t][1] = sq;
+    __syncthreads();
+    if (t < 2) {  // half t of the row: its D / 8 threads in order
+        const int n = D / 8;
+        float a = 0.f, c = 0.f;
+        for (int i = 0; i < n; ++i) {
+            a += red[t * n + i][0];
+            c += red[t * n + i][1];
+        }
+        st_out[(int64_t)b * 4 + t * 2] = a;
+        st_out[(int64_t)b * 4 + t * 2 + 1] = c;
+    }
+}
+
 __global__ void cls_rows(int B, int T, int *__restrict__ rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) rows[b] = b * T;
@@ -1057,11 +1238,12 @@ struct ssw_clip {
     // bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
     // bit 3 = attention and out-projection as two launches (round 3's layer) where attn_out.hip's one launch applies
     int flags = 0;
-#ifdef SSW_DEBUG_HOOKS
-    int tap_layer = -1, tap_tower = 0;  // ssw_clip_debug_tap: the residual rows behind this layer of this tower (0 image, 1 text) ...
+    // The lab build's tap (ssw_clip_debug_tap).  Declared in BOTH builds so that a handle has one layout whichever library
+    // created it (a product-made handle handed to the lab build's tap wrote past the allocation); the product
+    // never sets tap_layer and frees tap_buf, which only the lab build allocates, in its destroy as well.
+    int tap_layer = -1, tap_tower = 0;  // the residual rows behind this layer of this tower (0 image, 1 text) ...
     float *tap_buf = nullptr;           // ... as f32 [tap_rows][tap_dim]
     int64_t tap_rows = 0, tap_dim = 0, tap_cap = 0;
-#endif
 };
 
 namespace {
@@ -1350,22 +1532,40 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         const bool fused_attn = !unfused_ln && D % 256 == 0 && !causal && (c->flags & 8) == 0 &&
                                 attn_outproj_supports(S, D, tw.H) && ly.wo_pk != nullptr;
         if (fused_attn) {
-            if (bf16_stream) c->stream_in_xn = true;
-            SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo_pk, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
-                                        att_scale));
-            cons.stats_in = st_h2;
-            cons.c1 = ly.c1fc1;
-            cons.np_in = 2;
-            // The last layer's MLP on the pooled rows only: the final LayerNorm and the projection read the first row of
-            // every image and nothing else, and a row's MLP does not look at other rows -- 49 of an image's 50 rows of
-            // fc1 / fc2 (113 us of a B = 200 forward) feed nothing.  The rows are compacted (residual row, bf16 copy,
-            // statistics), fc1 runs on them as it is, fc2 -- 12 tiles with 48 K-steps each -- split over K.
-            // (The attention and the out-projection before it still run for every row.)
-            const bool full_last_layer = (c->flags & 16) != 0;  // SSW_CLIP_OPT_FULL_LAST_LAYER
+            // The last layer on the pooled rows only: the final LayerNorm and the projection read the first row of
+            // every image and nothing else.  A row's MLP does not look at other rows (round 4: fc1 / fc2 on B rows, 113 us
+            // of a B = 200 forward), and attention looks at other rows only through their keys and values (round 5): the
+            // last attention runs row 0's query against the image's keys (attn_pooled_rows), the out-projection on those B
+            // rows (split over K like the last fc2).  SSW_CLIP_OPT_FULL_LAST_LAYER runs every row as the reference's model does.
+            const bool full_last_layer = (c->flags & 16) != 0;
             bool pooled_only = l == tw.L - 1 && !full_last_layer && S >= 8 && M % 512 == 0;  // (S: the partial products borrow the qkv buffer)
 #ifdef SSW_DEBUG_HOOKS
             if (c->tap_layer == l && c->tap_tower == 0) pooled_only = false;  // the tap wants every row of this layer
 #endif
+            static const bool pooled_attn_off = getenv("SSW_CLIP_POOLED_MLP_ONLY") != nullptr;  // A/B: round 4's form
+            cons.c1 = ly.c1fc1;
+            cons.np_in = 2;
+            if (pooled_only && !pooled_attn_off && D % 256 == 0 && D <= 1024 && D / tw.H == 64 && S <= 64) {
+                bf16 *att_p = c->h1;                                    // [B][D]; fc1 writes h1 only after the product read it
+                float *partials = reinterpret_cast<float *>(c->qkv);     // free once attn_pooled_rows has read its keys and values
+                hipLaunchKernelGGL(attn_pooled_rows, dim3(B * tw.H), dim3(64), 0, s, c->qkv, att_p, S, D, tw.H, att_scale);
+                SSW_TRY(launch_gemm_splitk_partials(s, att_p, ly.wo, partials, B, D, D, 4));
+                hipLaunchKernelGGL(pooled_outproj_finish, dim3(B), dim3(256), 0, s, partials, 4, B, S, D, ly.bo,
+                                   bf16_stream ? (const float *)nullptr : h, c->xn, h2, c->att, st_h);
+                cons.stats_in = st_h;
+                SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->att, ly.w1_ln, ly.c2fc1, nullptr, c->h1, B, M, D, cons));
+                SSW_TRY(launch_gemm_splitk_f32(s, c->h1, ly.w2, ly.b2, h2, h, partials, B, D, M, 8));
+                c->pooled_compact = true;
+                c->stream_in_xn = false;  // the pooled rows are f32 rows of hidden whatever the stream's precision
+                continue;
+            }
+            if (bf16_stream) c->stream_in_xn = true;
+            SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo_pk, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
+                                        att_scale));
+            cons.stats_in = st_h2;
+            // round 4's form (SSW_CLIP_POOLED_MLP_ONLY=1): attention and out-projection for every row, then the rows are
+            // compacted (residual row, bf16 copy, statistics), fc1 runs on them as it is, fc2 -- 12 tiles with 48 K-steps
+            // each -- split over K
             if (pooled_only) {
                 float *res_p = h + (int64_t)B * D;  // hidden is free behind the out-projection: rows B .. 2B-1 take the residual rows
                 hipLaunchKernelGGL(gather_pooled_rows, dim3(B), dim3(256), 0, s, bf16_stream ? (const float *)nullptr : h2, c->xn, st_h2,
@@ -1557,9 +1757,7 @@ ssw_status ssw_clip_destroy(ssw_clip *c) {
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
                     (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
         (void)hipFree(p);
-#ifdef SSW_DEBUG_HOOKS
-    if (c->tap_buf) (void)hipFree(c->tap_buf);
-#endif
+    if (c->tap_buf) (void)hipFree(c->tap_buf);  // (allocated by the lab build's tap only; either build's destroy frees it)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SSW_OK;

@@ -36,7 +36,7 @@ __global__ void k_debug_maxdiff(const T *a, const T *b, int64_t n, float *out) {
 }  // namespace
 
 extern "C" ssw_status ssw_tune_gemm(int32_t variant) {
-    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15 &&
+    if (variant != 0 && variant != 2 && variant != 7 && variant != 9 && variant != 14 && variant != 15 && variant != 16 && variant != 17 &&
         !(variant >= 20 && variant <= 23)) {
         ssw::set_error("ssw_tune_gemm: variant %d unknown (0, 2, 7)", variant);
         return SSW_ERR_INVALID;

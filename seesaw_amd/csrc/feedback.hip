@@ -2454,6 +2454,7 @@ ssw_status ssw_fb_set_data(ssw_fb *fb, const float *X_host, int64_t n, int32_t c
     SSW_TRY(fb_reserve(fb, n));
     fb->n = n;
     fb->has_targets2 = false;
+    fb->targets_on_device = false;  // a new row set: the pseudo-sample's device-made targets (if any) went with the old one
     if (n > 0)
         SSW_HIP_TRY(hipMemcpyAsync(fb->X, X_host, (size_t)n * fb->dim * sizeof(float), hipMemcpyHostToDevice, fb->stream));
     SSW_TRY(fb_center(fb, center));
@@ -2471,6 +2472,7 @@ ssw_status ssw_fb_set_data_from_device(ssw_fb *fb, const float *dev_matrix, int6
     SSW_TRY(fb_reserve(fb, n));
     fb->n = n;
     fb->has_targets2 = false;
+    fb->targets_on_device = false;
     if (n > 0) {
         SSW_TRY(fb->rows_stage.push(fb->rows, rows_host, (size_t)n * sizeof(int64_t), fb->stream));
         hipLaunchKernelGGL(k_fb_gather_rows, dim3((unsigned)n), dim3(128), 0, fb->stream, dev_matrix, fb->rows, n,

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 
     // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*(128/WN) + j*16 + fq*4 + r]
     static_assert(!(PIPE && epi_ln(EPI)), "the LayerNorm-folded epilogues run on the two-stage loop");
-    if constexpr (epi_bf16_out(EPI) && WN == 4 && TM == 128 && !PIPE) {
+    if constexpr (epi_bf16_out(EPI) && !PIPE) {
         // another wave may still be reading its last fragments out of the bytes this wave is about to overwrite
         __syncthreads();
         store_rows_via_lds<EPI, 4, NJ>(acc, smem + wave * (64 * (NJ * 32 + 16)), lane, m0 + wm * 64, n0 + wn * (128 / WN), M, N,
@@ -645,24 +645,28 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                                        ln_c + 128 + wn * (128 / WN));
         return;
     }
-    if constexpr (epi_stats(EPI) && WN == 4 && TM == 128 && !PIPE) {
-        // The residual stream, the same way: the wave's 64 x 32 sub-tile goes through LDS as f32, 32 rows at a time
-        // (144-byte rows: the 16 rows of a write on different banks), and comes back row-major, four lanes a row with 8
-        // consecutive columns each.  bf16 stream (7): the row is read and written back in 16-byte pieces (64-byte
-        // segments per row) instead of 8-byte ones, the sum is taken in f32 as before, the statistics are those of the
-        // rounded values.  f32 stream (6): residual and output rows in 32-byte pieces (128-byte segments), the bf16 copy
-        // in 16-byte ones, statistics of the f32 values.  Partial sums: 8 per lane, the 4 lanes of the row, then the
-        // WN waves in wave order.
+    if constexpr (epi_stats(EPI) && !PIPE) {
+        // The residual stream, the same way: the wave's 64 x CW sub-tile (CW = 32 or 64 columns) goes through LDS as
+        // f32, 32 rows at a time (rows padded by 16 bytes: the 16 rows of a write on different banks), and comes back
+        // row-major, CW / 8 lanes a row with 8 consecutive columns each.  bf16 stream (7): the row is read and written
+        // back in 16-byte pieces instead of 8-byte ones, the sum is taken in f32 as before, the statistics are those of
+        // the rounded values.  f32 stream (6): residual and output rows in 32-byte pieces (128- / 256-byte segments),
+        // the bf16 copy in 16-byte ones, statistics of the f32 values.  Partial sums: 8 per lane, the lanes of the row
+        // (butterfly), then the WN waves in wave order.
         constexpr bool BF = EPI == EPI_BF16_STREAM_STATS;
-        constexpr int RBF = 32 * 4 + 16;
+        constexpr int CW = NJ * 16;       // columns of this wave
+        constexpr int RBF = CW * 4 + 16;  // bytes of a parked row
+        constexpr int LPR = CW / 8;       // lanes per row on the way back
+        constexpr int RPI = 64 / LPR;     // rows per pass
+        constexpr int NP = 64 / RPI;      // passes over the wave's 64 rows
         unsigned char *wl = smem + wave * (32 * RBF);
-        const int rr = lane >> 2, cc = lane & 3;
-        const int col0 = n0 + wn * 32 + cc * 8;
-        bf16x8 resb[4];
-        f32x4 resf[4][2];
+        const int rr = lane / LPR, cc = lane % LPR;
+        const int col0 = n0 + wn * CW + cc * 8;
+        bf16x8 resb[BF ? NP : 1];
+        f32x4 resf[BF ? 1 : NP][2];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {  // all four 16-row groups of the stream rows, requested before the LDS round trip
-            const int64_t o = (int64_t)min(m0 + wm * 64 + it * 16 + rr, M - 1) * N + col0;
+        for (int it = 0; it < NP; ++it) {  // every row group of the stream rows, requested before the LDS round trip
+            const int64_t o = (int64_t)min(m0 + wm * 64 + it * RPI + rr, M - 1) * N + col0;
             if constexpr (BF) {
                 resb[it] = epi_load(reinterpret_cast<const bf16x8 *>(ln.xcopy + o));
             } else {
@@ -676,14 +680,14 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #pragma unroll
             for (int il = 0; il < 2; ++il)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     *reinterpret_cast<f32x4 *>(wl + (il * 16 + fr) * RBF + j * 64 + fq * 16) = acc[2 * h + il][j];
 #pragma unroll
-            for (int il = 0; il < 2; ++il) {
-                const int it = 2 * h + il;
-                const int lrow = wm * 64 + it * 16 + rr;
-                f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32);
-                f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + (il * 16 + rr) * RBF + cc * 32 + 16);
+            for (int ps = 0; ps < NP / 2; ++ps) {
+                const int it = h * (NP / 2) + ps;
+                const int lrow = wm * 64 + it * RPI + rr;
+                f32x4 lo = *reinterpret_cast<const f32x4 *>(wl + (ps * RPI + rr) * RBF + cc * 32);
+                f32x4 hi = *reinterpret_cast<const f32x4 *>(wl + (ps * RPI + rr) * RBF + cc * 32 + 16);
                 bf16x8 o;
                 float ssum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -714,29 +718,32 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                         epi_store<1>(reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off + 4), hi);
                     }
                 }
-                ssum += __shfl_xor(ssum, 1, 64);
-                ssq += __shfl_xor(ssq, 1, 64);
-                ssum += __shfl_xor(ssum, 2, 64);
-                ssq += __shfl_xor(ssq, 2, 64);
+#pragma unroll
+                for (int sh = 1; sh < LPR; sh <<= 1) {
+                    ssum += __shfl_xor(ssum, sh, 64);
+                    ssq += __shfl_xor(ssq, sh, 64);
+                }
                 if (cc == 0) {
                     ln_lds[(wn * TM + lrow) * 2] = ssum;
                     ln_lds[(wn * TM + lrow) * 2 + 1] = ssq;
                 }
             }
         }
-    } else if constexpr ((EPI == EPI_F32 || EPI == EPI_F32_BIAS_RESIDUAL) && WN == 4 && TM == 128 && !PIPE) {
+    } else if constexpr ((EPI == EPI_F32 || EPI == EPI_F32_BIAS_RESIDUAL) && !PIPE) {
         // f32 outputs, the same way (a lane's 4 columns are 16 bytes here, but still 16 rows an instruction): 32 rows of
-        // the wave's 64 x 32 sub-tile at a time through LDS, back row-major, 8 lanes a row -- 128-byte segments for the
-        // store and for the residual row it adds
-        constexpr int RBF = 32 * 4 + 16;
+        // the wave's 64 x CW sub-tile at a time through LDS, back row-major, CW / 4 lanes a row -- 128- / 256-byte
+        // segments for the store and for the residual row it adds
+        constexpr int CW = NJ * 16;
+        constexpr int RBF = CW * 4 + 16;
+        constexpr int LPR = CW / 4, RPI = 64 / LPR, NP = 64 / RPI;
         unsigned char *wl = smem + wave * (32 * RBF);
-        const int rr = lane >> 3, cc = lane & 7;
-        const int col0 = n0 + wn * 32 + cc * 4;
-        f32x4 res[8];
+        const int rr = lane / LPR, cc = lane % LPR;
+        const int col0 = n0 + wn * CW + cc * 4;
+        f32x4 res[EPI == EPI_F32_BIAS_RESIDUAL ? NP : 1];
         if constexpr (EPI == EPI_F32_BIAS_RESIDUAL) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                res[it] = *reinterpret_cast<const f32x4 *>(residual + (int64_t)min(m0 + wm * 64 + it * 8 + rr, M - 1) * N + col0);
+            for (int it = 0; it < NP; ++it)
+                res[it] = *reinterpret_cast<const f32x4 *>(residual + (int64_t)min(m0 + wm * 64 + it * RPI + rr, M - 1) * N + col0);
         }
         __syncthreads();  // another wave may still be reading its last fragments out of these bytes
 #pragma unroll
@@ -744,13 +751,13 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #pragma unroll
             for (int il = 0; il < 2; ++il)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     *reinterpret_cast<f32x4 *>(wl + (il * 16 + fr) * RBF + j * 64 + fq * 16) = acc[2 * h + il][j];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                f32x4 v = *reinterpret_cast<const f32x4 *>(wl + (it * 8 + rr) * RBF + cc * 16);
-                if constexpr (EPI == EPI_F32_BIAS_RESIDUAL) v += res[h * 4 + it];
-                const int row = m0 + wm * 64 + h * 32 + it * 8 + rr;
+            for (int it = 0; it < NP / 2; ++it) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(wl + (it * RPI + rr) * RBF + cc * 16);
+                if constexpr (EPI == EPI_F32_BIAS_RESIDUAL) v += res[h * (NP / 2) + it];
+                const int row = m0 + wm * 64 + h * 32 + it * RPI + rr;
                 if (row < M) *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + (int64_t)row * N + col0) = v;
             }
         }
@@ -1076,6 +1083,10 @@ ssw_status launch_glds(hipStream_t s, const bf16 *A, const bf16 *W, const float 
 template <int EPI>
 ssw_status launch_auto(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, const float *res, void *C, int M,
                        int N, int K, const GemmLn &ln) {
+    // variants 16 / 17 (lab build): 256 x 128 tiles, 8 waves of 64 x 64 (16 fragment reads per 32 MFMAs where the 64 x 32
+    // waves of the 128-square kernel read 12 per 16), one workgroup per CU, three- / two-stage ring
+    if (g_gemm_variant == 16) return launch_glds<EPI, 3, 256, false, 2>(s, A, W, bias, res, C, M, N, K, ln);
+    if (g_gemm_variant == 17) return launch_glds<EPI, 2, 256, false, 2>(s, A, W, bias, res, C, M, N, K, ln);
     if constexpr (epi_bf16_out(EPI)) {  // (f32 outputs leave through LDS in the 128 x 128 kernel only)
         if (g_gemm_variant != 15 && N % 256 == 0) {
             int dev = 0;
@@ -1203,6 +1214,20 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__
     *reinterpret_cast<f32x4 *>(out + i) = v;
 }
 }  // namespace
+
+// the first launch alone: partials[z][M][N] = A[:, z K/splits ...] W[:, z K/splits ...]^T; the caller adds them up (ascending z)
+ssw_status launch_gemm_splitk_partials(hipStream_t s, const void *A, const void *W, float *partials, int M, int N, int K,
+                                       int splits) {
+    if (N % BN != 0 || M <= 0 || splits < 1 || K % (splits * BK) != 0 || !partials) {
+        set_error("gemm_splitk: shape M=%d N=%d K=%d in %d splits unsupported (N %% 128, K %% (64 splits))", M, N, K, splits);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((gemm_bf16_nt<EPI_F32, true>), dim3(N / BN, (M + BM - 1) / BM, splits), dim3(256), 0, s,
+                       static_cast<const bf16 *>(A), static_cast<const bf16 *>(W), (const float *)nullptr, (const float *)nullptr,
+                       (void *)partials, M, N, K, K / splits);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
 
 ssw_status launch_gemm_splitk_f32(hipStream_t s, const void *A, const void *W, const float *bias, const float *residual,
                                   float *out, float *partials, int M, int N, int K, int splits) {

@@ -160,6 +160,8 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const
 // products ([splits][M][N] f32 in `partials`) added in ascending order by a second launch
 ssw_status launch_gemm_splitk_f32(hipStream_t stream, const void *A, const void *W, const float *bias, const float *residual,
                                   float *out, float *partials, int M, int N, int K, int splits);
+ssw_status launch_gemm_splitk_partials(hipStream_t stream, const void *A, const void *W, float *partials, int M, int N, int K,
+                                       int splits);
 // attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image
 bool attn_outproj_supports(int S, int D, int H);
 ssw_status pack_attn_outproj_weight(hipStream_t stream, const void *Wo_768x768, void *out_same_size);

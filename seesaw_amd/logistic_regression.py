@@ -108,7 +108,8 @@ class LogisticRegressionPT:
         self._ensure_engine(dim)
         center = self.scale == "centered"
         if pseudo is not None:
-            assert self.class_weights != "balanced", "the targets of a device-assembled set are not on the host"
+            if self.class_weights == "balanced":  # (not an assert: python -O must not let it through)
+                raise ValueError("class_weights='balanced' needs the targets on the host; a device-assembled pseudo-sample has none")
             n_examples = self._engine.set_pseudo_sample(index, *pseudo, center=center)
         else:
             y = np.asarray(y, dtype=np.float64).reshape(-1)

@@ -141,16 +141,33 @@ class ShardedTopK:
         if not 1 <= k <= self.k_max:
             raise ValueError(f"k={k} outside [1, k_max={self.k_max}] of this exchange")
         stream_ptr = torch.cuda.current_stream().cuda_stream
+        timed = getattr(self, "_coll_events", None) is not None
+        if timed:  # HIP events on the stream the collective runs on (bench.py's allgather_us)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if getattr(self, "_comm", None):
             _lib.call("ssw_topk_allgather", self._comm, ctypes.c_void_p(stream_ptr), ctypes.c_void_p(self.send_buf.data_ptr()),
                       ctypes.c_void_p(self.all_buf.data_ptr()), self.msg_len)
         else:
             self.gather()
+        if timed:
+            e1.record()
+            self._coll_events.append((e0, e1))
         _lib.call("ssw_topk_merge_msgs_dev", int(self.all_buf.device.index), ctypes.c_void_p(stream_ptr),
                   ctypes.c_void_p(self.all_buf.data_ptr()), self.world, self.k_max, int(self.with_best), int(k),
                   ctypes.c_void_p(self.out_keys.data_ptr()), ctypes.c_void_p(self.out_count.data_ptr()),
                   ctypes.c_void_p(self.flags.data_ptr()), ctypes.c_void_p(self.flags_seen.data_ptr()))
         return self.out_keys, self.out_count
+
+    def time_collective(self, on: bool = True):
+        """bracket every exchange_fused collective with HIP events (two event records per step on the stream)"""
+        self._coll_events = [] if on else None
+
+    def collective_us(self):
+        """microseconds of each timed collective since time_collective(True) (synchronises)"""
+        ev = getattr(self, "_coll_events", None) or []
+        self.torch.cuda.synchronize()
+        return [1e3 * a.elapsed_time(b) for a, b in ev]
 
     def pack(self, local_keys, local_count, k: int, image_offset: Optional[int] = None, best_rows=None):
         """local_keys: int64 tensor [>=k] (bit pattern of the u64 keys, local image positions);

@@ -26,13 +26,16 @@ def bench(tmp_path, monkeypatch):
 
 def test_traffic_record_is_keyed_on_kernel_shape_and_source(bench):
     mod, root = bench
-    rec = {"kernel": mod.SCAN_KERNEL, "rows_per_launch": 1000, "kernel_source_sha256": mod.scan_source_sha256(),
-           "hbm_bytes_per_launch": 2052000.0, "git_head": "abc123"}
+    rec = {"kernel": mod.SCAN_KERNEL, "kernel_source_sha256": mod.scan_source_sha256(), "git_head": "abc123",
+           "shapes": {"1000": {"rows_per_launch": 1000, "hbm_bytes_per_launch": 2052000.0},
+                      "125": {"rows_per_launch": 125, "hbm_bytes_per_launch": 257000.0}}}
     path = root / "profiles" / "traffic.json"
     path.write_text(json.dumps(rec))
     val, note = mod.measured_traffic(1000)
     assert val == 2052000.0 and "abc123" in note
-    assert mod.measured_traffic(999)[0] is None                                  # another launch shape
+    assert mod.measured_traffic(125)[0] == 257000.0                              # one rank's launch of an 8-GPU run
+    val, note = mod.measured_traffic(999)
+    assert val is None and "125, 1000" in note                                   # another launch shape
     path.write_text(json.dumps(dict(rec, kernel="scan_scores_kernel<1,1,nt>")))
     assert mod.measured_traffic(1000)[0] is None                                 # another variant
     path.write_text(json.dumps(rec))
@@ -45,11 +48,13 @@ def test_traffic_record_is_keyed_on_kernel_shape_and_source(bench):
 
 
 def test_committed_traffic_record_matches_the_committed_kernel():
-    """the record under profiles/ belongs to the scan kernel in this tree"""
+    """the records under profiles/ belong to the scan kernel in this tree; the one-GPU shape and the shapes one rank of a
+    2 / 4 / 8-GPU run launches (VERDICT r4 #3: roofline.traffic must not be null at N > 1) are all there"""
     spec = importlib.util.spec_from_file_location("bench_real", os.path.join(ROOT, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    val, note = mod.measured_traffic(tj["rows_per_launch"])
-    assert val is not None, note
-    assert 0.98 < val / tj["algorithmic_bytes_per_launch"] < 1.10
+    for rows in (100_000_000, 50_000_000, 25_000_000, 12_500_000):
+        val, note = mod.measured_traffic(rows)
+        assert val is not None, note
+        assert 0.98 < val / tj["shapes"][str(rows)]["algorithmic_bytes_per_launch"] < 1.10

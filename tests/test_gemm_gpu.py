@@ -61,7 +61,7 @@ SHAPES = [(768, 768), (2304, 768), (768, 3072), (3072, 768), (512, 2048)]  # (N,
 ROWS = [1, 17, 127, 129, 255, 257, 650, 1000]
 
 
-@pytest.mark.parametrize("variant", [-1, 15, 9])  # the default choice, the 128 x 128 kernel, the 256 x 256 kernel
+@pytest.mark.parametrize("variant", [-1, 15, 9, 16, 17])  # the default choice, the 128 x 128 kernel, the 256 x 256 kernel, 256 x 128 (3 / 2 stages)
 @pytest.mark.parametrize("M", ROWS)
 def test_plain_epilogues_against_torch_f32(lab_build, M, variant):
     """epi 0-3: product, +bias -> bf16, +bias quick-GELU -> bf16, +bias +residual -> f32"""
@@ -137,7 +137,7 @@ def _ln_case(rng, M, N, K):
     return xb_bits, Wp_bits, c1, c2, stats, np_in, ref
 
 
-@pytest.mark.parametrize("variant", [-1, 15, 9])
+@pytest.mark.parametrize("variant", [-1, 15, 9, 16, 17])
 @pytest.mark.parametrize("M", [1, 129, 257, 650])
 def test_layernorm_folded_epilogues_against_a_true_f32_layernorm(lab_build, M, variant):
     """epi 4 / 5 (QKV and fc1 of the tile path): rstd (bf16(x) W'^T - mean c1) + c2 [quick-GELU] against LayerNorm(x) W^T + b"""
@@ -154,8 +154,9 @@ def test_layernorm_folded_epilogues_against_a_true_f32_layernorm(lab_build, M, v
             assert float(np.sqrt((d * d).mean())) <= 4e-3 * rms  # typical error: a tenth of the bound
 
 
+@pytest.mark.parametrize("variant", [-1, 16, 17])  # the default choice; 256 x 128 tiles (3 / 2 stages)
 @pytest.mark.parametrize("M", ROWS)
-def test_residual_stream_epilogues_against_torch_f32(lab_build, M):
+def test_residual_stream_epilogues_against_torch_f32(lab_build, M, variant):
     """epi 6 (f32 rows + bf16 copy + partial statistics) and 7 (the bf16 stream added to in place, statistics of the
     rounded values): out-projection and fc2 of the tile path"""
     lib = lab_build
@@ -168,7 +169,7 @@ def test_residual_stream_epilogues_against_torch_f32(lab_build, M):
         # epi 6
         res = rng.standard_normal((M, N)).astype(np.float32)
         xc = np.zeros((M, N), dtype=np.uint16)
-        got, st = _run(lib, 6, -1, Ab, Wb, bias=bias, residual=res, xcopy=xc)
+        got, st = _run(lib, 6, variant, Ab, Wb, bias=bias, residual=res, xcopy=xc)
         ref = prod + res
         assert (np.abs(got - ref) <= 2e-4).all(), (M, N, K, float(np.abs(got - ref).max()))
         assert np.array_equal(xc, _bf16_bits(got)[0])                       # the copy is the f32 output, rounded
@@ -177,7 +178,7 @@ def test_residual_stream_epilogues_against_torch_f32(lab_build, M):
         # epi 7
         x0_bits, x0 = _bf16_bits(rng.standard_normal((M, N)))
         xs = x0_bits.copy()
-        _, st = _run(lib, 7, -1, Ab, Wb, bias=bias, xcopy=xs)
+        _, st = _run(lib, 7, variant, Ab, Wb, bias=bias, xcopy=xs)
         new = _from_bits(xs)
         ref = prod + x0
         assert (np.abs(new - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-3).all(), (M, N, K, float(np.abs(new - ref).max()))
@@ -224,7 +225,7 @@ def test_fused_attention_outprojection_against_torch_f32(lab_build, B, S, f32_ro
     assert np.allclose(stats[:, :, 0], h.sum(2), rtol=0, atol=3e-3) and np.allclose(stats[:, :, 1], (h * h).sum(2), rtol=3e-5, atol=3e-3)
 
 
-@pytest.mark.parametrize("variant", [15, 9, 14])
+@pytest.mark.parametrize("variant", [15, 9, 14, 16, 17])
 @pytest.mark.parametrize("M", [1, 129, 257, 1000])
 def test_tile_gemm_variants_agree_with_the_register_staged_kernel(lab_build, M, variant):
     """the earlier self-comparison, kept as a second line: every tile kernel against variant 0 (the first, register-staged

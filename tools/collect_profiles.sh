@@ -10,10 +10,7 @@ export PYTHONPATH=.
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -o bench -- \
     python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_fetch" -o bench -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_write" -o bench -- \
-    python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_write.log" 2>&1
+bash tools/collect_traffic.sh "$OUT"   # FETCH_SIZE / WRITE_SIZE passes at 100 / 50 / 25 / 12.5 M rows per launch -> profiles/traffic.json
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/clip_trace" -o clip -- \
     python3 tools/perf_clip_b200.py 200 > "$OUT/clip_trace.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
@@ -28,7 +25,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn 
 python3 tools/perf_gemm.py 15 14 --lib > "$OUT/gemm_ab.txt" 2> "$OUT/gemm_ab.err" || true
 ( echo "# f32 rows (default)"; SSW_AO_STAMPS=1 python3 tools/attn_out_stamps.py; echo "# bf16 rows"; SSW_AO_STAMPS=1 SSW_CLIP_BF16_STREAM=1 python3 tools/attn_out_stamps.py ) 2>/dev/null | grep -v amdgpu > "$OUT/attn_out_stamps.txt" || true
 
-python3 tools/make_traffic_json.py "$OUT" 100000000 > "$OUT/traffic.log" 2>&1   # -> profiles/traffic.json (stamp git locally)
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"   # after the PMC passes: its roofline.traffic reads the file just made
 python3 tools/summarise_pmc.py "$OUT/bench_fetch" scan_scores > "$OUT/fetch_summary.csv"
 python3 tools/summarise_pmc.py "$OUT/bench_write" scan_scores > "$OUT/write_summary.csv"
