@@ -10,7 +10,10 @@ Parity status: every function here is pinned against outputs of the reference it
 which imports the reference from /root/reference) and against the reference's own
 known-answer tests where it has them (rank-loss table, distinct_topk_positions).
 CLIP is the exception: the reference holds no fixture for it and delegates the
-arithmetic to ``transformers`` -- see ``oracle/clip_oracle.py``.
+arithmetic to ``transformers`` (parity unpinned by the reference): its oracle is the
+in-container ``transformers.CLIPModel`` (f32, torch-CPU, seeded random-init weights),
+built and compared in ``tests/test_clip_gpu.py`` (fixture ``models``); there is no
+restatement of CLIP in this directory.
 """
 from __future__ import annotations
 

@@ -1,7 +1,9 @@
 """CPU, build container only: every committed fixture under tests/golden/ is what the committed generator
-produces from the reference TODAY -- `python oracle/gen_golden.py --check` regenerates all eight families into a
+produces from the reference TODAY -- `python oracle/gen_golden.py --check` regenerates all FOURTEEN families into a
 scratch directory (importing /root/reference, never touching a GPU) and fails on any byte of any array that
-differs.  Skipped where the reference is absent (the GPU box)."""
+differs.  The thirteen light families run in one generator process, `c5_sequence` (a dense 14 417 x 14 417 distance matrix
+and ~90 L-BFGS fits: about four minutes) in a second one beside it, so the pair costs the longer of the two.
+Skipped where the reference is absent (the GPU box)."""
 import os
 import subprocess
 import sys
@@ -10,15 +12,57 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFERENCE = "/root/reference"
+LIGHT = ("tiling", "sliding", "lknn", "scan_topk", "multiscale_query", "labelprop", "rank_loss", "logreg", "multireg", "bench_loop",
+         "multiregneg", "contweighted", "multireg_det")
+HEAVY = ("c5_sequence",)
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "seesaw")), reason="reference checkout not present")
 
 
-@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "seesaw")), reason="reference checkout not present")
-def test_all_golden_families_regenerate_byte_for_byte():
+@pytest.fixture(scope="module")
+def regen():
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""  # the generator must not need a GPU
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "gen_golden.py"), "--check"], cwd=ROOT,
-                          env=env, capture_output=True, text=True, timeout=900)
-    tail = "\n".join((proc.stdout + proc.stderr).splitlines()[-40:])
-    assert proc.returncode == 0, tail
-    for family in ("scan_topk", "multiscale_query", "labelprop", "rank_loss", "logreg", "multireg", "bench_loop", "lknn"):
-        assert f"{family}: reproduced byte for byte" in proc.stdout, tail
+    gen = os.path.join(ROOT, "oracle", "gen_golden.py")
+    procs = {"light": subprocess.Popen([sys.executable, gen, "--check"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                       stderr=subprocess.STDOUT, text=True),
+             "heavy": subprocess.Popen([sys.executable, gen, "--check", *HEAVY], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                                       stderr=subprocess.STDOUT, text=True)}
+    out = {}
+    for tag, proc in procs.items():
+        try:
+            text, _ = proc.communicate(timeout=1500)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            text, _ = proc.communicate()
+            text += "\n[timed out]"
+        out[tag] = (proc.returncode, text)
+    return out
+
+
+def test_the_generator_knows_exactly_these_families():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import gen_golden
+    finally:
+        sys.path.pop(0)
+    assert set(gen_golden.FAMILIES) == set(LIGHT) | set(HEAVY) and set(gen_golden.HEAVY) == set(HEAVY)
+    have = {f[:-4] for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".npz")}
+    assert set(LIGHT) | set(HEAVY) <= have, sorted((set(LIGHT) | set(HEAVY)) - have)
+
+
+def test_all_light_golden_families_regenerate_byte_for_byte(regen):
+    rc, text = regen["light"]
+    tail = "\n".join(text.splitlines()[-40:])
+    assert rc == 0, tail
+    for family in LIGHT:
+        assert f"{family}: reproduced byte for byte" in text, (family, tail)
+
+
+def test_c5_sequence_regenerates_byte_for_byte(regen):
+    """the reference's own 30-round sessions at C5's small size (1 109 images x 13 tiles), all four loops"""
+    rc, text = regen["heavy"]
+    tail = "\n".join(text.splitlines()[-40:])
+    assert rc == 0, tail
+    for family in HEAVY:
+        assert f"{family}: reproduced byte for byte" in text, (family, tail)
