@@ -1122,58 +1122,6 @@ __global__ __launch_bounds__(64) void attn_pooled_rows(const bf16 *__restrict__ 
     }
 }
 
-// ... and its out-projection on those B rows: the split-K partial products of att_p Wo^T (launch_gemm_splitk_partials) added in
-// ascending order, + bias + the residual row (row b S of the stack's rows: f32, or the bf16 stream's row) -> the pooled
-// row of hidden2 (f32), its bf16 copy and the two partial (sum, sum of squares) pairs over columns [0, D/2), [D/2, D)
-// that the fc1 product's folded LayerNorm reads -- what attn_outproj_image + gather_pooled_rows leave for these rows.
-__global__ __launch_bounds__(256) void pooled_outproj_finish(const float *__restrict__ part, int splits, int B, int S, int D,
-                                                             const float *__restrict__ bias, const float *__restrict__ res_f32,
-                                                             const bf16 *__restrict__ res_bf16, float *__restrict__ x_out,
-                                                             bf16 *__restrict__ xb_out, float *__restrict__ st_out) {
-    __shared__ float red[256][2];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int col = t * 4;
-    float sm = 0.f, sq = 0.f;
-    if (col < D) {
-        const int64_t o = (int64_t)b * D + col, mn = (int64_t)B * D;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(part + o);
-        for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (int64_t)z * mn + o);
-        v += *reinterpret_cast<const f32x4 *>(bias + col);
-        const int64_t ro = (int64_t)b * S * D + col;
-        if (res_f32) {
-            v += *reinterpret_cast<const f32x4 *>(res_f32 + ro);
-        } else {
-            const bf16x4 rb = *reinterpret_cast<const bf16x4 *>(res_bf16 + ro);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rb[r];
-        }
-        bf16x4 hb;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hb[r] = to_bf16(v[r]);
-        if (!res_f32) {  // bf16 stream: the row as stored is the row the statistics describe
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (float)hb[r];
-        }
-        *reinterpret_cast<f32x4 *>(x_out + o) = v;
-        *reinterpret_cast<bf16x4 *>(xb_out + o) = hb;
-        sm = (v[0] + v[1]) + (v[2] + v[3]);
-        sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-    }
-    red[t][0] = sm;
-    red[t][1] = sq;
-    __syncthreads();
-    if (t < 2) {  // half t of the row: its D / 8 threads in order
-        const int n = D / 8;
-        float a = 0.f, c = 0.f;
-        for (int i = 0; i < n; ++i) {
-            a += red[t * n + i][0];
-            c += red[t * n + i][1];
-        }
-        st_out[(int64_t)b * 4 + t * 2] = a;
-        st_out[(int64_t)b * 4 + t * 2 + 1] = c;
-    }
-}
-
 __global__ void cls_rows(int B, int T, int *__restrict__ rows) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) rows[b] = b * T;
@@ -1233,6 +1181,7 @@ struct ssw_clip {
     bool pooled_compact = false;  // run_tower left only the pooled rows of the last layer, as rows 0 .. B-1 of hidden
     float *stats_a = nullptr, *stats_b = nullptr;  // [rows][D / 128][2] partial LayerNorm statistics of hidden / hidden2
     float *pixels = nullptr, *out = nullptr;
+    float *splitk = nullptr;  // [8][min(rows, SPLITK_MAX_ROWS)][D] f32: partial products of the text tower's split-K producers
     int *ids = nullptr, *rows = nullptr;
     // ssw_clip_set_option: bit 0 = bf16 residual rows in the image tower's tile path, bit 1 = bf16 rows in the text tower's,
     // bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
@@ -1368,12 +1317,14 @@ ssw_status gemm(hipStream_t s, const bf16 *A, const bf16 *W, const float *bias, 
     return launch_gemm_bf16_nt(EPI, s, A, W, bias, res, C, M, N, K);
 }
 
+constexpr int64_t SPLITK_MAX_ROWS = 4096;  // rows up to which a producer product may be split over K (its partial-product buffer)
+
 ssw_status reserve(ssw_clip *c, int64_t batch) {
     if (batch <= c->cap_batch) return SSW_OK;
     SSW_HIP_TRY(hipStreamSynchronize(c->stream));
     for (void *p : {(void *)c->hidden, (void *)c->hidden2, (void *)c->pooled, (void *)c->patch_out, (void *)c->xn,
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
-                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
+                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b, (void *)c->splitk})
         (void)hipFree(p);
     const Header &h = c->hdr;
     const int64_t Tv = (int64_t)(h.image / h.patch) * (h.image / h.patch) + 1;
@@ -1395,6 +1346,7 @@ ssw_status reserve(ssw_clip *c, int64_t batch) {
     SSW_HIP_TRY(hipMalloc((void **)&c->rows, batch * sizeof(int)));
     SSW_HIP_TRY(hipMalloc((void **)&c->stats_a, rows * (D / 128 + 1) * 2 * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&c->stats_b, rows * (D / 128 + 1) * 2 * sizeof(float)));
+    SSW_HIP_TRY(hipMalloc((void **)&c->splitk, 8 * std::min<int64_t>(rows, SPLITK_MAX_ROWS) * D * sizeof(float)));
     c->cap_batch = batch;
     return SSW_OK;
 }
@@ -1545,13 +1497,22 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             static const bool pooled_attn_off = getenv("SSW_CLIP_POOLED_MLP_ONLY") != nullptr;  // A/B: round 4's form
             cons.c1 = ly.c1fc1;
             cons.np_in = 2;
-            if (pooled_only && !pooled_attn_off && D % 256 == 0 && D <= 1024 && D / tw.H == 64 && S <= 64) {
+            if (pooled_only && !pooled_attn_off && !bf16_stream && D / tw.H == 64 && S <= 64) {
+                // Two launches: row 0's attention, then the out-projection of those B rows as the tile GEMM's producer
+                // form (bias-started accumulators, k ascending, + the residual row b S of the stack: GemmLn::res_ld) -- the
+                // f32 row and the bf16 copy attn_outproj_image leaves for that row, bit for bit; only the partial
+                // statistics are cut differently (six 128-column pairs instead of two halves).  Measured first and
+                // dropped: the product split over K (another summation order moves the row by 1e-7, now and then its
+                // bf16 copy by a whole ulp, and the vectors by 7e-5 where this form moves them by 2e-5), and separate
+                // gather / finish passes (every launch of this tail is ~5 us on a slow box, whatever it does).
                 bf16 *att_p = c->h1;                                    // [B][D]; fc1 writes h1 only after the product read it
-                float *partials = reinterpret_cast<float *>(c->qkv);     // free once attn_pooled_rows has read its keys and values
+                float *partials = reinterpret_cast<float *>(c->qkv);     // (fc2's partial products; free once the keys and values are read)
                 hipLaunchKernelGGL(attn_pooled_rows, dim3(B * tw.H), dim3(64), 0, s, c->qkv, att_p, S, D, tw.H, att_scale);
-                SSW_TRY(launch_gemm_splitk_partials(s, att_p, ly.wo, partials, B, D, D, 4));
-                hipLaunchKernelGGL(pooled_outproj_finish, dim3(B), dim3(256), 0, s, partials, 4, B, S, D, ly.bo,
-                                   bf16_stream ? (const float *)nullptr : h, c->xn, h2, c->att, st_h);
+                prod.xcopy = c->att;
+                prod.stats_out = st_h;
+                prod.res_ld = (int64_t)S * D;
+                SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, att_p, ly.wo, ly.bo, h, h2, B, D, D, prod));
+                cons.np_in = np;
                 cons.stats_in = st_h;
                 SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->att, ly.w1_ln, ly.c2fc1, nullptr, c->h1, B, M, D, cons));
                 SSW_TRY(launch_gemm_splitk_f32(s, c->h1, ly.w2, ly.b2, h2, h, partials, B, D, M, 8));
@@ -1617,13 +1578,25 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             prod.stats_out = st_h;
             SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_STREAM_STATS, s, c->h1, ly.w2, ly.b2, nullptr, nullptr, R, D, M, prod));
         } else {
+            // Round 5: the text tower's N = 512 products are 40 tiles at 16 x 77 rows -- a launch as long as ONE workgroup's
+            // K loop (fc2: 32 steps, 31 us; 5 % of the MFMA peak on the whole tower).  Split over K in a fixed order
+            // (launch_gemm_splitk_stats: partial products, then one pass that adds them in ascending order with bias and
+            // residual and leaves the bf16 copy and the statistics) they are 160-320 workgroups of 2-4 steps.  Text tower
+            // only: the image tower's vectors must not depend on how many tiles share a call (the split is chosen by the row
+            // count), and its products fill the chip at the sizes that matter.
+            static const bool no_splitk = getenv("SSW_CLIP_NO_SPLITK") != nullptr;  // A/B
+            const int cus = num_cus(c->device);
+            const int sp_o = 1;  // (the out-projection's 8 steps split 4 ways: 9.2 + 5.3 us for the two launches against 8.5)
+            const int sp_2 = (causal && !no_splitk && R <= SPLITK_MAX_ROWS) ? splitk_choice(R, D, M, cus) : 1;
             prod.stats_out = st_h2;
-            SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->att, ly.wo, ly.bo, h, h2, R, D, D, prod));
+            if (sp_o > 1) SSW_TRY(launch_gemm_splitk_stats(s, c->att, ly.wo, ly.bo, h, h2, c->splitk, R, D, D, sp_o, prod));
+            else SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->att, ly.wo, ly.bo, h, h2, R, D, D, prod));
             cons.stats_in = st_h2;
             cons.c1 = ly.c1fc1;
             SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN_GELU, s, c->xn, ly.w1_ln, ly.c2fc1, nullptr, c->h1, R, M, D, cons));
             prod.stats_out = st_h;
-            SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
+            if (sp_2 > 1) SSW_TRY(launch_gemm_splitk_stats(s, c->h1, ly.w2, ly.b2, h2, h, c->splitk, R, D, M, sp_2, prod));
+            else SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->h1, ly.w2, ly.b2, h2, h, R, D, M, prod));
         }
         SSW_TAP(l, c->stream_in_xn ? nullptr : h, c->stream_in_xn ? c->xn : nullptr);
     }
@@ -1755,7 +1728,7 @@ ssw_status ssw_clip_destroy(ssw_clip *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     for (void *p : {(void *)c->hidden, (void *)c->hidden2, (void *)c->pooled, (void *)c->patch_out, (void *)c->xn,
                     (void *)c->qkv, (void *)c->att, (void *)c->h1, (void *)c->patches, (void *)c->pixels,
-                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b})
+                    (void *)c->out, (void *)c->ids, (void *)c->rows, (void *)c->stats_a, (void *)c->stats_b, (void *)c->splitk})
         (void)hipFree(p);
     if (c->tap_buf) (void)hipFree(c->tap_buf);  // (allocated by the lab build's tap only; either build's destroy frees it)
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -24,6 +24,7 @@
 // Measured and dropped: one LDS buffer with two barriers (-5...-25 %), a 3-stage ring at one workgroup per CU
 // (-20 %), 256-row tiles without the pipelined loop (-6 %), the pipelined loop on 128-row tiles (-7 %).
 #include "ssw_common.h"
+#include <cstdlib>
 
 namespace ssw {
 namespace {
@@ -664,14 +665,15 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
         const int col0 = n0 + wn * CW + cc * 8;
         bf16x8 resb[BF ? NP : 1];
         f32x4 resf[BF ? 1 : NP][2];
+        const int64_t res_ld = ln.res_ld ? ln.res_ld : (int64_t)N;
 #pragma unroll
         for (int it = 0; it < NP; ++it) {  // every row group of the stream rows, requested before the LDS round trip
-            const int64_t o = (int64_t)min(m0 + wm * 64 + it * RPI + rr, M - 1) * N + col0;
+            const int64_t rrow = min(m0 + wm * 64 + it * RPI + rr, M - 1);
             if constexpr (BF) {
-                resb[it] = epi_load(reinterpret_cast<const bf16x8 *>(ln.xcopy + o));
+                resb[it] = epi_load(reinterpret_cast<const bf16x8 *>(ln.xcopy + rrow * N + col0));
             } else {
-                resf[it][0] = epi_load(reinterpret_cast<const f32x4 *>(residual + o));
-                resf[it][1] = epi_load(reinterpret_cast<const f32x4 *>(residual + o + 4));
+                resf[it][0] = epi_load(reinterpret_cast<const f32x4 *>(residual + rrow * res_ld + col0));
+                resf[it][1] = epi_load(reinterpret_cast<const f32x4 *>(residual + rrow * res_ld + col0 + 4));
             }
         }
         __syncthreads();  // another wave may still be reading its last fragments out of these bytes
@@ -1101,6 +1103,19 @@ ssw_status launch_auto(hipStream_t s, const bf16 *A, const bf16 *W, const float 
             if (100 * tiles256 >= 85 * rounds * cus) return launch_256<EPI>(s, A, W, bias, res, C, M, N, K, ln);
         }
     }
+    // Few tiles (round 5): a launch of at most one workgroup per CU lasts as long as ONE workgroup's K loop, and with two
+    // stages that loop is a chain of memory round trips -- a K-step waits for the pieces requested one step earlier
+    // (~1 us a step whatever the tile: the text tower's 40-tile fc2 took 31 us for 32 steps).  Such launches get a
+    // four-stage ring (128 KB of the CU's LDS: nobody else wants it), three stages in flight; same sums in the same
+    // order, so a row's result does not depend on which ring its launch took.
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int64_t tiles128 = (int64_t)((M + 127) / 128) * (N / 128);
+        static const bool no_deep = getenv("SSW_GEMM_NO_DEEP_RING") != nullptr;  // A/B
+        if (!no_deep && g_gemm_variant == 14 && tiles128 <= num_cus(dev) && K >= 4 * BK)
+            return launch_glds<EPI, 4, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
+    }
     return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);
 }
 
@@ -1213,6 +1228,38 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__
     if (residual) v += *reinterpret_cast<const f32x4 *>(residual + i);
     *reinterpret_cast<f32x4 *>(out + i) = v;
 }
+// the producers' epilogue (EPI_F32_BIAS_RESIDUAL_STATS) behind a split-K product: a row per workgroup, four columns a
+// thread -- partial products added in ascending order, + bias + residual -> the f32 row, its bf16 copy, and the (sum,
+// sum of squares) of each 128-column tile (32 threads: a butterfly inside the half wave) for the next product's LayerNorm
+__global__ __launch_bounds__(256) void k_splitk_reduce_stats(const float *__restrict__ part, int splits, int M, int N,
+                                                             const float *__restrict__ bias, const float *__restrict__ residual,
+                                                             float *__restrict__ out, bf16 *__restrict__ xcopy,
+                                                             float *__restrict__ stats_out) {
+    const int row = blockIdx.x, t = threadIdx.x, col = t * 4;
+    if (col >= N) return;  // (N / 4 is a multiple of 32: whole half waves leave)
+    const int64_t o = (int64_t)row * N + col, mn = (int64_t)M * N;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(part + o);
+    for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (int64_t)z * mn + o);
+    v += *reinterpret_cast<const f32x4 *>(bias + col);
+    v += *reinterpret_cast<const f32x4 *>(residual + o);
+    *reinterpret_cast<f32x4 *>(out + o) = v;
+    bf16x4 hb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hb[r] = to_bf16(v[r]);
+    *reinterpret_cast<bf16x4 *>(xcopy + o) = hb;
+    float sm = (v[0] + v[1]) + (v[2] + v[3]);
+    float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+    for (int sh = 1; sh < 32; sh <<= 1) {
+        sm += __shfl_xor(sm, sh, 64);
+        sq += __shfl_xor(sq, sh, 64);
+    }
+    if ((t & 31) == 0) {
+        float *so = stats_out + ((int64_t)row * (N / 128) + (t >> 5)) * 2;
+        so[0] = sm;
+        so[1] = sq;
+    }
+}
 }  // namespace
 
 // the first launch alone: partials[z][M][N] = A[:, z K/splits ...] W[:, z K/splits ...]^T; the caller adds them up (ascending z)
@@ -1246,4 +1293,28 @@ ssw_status launch_gemm_splitk_f32(hipStream_t s, const void *A, const void *W, c
 }
 
 }  // namespace ssw
+// A producer product (f32 row + bf16 copy + statistics) of FEW tiles, split over K (round 5: the text tower's N = 512
+// products at 16 x 77 rows are 40 tiles -- one workgroup's 32-step K loop long as one launch)
+namespace ssw {
+int splitk_choice(int M, int N, int K, int cus) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * (N / BN);
+    if (tiles * 4 > cus || K < 4 * BK) return 1;         // a good part of a round already, or nothing to split
+    int splits = 1;
+    while (splits < 8 && tiles * (splits * 2) <= 2 * cus && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
+    return splits;
+}
+ssw_status launch_gemm_splitk_stats(hipStream_t s, const void *A, const void *W, const float *bias, const float *residual,
+                                    float *out, float *partials, int M, int N, int K, int splits, const GemmLn &ln) {
+    if (N % BN != 0 || N > 1024 || !bias || !residual || !ln.xcopy || !ln.stats_out) {
+        set_error("gemm_splitk_stats: N=%d unsupported or a NULL operand", N);
+        return SSW_ERR_UNSUPPORTED;
+    }
+    SSW_TRY(launch_gemm_splitk_partials(s, A, W, partials, M, N, K, splits));
+    hipLaunchKernelGGL(k_splitk_reduce_stats, dim3(M), dim3(256), 0, s, partials, splits, M, N, bias, residual, out, ln.xcopy,
+                       ln.stats_out);
+    SSW_HIP_TRY(hipGetLastError());
+    return SSW_OK;
+}
+}  // namespace ssw
+
 

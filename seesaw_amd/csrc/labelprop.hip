@@ -232,7 +232,7 @@ __global__ __launch_bounds__(LP_BLOCK) void k_lp_sweep_fused(
 }
 
 // after sweep number `sweep_index` (1-based) that read buffer `src`: decide convergence
-__global__ void k_lp_check(LpState *st, double eps, int src) {
+__global__ void k_lp_check(LpState *st, double eps, int src, int dst) {
     if (st->done) return;
     const double m = __longlong_as_double((long long)st->maxdiff_bits);
     st->sweeps += 1;
@@ -240,7 +240,7 @@ __global__ void k_lp_check(LpState *st, double eps, int src) {
         st->done = 1;
         st->result_buf = src;  // converged: the reference returns the iterate that ENTERED this sweep
     } else {
-        st->result_buf = src ^ 1;  // `old_fvalues = new_fvalues`: the output of this sweep
+        st->result_buf = dst;  // `old_fvalues = new_fvalues`: the output of this sweep
     }
     st->maxdiff_bits = 0ull;
 }
@@ -261,6 +261,85 @@ __global__ void k_lp_scores_f32(const double *__restrict__ f, const unsigned cha
                                 int64_t n, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (is_label_or_null && is_label_or_null[i]) ? -INFINITY : (float)f[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// Incremental propagation (round 5, ssw_labelprop_run_resident).  Every call of the ranking loop starts from the SAME
+// installed prior and differs from the call before it in a handful of labels, so row i of iterate k can differ from
+// the previous call's only if a label changed within k hops of i.  The handle keeps the previous call's iterates
+// F[0..s] and, per sweep, the maximum of (F[k] - F[k-1])^2 over each block of 256 nodes; a call recomputes the rows
+// whose inputs changed (host: frontier sets through the transposed pattern), the maxima of the blocks they sit in,
+// and the per-sweep maximum over all blocks -- the same per-row arithmetic in the same order as the full sweeps
+// (products formed once, added in ascending position), so every value, the sweep count and the returned iterate
+// are what the full sweeps give, bit for bit (tests/test_labelprop_gpu.py), at a cost that does not depend on n.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lp_rows(const int64_t *__restrict__ rows, int64_t m, const int64_t *__restrict__ indptr,
+                                                 const int32_t *__restrict__ indices, const double *__restrict__ data,
+                                                 const double *__restrict__ wsum, const double *__restrict__ prior,
+                                                 const double *__restrict__ f_old, double *__restrict__ f_new,
+                                                 const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
+                                                 double lambda, double low_bound, double high_bound, LpState *__restrict__ st) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int64_t row = rows[i];
+    double sum = 0.0;
+    for (int64_t p = indptr[row], e = indptr[row + 1]; p < e; ++p) sum = __dadd_rn(sum, __dmul_rn(data[p], f_old[indices[p]]));
+    const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
+    double v = weighted / __dadd_rn(wsum[row], lambda);
+    if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
+    if (is_label[row]) v = label_val[row];
+    f_new[row] = v;
+}
+
+// max over a block of 256 nodes of (f_new - f_old)^2; blocks == nullptr: block b = blockIdx.x (all of them)
+__global__ __launch_bounds__(256) void k_lp_blockmax(const int64_t *__restrict__ blocks, int64_t n, const double *__restrict__ f_new,
+                                                     const double *__restrict__ f_old, double *__restrict__ bmax,
+                                                     const LpState *__restrict__ st_or_null) {
+    __shared__ double red[4];
+    if (st_or_null && st_or_null->done) return;  // a sweep enqueued past convergence wrote nothing
+    const int64_t b = blocks ? blocks[blockIdx.x] : (int64_t)blockIdx.x;
+    const int64_t row = b * 256 + threadIdx.x;
+    double d2 = 0.0;
+    if (row < n) {
+        const double d = __dadd_rn(f_new[row], -f_old[row]);
+        d2 = __dmul_rn(d, d);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x == 0) bmax[b] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(1024) void k_lp_levelmax(const double *__restrict__ bmax, int64_t nb, double *__restrict__ out) {
+    __shared__ double red[16];
+    double m = 0.0;
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) m = fmax(m, bmax[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmax(m, red[i]);
+        *out = m;
+    }
+}
+
+// label changes of an incremental call: ids [0, n_set) become labelled with vals, ids [n_set, n_set + n_unset) lose their label
+__global__ void k_lp_label_changes(const int64_t *__restrict__ ids, const double *__restrict__ vals, int64_t n_set, int64_t n_unset,
+                                   const double *__restrict__ prior, double *__restrict__ f0, unsigned char *__restrict__ is_label,
+                                   double *__restrict__ label_val) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_set + n_unset) return;
+    const int64_t r = ids[i];
+    if (i < n_set) {
+        is_label[r] = 1;
+        label_val[r] = vals[i];
+        f0[r] = vals[i];
+    } else {
+        is_label[r] = 0;
+        f0[r] = prior[r];
+    }
 }
 
 __global__ void k_lp_clear_labels(unsigned char *is_label, const int64_t *ids, int64_t n_labels) {
@@ -389,7 +468,8 @@ struct ssw_lp {
     double *data = nullptr;
     double *wsum = nullptr;
     double *prior = nullptr;
-    double *f[2] = {nullptr, nullptr};
+    static constexpr int KEEP = 8;            // iterates a tracked run keeps: F[0 .. KEEP - 1], i.e. up to KEEP - 1 sweeps
+    double *f[KEEP] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [0], [1] always; the rest on demand
     unsigned char *is_label = nullptr;
     double *label_val = nullptr;
     int64_t *ids = nullptr;
@@ -422,6 +502,27 @@ struct ssw_lp {
     int64_t *g_rows = nullptr, *g_rows_host = nullptr;
     double *g_vals = nullptr, *g_vals_host = nullptr;
     int64_t g_cap = 0;
+    // ---- incremental propagation (ssw_labelprop_run_resident): what the previous tracked run left behind
+    struct Track {
+        bool valid = false;               // f[0 .. levels], bmax[1 .. levels] and the labels below describe the previous call
+        int levels = 0;                   // sweeps whose iterates are kept (the previous call converged within them)
+        int sweeps = 0, result = 0;       // what the previous call returned (reused when the labels did not change)
+        double lambda = 0.0, eps = 0.0;
+        int max_iter = 0;
+        std::vector<int64_t> ids;         // installed labels, device positions, ascending
+        std::vector<double> vals;
+    } trk;
+    double *bmax[KEEP] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [k][blocks of 256 nodes]: max (f[k] - f[k-1])^2
+    double *level_max = nullptr;          // device [KEEP]
+    int64_t *inc_dev = nullptr, *inc_host = nullptr;  // packed per-call lists (device / pinned host), inc_cap words each
+    int64_t inc_cap = 0;
+    // host copy of the pattern (device row space) and its transpose, for the frontier sets; built on first use
+    std::vector<int64_t> h_indptr, ht_indptr;
+    std::vector<int32_t> h_indices, ht_indices;
+    std::vector<uint32_t> stamp, bstamp;  // per node / per block of 256 nodes: the epoch that last touched it
+    uint32_t epoch = 0;
+    // what the last propagation did (ssw_labelprop_last_run_info)
+    int64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 extern "C" {
@@ -442,8 +543,13 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
     (void)hipFree(lp->data);
     (void)hipFree(lp->wsum);
     (void)hipFree(lp->prior);
-    (void)hipFree(lp->f[0]);
-    (void)hipFree(lp->f[1]);
+    for (int k = 0; k < ssw_lp::KEEP; ++k) {
+        (void)hipFree(lp->f[k]);
+        (void)hipFree(lp->bmax[k]);
+    }
+    (void)hipFree(lp->level_max);
+    (void)hipFree(lp->inc_dev);
+    if (lp->inc_host) (void)hipHostFree(lp->inc_host);
     (void)hipFree(lp->is_label);
     (void)hipFree(lp->g_rows);
     (void)hipFree(lp->g_vals);
@@ -586,24 +692,27 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
                 break;
             }
     }
+    // the pattern stays on the host too: the incremental runs walk it (and its transpose) for their frontier sets
+    lp->h_indptr.assign(indptr_host, indptr_host + n + 1);
+    lp->h_indices.assign(indices_host, indices_host + nnz);
     *out = lp;
     return SSW_OK;
 }
 
-// one sweep f[src] -> f[src ^ 1]: the plain kernel, or the column-blocked one (same result, bit for bit)
-static void lp_launch_sweep(ssw_lp *lp, int src, double reg_lambda, double lo, double hi) {
+// one sweep f[src] -> f[dst]: the plain kernel, or the column-blocked one (same result, bit for bit)
+static void lp_launch_sweep(ssw_lp *lp, int src, int dst, double reg_lambda, double lo, double hi) {
     const int64_t n = lp->n;
     hipStream_t s = lp->stream;
     if (lp->nblk <= 1) {
         const unsigned grid = (unsigned)((n + LP_BLOCK - 1) / LP_BLOCK);
         hipLaunchKernelGGL(k_lp_sweep, dim3(grid), dim3(LP_BLOCK), 0, s, n, lp->indptr, lp->indices, lp->data, lp->wsum,
-                           lp->prior, lp->f[src], lp->f[src ^ 1], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state);
+                           lp->prior, lp->f[src], lp->f[dst], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state);
         return;
     }
 #define LP_FUSED(G)                                                                                                        \
     hipLaunchKernelGGL((k_lp_sweep_fused<G, LP_CHUNK>), dim3((unsigned)((n + (int64_t)(G) * LP_BLOCK - 1) / ((int64_t)(G) * LP_BLOCK))), \
                        dim3(LP_BLOCK), 0, s, n, lp->nblk, lp->bl_ptr, lp->bl_base_dev, lp->bl_indices, lp->bl_data, lp->wsum,       \
-                       lp->prior, lp->f[src], lp->f[src ^ 1], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state)
+                       lp->prior, lp->f[src], lp->f[dst], lp->is_label, lp->label_val, reg_lambda, lo, hi, lp->state)
     switch (lp->groups) {
         case 2: LP_FUSED(2); break;
         case 3: LP_FUSED(3); break;
@@ -631,6 +740,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
                     (long long)label_ids[i]);
     const int64_t n = lp->n;
     hipStream_t s = lp->stream;
+    lp->trk.valid = false;  // this path keeps two iterates and no block maxima: the next resident call starts over
     // bounds of the reference's sanity asserts: min(0, prior.min()) .. max(1, prior.max())
     double lo = 0.0, hi = 1.0;
     if (use_installed) {
@@ -706,8 +816,8 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
         batch = 8;  // a second batch means the hint was too short: full size from here on
         for (; issued < upto; ++issued) {
             const int src = issued & 1;
-            lp_launch_sweep(lp, src, reg_lambda, lo, hi);
-            hipLaunchKernelGGL(k_lp_check, dim3(1), dim3(1), 0, s, lp->state, eps, src);
+            lp_launch_sweep(lp, src, src ^ 1, reg_lambda, lo, hi);
+            hipLaunchKernelGGL(k_lp_check, dim3(1), dim3(1), 0, s, lp->state, eps, src, src ^ 1);
         }
         SSW_HIP_TRY(hipGetLastError());
         SSW_HIP_TRY(hipMemcpyAsync(&st, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
@@ -721,6 +831,8 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
     }
     lp->last_result = (st.sweeps > 0) ? st.result_buf : 0;
     lp->sweeps_hint = st.done ? (int)st.sweeps : 0;
+    lp->info[0] = 0, lp->info[1] = st.sweeps, lp->info[2] = 2 * (int64_t)issued + 2, lp->info[3] = (issued + 7) / 8 + 0,
+    lp->info[4] = (int64_t)issued * n, lp->info[5] = 0;
     *st_out = st;
     return SSW_OK;
 }
@@ -820,6 +932,282 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
     lp->prior_lo = lo;
     lp->prior_hi = hi;
     lp->prior_installed = true;
+    lp->trk.valid = false;  // the kept iterates belong to the prior that was just replaced
+    return SSW_OK;
+}
+
+// ---- the tracked run behind ssw_labelprop_run_resident (see k_lp_rows above) ------------------------------------
+static ssw_status lp_ensure_level(ssw_lp *lp, int k) {
+    const int64_t nb = (lp->n + 255) / 256;
+    if (!lp->f[k]) SSW_HIP_TRY(hipMalloc((void **)&lp->f[k], (size_t)lp->n * sizeof(double) + 16));
+    if (!lp->bmax[k]) SSW_HIP_TRY(hipMalloc((void **)&lp->bmax[k], (size_t)nb * sizeof(double) + 16));
+    if (!lp->level_max) SSW_HIP_TRY(hipMalloc((void **)&lp->level_max, ssw_lp::KEEP * sizeof(double)));
+    return SSW_OK;
+}
+
+static ssw_status lp_inc_reserve(ssw_lp *lp, int64_t words) {
+    if (words <= lp->inc_cap) return SSW_OK;
+    SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    (void)hipFree(lp->inc_dev);
+    if (lp->inc_host) (void)hipHostFree(lp->inc_host);
+    lp->inc_dev = nullptr, lp->inc_host = nullptr, lp->inc_cap = 0;
+    int64_t cap = 1 << 16;
+    while (cap < words) cap <<= 1;
+    SSW_HIP_TRY(hipMalloc((void **)&lp->inc_dev, (size_t)cap * sizeof(int64_t)));
+    SSW_HIP_TRY(hipHostMalloc((void **)&lp->inc_host, (size_t)cap * sizeof(int64_t), hipHostMallocDefault));
+    lp->inc_cap = cap;
+    return SSW_OK;
+}
+
+// rows of the transposed pattern: ht row j lists the rows i with W[i][j] != 0, i.e. the rows whose sum reads f[j]
+static void lp_build_transpose(ssw_lp *lp) {
+    if (!lp->ht_indptr.empty()) return;
+    const int64_t n = lp->n, nnz = lp->nnz;
+    lp->ht_indptr.assign((size_t)n + 1, 0);
+    for (int64_t p = 0; p < nnz; ++p) lp->ht_indptr[(size_t)lp->h_indices[(size_t)p] + 1]++;
+    for (int64_t j = 0; j < n; ++j) lp->ht_indptr[(size_t)j + 1] += lp->ht_indptr[(size_t)j];
+    lp->ht_indices.resize((size_t)nnz);
+    std::vector<int64_t> fill(lp->ht_indptr.begin(), lp->ht_indptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t p = lp->h_indptr[(size_t)i]; p < lp->h_indptr[(size_t)i + 1]; ++p)
+            lp->ht_indices[(size_t)fill[(size_t)lp->h_indices[(size_t)p]]++] = (int32_t)i;
+    lp->stamp.assign((size_t)n, 0u);
+    lp->epoch = 0;
+}
+
+static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below KEEP, the last two alternate beyond
+    return k < ssw_lp::KEEP ? k : ssw_lp::KEEP - 2 + ((k - (ssw_lp::KEEP - 2)) & 1);
+}
+
+static ssw_status lp_upload_label_list(ssw_lp *lp, const std::vector<int64_t> &ids, const std::vector<double> &vals) {
+    const int64_t m = (int64_t)ids.size();
+    if (m > lp->ids_cap) {
+        SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+        (void)hipFree(lp->ids);
+        (void)hipFree(lp->vals);
+        lp->ids = nullptr, lp->vals = nullptr;
+        int64_t cap = 1024;
+        while (cap < m) cap <<= 1;
+        SSW_HIP_TRY(hipMalloc((void **)&lp->ids, (size_t)cap * sizeof(int64_t)));
+        SSW_HIP_TRY(hipMalloc((void **)&lp->vals, (size_t)cap * sizeof(double)));
+        lp->ids_cap = cap;
+    }
+    return SSW_OK;
+}
+
+static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const double *label_vals, int64_t n_labels,
+                                 double reg_lambda, double eps, int32_t max_iter, LpState *st_out) {
+    SSW_REQUIRE(reg_lambda >= 0.0, "reg_lambda < 0");
+    SSW_REQUIRE(max_iter >= 0, "max_iter < 0");
+    SSW_REQUIRE(n_labels == 0 || (label_ids && label_vals), "NULL labels");
+    for (int64_t i = 0; i < n_labels; ++i)
+        SSW_REQUIRE(label_ids[i] >= 0 && label_ids[i] < lp->n, "label id %lld out of range", (long long)label_ids[i]);
+    const int64_t n = lp->n, nb = (n + 255) / 256;
+    hipStream_t s = lp->stream;
+    const double lo = lp->prior_lo, hi = lp->prior_hi;
+    // the labels in device positions, ascending; duplicate ids (numpy: the last assignment wins) take the untracked path
+    const int64_t *mapped = lp_map_ids(lp, label_ids, n_labels);
+    std::vector<std::pair<int64_t, double>> lab((size_t)n_labels);
+    for (int64_t i = 0; i < n_labels; ++i) lab[(size_t)i] = {mapped[i], label_vals[i]};
+    std::sort(lab.begin(), lab.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    bool unique = true;
+    for (size_t i = 1; i < lab.size(); ++i) unique = unique && lab[i].first != lab[i - 1].first;
+    static const bool inc_off = getenv("SSW_LP_NO_INCREMENTAL") != nullptr;  // A/B and tests: every call runs the full sweeps
+    if (!unique || max_iter == 0)
+        return lp_run_core(lp, nullptr, true, nullptr, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, st_out);
+    std::vector<int64_t> ids((size_t)n_labels);
+    std::vector<double> vals((size_t)n_labels);
+    for (size_t i = 0; i < lab.size(); ++i) ids[i] = lab[i].first, vals[i] = lab[i].second;
+    SSW_TRY(lp_upload_label_list(lp, ids, vals));
+    ssw_lp::Track &tk = lp->trk;
+    LpState st;
+    memset(&st, 0, sizeof(st));
+
+    bool inc = !inc_off && tk.valid && tk.lambda == reg_lambda && tk.eps == eps && tk.max_iter == max_iter && tk.levels >= 1;
+    if (inc) {
+        // ---- what changed: labels set (new, or another value) and labels removed
+        std::vector<int64_t> set_ids, unset_ids;
+        std::vector<double> set_vals;
+        size_t a = 0, b = 0;
+        while (a < ids.size() || b < tk.ids.size()) {
+            if (b == tk.ids.size() || (a < ids.size() && ids[a] < tk.ids[b])) {
+                set_ids.push_back(ids[a]), set_vals.push_back(vals[a]), ++a;
+            } else if (a == ids.size() || tk.ids[b] < ids[a]) {
+                unset_ids.push_back(tk.ids[b]), ++b;
+            } else {
+                if (memcmp(&vals[a], &tk.vals[b], sizeof(double)) != 0) set_ids.push_back(ids[a]), set_vals.push_back(vals[a]);
+                ++a, ++b;
+            }
+        }
+        if (set_ids.empty() && unset_ids.empty()) {  // the same labels: the kept iterates ARE the answer
+            st.sweeps = tk.sweeps, st.done = 1, st.result_buf = tk.result;
+            lp->last_result = tk.result;
+            lp->info[0] = 1, lp->info[1] = st.sweeps, lp->info[2] = 0, lp->info[3] = 0, lp->info[4] = 0, lp->info[5] = tk.levels;
+            *st_out = st;
+            return SSW_OK;
+        }
+        // ---- frontier sets: row i of iterate k is recomputed when a label changed within k hops (walking the transposed
+        // pattern: the rows whose sums read a changed value).  The sets are nested, so ONE list in insertion order serves
+        // every level by its prefix; likewise the blocks of 256 nodes they touch.
+        lp_build_transpose(lp);
+        if (++lp->epoch == 0) {  // (wrapped)
+            std::fill(lp->stamp.begin(), lp->stamp.end(), 0u);
+            std::fill(lp->bstamp.begin(), lp->bstamp.end(), 0u);
+            lp->epoch = 1;
+        }
+        const uint32_t ep = lp->epoch;
+        std::vector<int64_t> members, blocks;
+        std::vector<int64_t> m_at((size_t)tk.levels + 1, 0), nb_at((size_t)tk.levels + 1, 0);
+        std::vector<uint32_t> &stamp = lp->stamp;
+        for (int64_t r : set_ids) if (stamp[(size_t)r] != ep) stamp[(size_t)r] = ep, members.push_back(r);
+        for (int64_t r : unset_ids) if (stamp[(size_t)r] != ep) stamp[(size_t)r] = ep, members.push_back(r);
+        const int64_t cap_rows = std::max<int64_t>(4096, n / 8);
+        size_t expanded = 0;
+        for (int k = 1; k <= tk.levels && inc; ++k) {
+            const size_t upto = members.size();
+            for (size_t q = expanded; q < upto; ++q) {
+                const int64_t j = members[q];
+                for (int64_t p = lp->ht_indptr[(size_t)j]; p < lp->ht_indptr[(size_t)j + 1]; ++p) {
+                    const int64_t i = lp->ht_indices[(size_t)p];
+                    if (stamp[(size_t)i] != ep) stamp[(size_t)i] = ep, members.push_back(i);
+                }
+            }
+            expanded = upto;
+            if ((int64_t)members.size() > cap_rows) inc = false;  // the change reaches a good part of the graph: full sweeps are cheaper
+            m_at[(size_t)k] = (int64_t)members.size();
+        }
+        if (inc) {  // the blocks of 256 nodes each level touches, in first-touch order (a level's blocks are a prefix too)
+            if (lp->bstamp.size() != (size_t)nb) lp->bstamp.assign((size_t)nb, 0u);
+            for (int k = 1; k <= tk.levels; ++k) {
+                for (int64_t q = m_at[(size_t)k - 1]; q < m_at[(size_t)k]; ++q) {
+                    const int64_t bb = members[(size_t)q] >> 8;
+                    if (lp->bstamp[(size_t)bb] != ep) lp->bstamp[(size_t)bb] = ep, blocks.push_back(bb);
+                }
+                nb_at[(size_t)k] = (int64_t)blocks.size();
+            }
+        }
+        if (inc) {
+            // ---- one packed upload: [set ids | unset ids | set values | members | blocks | all ids | all values]
+            const int64_t n_set = (int64_t)set_ids.size(), n_unset = (int64_t)unset_ids.size();
+            const int64_t o_ch = 0, o_sv = n_set + n_unset, o_mem = o_sv + n_set, o_blk = o_mem + (int64_t)members.size(),
+                          o_ids = o_blk + (int64_t)blocks.size(), o_vals = o_ids + n_labels, words = o_vals + n_labels + 32;
+            SSW_TRY(lp_inc_reserve(lp, words));
+            int64_t *hb = lp->inc_host;
+            for (int64_t i = 0; i < n_set; ++i) hb[o_ch + i] = set_ids[(size_t)i];
+            for (int64_t i = 0; i < n_unset; ++i) hb[o_ch + n_set + i] = unset_ids[(size_t)i];
+            memcpy(hb + o_sv, set_vals.data(), (size_t)n_set * sizeof(double));
+            memcpy(hb + o_mem, members.data(), members.size() * sizeof(int64_t));
+            memcpy(hb + o_blk, blocks.data(), blocks.size() * sizeof(int64_t));
+            memcpy(hb + o_ids, ids.data(), (size_t)n_labels * sizeof(int64_t));
+            memcpy(hb + o_vals, vals.data(), (size_t)n_labels * sizeof(double));
+            SSW_HIP_TRY(hipMemcpyAsync(lp->inc_dev, hb, (size_t)(o_vals + n_labels) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            int64_t *db = lp->inc_dev;
+            SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
+            hipLaunchKernelGGL(k_lp_label_changes, dim3((unsigned)((n_set + n_unset + 255) / 256)), dim3(256), 0, s, db + o_ch,
+                               reinterpret_cast<const double *>(db + o_sv), n_set, n_unset, lp->prior, lp->f[0], lp->is_label,
+                               lp->label_val);
+            int64_t rows_total = 0;
+            for (int k = 1; k <= tk.levels; ++k) {
+                const int64_t mk = m_at[(size_t)k], nbk = nb_at[(size_t)k];
+                rows_total += mk;
+                hipLaunchKernelGGL(k_lp_rows, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, s, db + o_mem, mk, lp->indptr,
+                                   lp->indices, lp->data, lp->wsum, lp->prior, lp->f[k - 1], lp->f[k], lp->is_label, lp->label_val,
+                                   reg_lambda, lo, hi, lp->state);
+                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nbk), dim3(256), 0, s, db + o_blk, n, lp->f[k], lp->f[k - 1],
+                                   lp->bmax[k], (const LpState *)nullptr);
+                hipLaunchKernelGGL(k_lp_levelmax, dim3(1), dim3(1024), 0, s, lp->bmax[k], nb, lp->level_max + k);
+            }
+            SSW_HIP_TRY(hipGetLastError());
+            // the device-side label list other entry points clear by (ids / vals of every installed label)
+            if (n_labels > 0) {
+                SSW_HIP_TRY(hipMemcpyAsync(lp->ids, db + o_ids, (size_t)n_labels * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+                SSW_HIP_TRY(hipMemcpyAsync(lp->vals, db + o_vals, (size_t)n_labels * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
+            lp->n_labels_installed = n_labels;
+            double *hres = reinterpret_cast<double *>(hb + o_vals + n_labels);  // [KEEP] level maxima, then the state
+            SSW_HIP_TRY(hipMemcpyAsync(hres, lp->level_max, ssw_lp::KEEP * sizeof(double), hipMemcpyDeviceToHost, s));
+            SSW_HIP_TRY(hipMemcpyAsync(hres + ssw_lp::KEEP, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
+            SSW_HIP_TRY(hipStreamSynchronize(s));
+            LpState dst;
+            memcpy(&dst, hres + ssw_lp::KEEP, sizeof(LpState));
+            tk.ids = ids, tk.vals = vals;  // the device now holds these labels whatever happens next
+            if (dst.bound_violation) {
+                tk.valid = false;
+                set_error("label propagation: averaged scores left [%g, %g] (label_propagation.py:39-40)", lo, hi);
+                return SSW_ERR_NUMERIC;
+            }
+            int conv = 0;
+            for (int k = 1; k <= tk.levels && !conv; ++k)
+                if (hres[k] < eps) conv = k;
+            if (conv) {
+                st.sweeps = conv, st.done = 1, st.result_buf = conv - 1;
+                tk.sweeps = conv, tk.result = conv - 1;
+                lp->last_result = conv - 1;
+                lp->sweeps_hint = conv;
+                lp->info[0] = 1, lp->info[1] = conv, lp->info[2] = 1 + 3 * (int64_t)tk.levels, lp->info[3] = 1, lp->info[4] = rows_total,
+                lp->info[5] = tk.levels;
+                *st_out = st;
+                return SSW_OK;
+            }
+            // the new labels need more sweeps than were kept: start over with the full sweeps (below), from the labels just installed
+        }
+    }
+
+    // ---- full sweeps, every iterate and its block maxima kept (the state the next call updates)
+    tk.valid = false;
+    SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (lp->n_labels_installed > 0) {
+        const int64_t m = lp->n_labels_installed;
+        hipLaunchKernelGGL(k_lp_clear_labels, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, lp->is_label, lp->ids, m);
+        lp->n_labels_installed = 0;
+    }
+    if (n_labels > 0) {
+        SSW_TRY(lp_inc_reserve(lp, 2 * n_labels + 64));
+        memcpy(lp->inc_host, ids.data(), (size_t)n_labels * sizeof(int64_t));
+        memcpy(lp->inc_host + n_labels, vals.data(), (size_t)n_labels * sizeof(double));
+        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, lp->inc_host, (size_t)n_labels * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        SSW_HIP_TRY(hipMemcpyAsync(lp->vals, lp->inc_host + n_labels, (size_t)n_labels * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_lp_apply_labels, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, lp->f[0], lp->is_label,
+                           lp->label_val, lp->ids, lp->vals, n_labels);
+        lp->n_labels_installed = n_labels;
+    }
+    SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
+    int issued = 0, syncs = 0;
+    int batch = lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 8;
+    while (issued < max_iter) {
+        const int upto = (issued + batch < max_iter) ? issued + batch : max_iter;
+        batch = 8;
+        for (; issued < upto; ++issued) {
+            const int k = issued + 1;  // this sweep produces iterate k
+            const int src = lp_iter_buf(k - 1), dst = lp_iter_buf(k);
+            if (k < ssw_lp::KEEP) SSW_TRY(lp_ensure_level(lp, k));
+            lp_launch_sweep(lp, src, dst, reg_lambda, lo, hi);
+            if (k < ssw_lp::KEEP)
+                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nb), dim3(256), 0, s, (const int64_t *)nullptr, n, lp->f[dst], lp->f[src],
+                                   lp->bmax[k], (const LpState *)lp->state);
+            hipLaunchKernelGGL(k_lp_check, dim3(1), dim3(1), 0, s, lp->state, eps, src, dst);
+        }
+        SSW_HIP_TRY(hipGetLastError());
+        SSW_HIP_TRY(hipMemcpyAsync(&st, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
+        SSW_HIP_TRY(hipStreamSynchronize(s));
+        ++syncs;
+        if (st.done) break;
+    }
+    if (st.bound_violation) {
+        set_error("label propagation: averaged scores left [%g, %g] (label_propagation.py:39-40)", lo, hi);
+        return SSW_ERR_NUMERIC;
+    }
+    lp->last_result = (st.sweeps > 0) ? st.result_buf : 0;
+    lp->sweeps_hint = st.done ? (int)st.sweeps : 0;
+    if (st.done && st.sweeps >= 1 && st.sweeps < ssw_lp::KEEP) {
+        tk.valid = true;
+        tk.levels = st.sweeps, tk.sweeps = st.sweeps, tk.result = st.result_buf;
+        tk.lambda = reg_lambda, tk.eps = eps, tk.max_iter = max_iter;
+        tk.ids = ids, tk.vals = vals;
+    }
+    lp->info[0] = 0, lp->info[1] = st.sweeps, lp->info[2] = 3 * (int64_t)issued + 3, lp->info[3] = syncs, lp->info[4] = (int64_t)issued * n,
+    lp->info[5] = tk.valid ? tk.levels : 0;
+    *st_out = st;
     return SSW_OK;
 }
 
@@ -830,9 +1218,18 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
     SSW_REQUIRE(lp->prior_installed, "ssw_labelprop_run_resident: no prior installed (ssw_labelprop_set_prior)");
     DeviceGuard guard(lp->device);
     LpState st;
-    SSW_TRY(lp_run_core(lp, nullptr, true, nullptr, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, &st));
+    SSW_TRY(lp_run_tracked(lp, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, &st));
     if (out_sweeps) *out_sweeps = st.sweeps;
     if (out_converged) *out_converged = st.done;
+    return SSW_OK;
+}
+
+/* what the last propagation of this handle did: out[0] = 1 if it was an incremental update (0: full sweeps),
+ * [1] sweeps (as the reference counts them), [2] kernel launches, [3] host synchronisations, [4] rows recomputed over all
+ * sweeps, [5] iterates kept for the next call, [6..7] 0 */
+ssw_status ssw_labelprop_last_run_info(ssw_lp *lp, int64_t *out8) {
+    SSW_REQUIRE(lp != nullptr && out8 != nullptr, "NULL argument");
+    memcpy(out8, lp->info, sizeof(lp->info));
     return SSW_OK;
 }
 
@@ -844,6 +1241,7 @@ ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, i
         SSW_REQUIRE(label_ids[i] >= 0 && label_ids[i] < lp->n, "label id %lld out of range", (long long)label_ids[i]);
     DeviceGuard guard(lp->device);
     hipStream_t s = lp->stream;
+    lp->trk.valid = false;
     SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)lp->n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (lp->n_labels_installed > 0) {
         const int64_t m = lp->n_labels_installed;

@@ -153,6 +153,8 @@ struct GemmLn {
     const float *c1 = nullptr;        // [N]
     __bf16 *xcopy = nullptr;          // producer: [M][N] bf16 copy of the f32 output
     float *stats_out = nullptr;       // producer: [M][N / 128][2]
+    int64_t res_ld = 0;               // producer (f32 rows): elements between consecutive residual rows, 0 = N (round 5: the
+                                      // pooled last layer adds row b S of the stack to row b of the product)
 };
 ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K, const GemmLn &ln);
@@ -160,6 +162,11 @@ ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const
 // products ([splits][M][N] f32 in `partials`) added in ascending order by a second launch
 ssw_status launch_gemm_splitk_f32(hipStream_t stream, const void *A, const void *W, const float *bias, const float *residual,
                                   float *out, float *partials, int M, int N, int K, int splits);
+// producer epilogue 6 (f32 row + bf16 copy + per-128-column statistics) behind a split-K product of few tiles;
+// splitk_choice: how many ways such a product is worth splitting (1 = not at all)
+int splitk_choice(int M, int N, int K, int cus);
+ssw_status launch_gemm_splitk_stats(hipStream_t stream, const void *A, const void *W, const float *bias, const float *residual,
+                                    float *out, float *partials, int M, int N, int K, int splits, const GemmLn &ln);
 ssw_status launch_gemm_splitk_partials(hipStream_t stream, const void *A, const void *W, float *partials, int M, int N, int K,
                                        int splits);
 // attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image

@@ -525,7 +525,10 @@ def test_trained_like_residual_distribution_both_forms(lab_build):
     """a random-init CLIP has none of the outlier channels / large mean-to-std ratios of a trained residual
     stream, which is where bf16 rows and the folded LayerNorm's `x W' - mean c1` cancellation lose the most.  Here the
     pre-LayerNorm of the image tower (and the token embedding of the text tower) puts values of magnitude 60-300 and a
-    non-zero row mean into a few channels of every residual row; both row precisions must still meet the bar."""
+    non-zero row mean into a few channels of every residual row; both row precisions must still meet the bar.
+    Round 5: 56 tiles (four 13-tile image pyramids and a ragged rest -- 2 800 token rows: 22 row tiles of the
+    128-row kernels, a ragged last one) and 16 sequences instead of 5 and 4, and the same 56 tiles once more as the tail of a
+    1 056-tile call, where they straddle the 1024-tile device chunk: the vectors must be the bytes of the short call."""
     import torch
     import transformers
     from seesaw_amd.models.clip import ClipModel
@@ -542,9 +545,9 @@ def test_trained_like_residual_distribution_both_forms(lab_build):
         emb[:, 511] += 250.0
     ours = ClipModel.from_hf(hf)
     torch.manual_seed(1)
-    x = torch.randn(5, 3, 224, 224)
+    x = torch.randn(56, 3, 224, 224)
     rng = np.random.default_rng(12)
-    ids = rng.integers(0, 49405, size=(4, 33)).astype(np.int64)
+    ids = rng.integers(0, 49405, size=(16, 33)).astype(np.int64)
     ids[:, 0], ids[:, -1] = 49406, 49407
     with torch.inference_mode():
         hs = hf.vision_model(pixel_values=x, output_hidden_states=True).hidden_states
@@ -564,6 +567,11 @@ def test_trained_like_residual_distribution_both_forms(lab_build):
                   f"|d| max {np.abs(gi - ref_i).max():.2e} / {np.abs(gt - ref_t).max():.2e}")
             assert ci >= COS_MIN and ct >= COS_MIN, (flags, ci, ct)
             assert np.abs(gi - ref_i).max() <= ABS_MAX and np.abs(gt - ref_t).max() <= ABS_MAX, flags
+            if flags == 0:  # across the device chunk boundary (tiles 1000 .. 1055 of one call)
+                big = np.concatenate([np.broadcast_to(x.numpy()[:1], (1000, 3, 224, 224)), x.numpy()])
+                gb = ours.embed_image(big, normalize=True)
+                del big
+                assert np.array_equal(gb[1000:], gi) and np.array_equal(gb[999], gi[0])
     finally:
         ours.close()
 
