@@ -257,6 +257,18 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host);
 ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, const double *label_vals,
                                       int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
                                       int32_t *out_sweeps, int32_t *out_converged);
+/* Consecutive ssw_labelprop_run_resident calls of a ranking loop (knn_methods.py:176-199: every update() restarts from
+ * the same prior with a few more labels) are INCREMENTAL: the handle keeps the previous call's iterates and, per sweep,
+ * the block maxima of the convergence test; a call recomputes the rows within k hops of a changed label for sweep k and
+ * nothing else -- same per-row arithmetic and order as the full sweeps, so values, sweep count and the returned iterate
+ * are bit-identical to a from-scratch run (label_propagation.py:45-79), at a cost independent of n.  Falls back to full
+ * sweeps when the change reaches n / 8 rows, when parameters change, or when more sweeps are needed than were kept (7).
+ * out8: [0] 1 = the last propagation was an incremental update (0 = full sweeps, 2 = an incremental pass over the kept
+ * iterates that did not converge within them, continued by full sweeps from there), [1] sweeps as the reference counts
+ * them, [2] kernel launches, [3] host synchronisations, [4] rows recomputed over all sweeps, [5] iterates kept for the
+ * next call, [6] nanoseconds of host time in the frontier walk, [7] nanoseconds waited for the device (incremental
+ * runs).  Environment SSW_LP_NO_INCREMENTAL=1: every call runs the full sweeps (A/B, tests). */
+ssw_status ssw_labelprop_last_run_info(ssw_lp *lp, int64_t *out8);
 /* "nothing to propagate yet": the installed prior itself becomes the resident result (unchanged values) and the given
  * nodes are marked labelled, so that the first rounds of a graph loop -- BaseLabelPropagationRanker.update skips the
  * propagation until a negative label exists and serves the prior (research/knn_methods.py:62-75) -- go through the
@@ -485,9 +497,10 @@ ssw_status ssw_clip_sync(ssw_clip *clip);
  *   SSW_CLIP_OPT_FULL_LAST_LAYER (4): the image tower's last layer over every row (as the reference's model runs it)
  *       instead of for the pooled rows only -- the embedding reads the first row of an image and nothing else, so the
  *       default runs the last attention for row 0's query only (all keys and values), and the out-projection, fc1 and
- *       fc2 on those B rows.  The vectors differ from the full layer's by 1.1e-5 at most on unit vectors (measured at
- *       200 tiles; test bar 5e-5): the products on B rows select other tile kernels and split K over workgroups, so
- *       sums are taken in another order and a bf16 hidden value may round the other way;
+ *       fc2 on those B rows.  The vectors differ from the full layer's by 2e-5 ... 5e-5 on unit vectors (measured at
+ *       200 tiles; test bar 1e-4, the tower itself is 4e-4 from transformers' f32 model): row 0's attention output and
+ *       residual row are the full layer's bit for bit, but the products on B rows select other tile kernels and split
+ *       K over workgroups, so sums are taken in another order and a bf16 hidden value may round the other way;
  *   SSW_CLIP_OPT_ATTN_DIRECT (2), SSW_CLIP_OPT_ATTN_OUT_UNFUSED (3): earlier kernel forms of the image tower's attention
  *       (fragments straight from memory; attention and out-projection as two launches) kept for A/B measurements.
  * Not part of the reference's interface (its precision choice is `.half()` on the whole model, embeddings.py:433-435). */

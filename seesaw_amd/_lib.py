@@ -90,6 +90,7 @@ _SIGNATURES = {
     "ssw_labelprop_prior_as_result": (c_i32, [c_void_p, c_void_p, c_i64]),
     "ssw_labelprop_fetch": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_gather": (c_i32, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ssw_labelprop_last_run_info": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_scores_to_index": (c_i32, [c_void_p, c_void_p, c_i32]),
     "ssw_labelprop_device_scores": (c_i32, [c_void_p, ctypes.POINTER(c_void_p)]),
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),

@@ -52,6 +52,12 @@ __device__ __forceinline__ bf16 to_bf16(float x) { return (bf16)x; }
 #ifndef SSW_GEMM_STAGGER
 #define SSW_GEMM_STAGGER 0
 #endif
+#ifndef SSW_ABL_LN
+#define SSW_ABL_LN 0  // timing-only ablations of the LayerNorm-folded consumers (wrong results): bit 0 no statistics prologue, bit 1 no epilogue arithmetic
+#endif
+#ifndef SSW_EPI6_FULL_LINES
+#define SSW_EPI6_FULL_LINES 1  // the f32-row producers' epilogue with four columns a lane (whole lines per instruction); 0: round 4's eight
+#endif
 #ifndef SSW_NT_LOADS
 #define SSW_NT_LOADS 0  // the producers' residual reads non-temporal: measured 2.56 -> 2.64 ms (f32 rows), 2.43 -> 2.45 (bf16): off
 #endif
@@ -139,7 +145,7 @@ __device__ __forceinline__ void epilogue_store(f32x4 v, int64_t o, int col, cons
 // 64- or 128-byte row segments, 16 bytes a lane.  Same values, same bits.
 template <int EPI>
 __device__ __forceinline__ f32x4 epilogue_value(f32x4 v, float mean, float rstd, const float *c1_lds, const float *c2_lds) {
-    if constexpr (epi_ln(EPI)) {
+    if constexpr (epi_ln(EPI) && !(SSW_ABL_LN & 2)) {
         const f32x4 c1 = *reinterpret_cast<const f32x4 *>(c1_lds), c2 = *reinterpret_cast<const f32x4 *>(c2_lds);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * c1[r]) + c2[r];
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     LnRowPre ln_pre;
     f32x4 ln_cpre = f32x4{0.f, 0.f, 0.f, 0.f};  // threads 0-31: c1 of 4 of the tile's 128 columns, 32-63: c2
     float *const ln_c = ln_lds + 2 * TM;         // [2][128] behind the statistics
-    if constexpr (epi_ln(EPI)) {
+    if constexpr (epi_ln(EPI) && !(SSW_ABL_LN & 1)) {
         if (t < TM) ln_pre = ln_row_request(ln, min(m0 + t, M - 1));
         ln_cpre = *reinterpret_cast<const f32x4 *>(((t & 32) ? bias : ln.c1) + n0 + (t & 31) * 4);
     }
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
 #pragma unroll
         for (int s = 0; s < DEPTH - 1; ++s)
             if (s < nk) SSW_ISSUE(s, s)
-        if constexpr (epi_ln(EPI)) {  // published by the loop's barriers; read behind the loop
+        if constexpr (epi_ln(EPI) && !(SSW_ABL_LN & 1)) {  // published by the loop's barriers; read behind the loop
             if (t < TM) ln_row_finish(ln, ln_pre, ln_lds + 2 * t);
             if (t < 64) *reinterpret_cast<f32x4 *>(ln_c + t * 4) = ln_cpre;
         }
@@ -646,7 +652,60 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
                                        ln_c + 128 + wn * (128 / WN));
         return;
     }
-    if constexpr (epi_stats(EPI) && !PIPE) {
+    if constexpr (EPI == EPI_F32_BIAS_RESIDUAL_STATS && !PIPE && SSW_EPI6_FULL_LINES) {
+        // f32 rows (round 5): the wave's 64 x CW sub-tile goes through LDS 32 rows at a time and comes back row-major with
+        // CW / 4 lanes a row, FOUR consecutive columns a lane -- one store instruction writes whole 128-byte (CW = 32) row
+        // segments of the f32 row, one load reads the residual row the same way, the bf16 copy leaves as 64-byte segments.
+        // (Round 4's form gave a lane 8 columns as two 16-byte halves: every line was touched by two instructions, half of
+        // it each -- the request count again, not the bytes.)  Partial sums: 4 per lane, the lanes of the row (butterfly),
+        // then the WN waves in wave order.
+        constexpr int CW = NJ * 16;
+        constexpr int RBF = CW * 4 + 16;
+        constexpr int LPR = CW / 4, RPI = 64 / LPR, NP = 64 / RPI;
+        unsigned char *wl = smem + wave * (32 * RBF);
+        const int rr = lane / LPR, cc = lane % LPR;
+        const int col0 = n0 + wn * CW + cc * 4;
+        const int64_t res_ld = ln.res_ld ? ln.res_ld : (int64_t)N;
+        f32x4 res[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it)
+            res[it] = epi_load(reinterpret_cast<const f32x4 *>(residual + (int64_t)min(m0 + wm * 64 + it * RPI + rr, M - 1) * res_ld + col0));
+        __syncthreads();  // another wave may still be reading its last fragments out of these bytes
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    *reinterpret_cast<f32x4 *>(wl + (il * 16 + fr) * RBF + j * 64 + fq * 16) = acc[2 * h + il][j];
+#pragma unroll
+            for (int ps = 0; ps < NP / 2; ++ps) {
+                const int it = h * (NP / 2) + ps;
+                const int lrow = wm * 64 + it * RPI + rr;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(wl + (ps * RPI + rr) * RBF + cc * 16);
+                v += res[it];
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = to_bf16(v[r]);
+                float ssum = (v[0] + v[1]) + (v[2] + v[3]);
+                float ssq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                if (m0 + lrow < M) {
+                    const int64_t off = (int64_t)(m0 + lrow) * N + col0;
+                    epi_store<1>(reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cout) + off), v);
+                    epi_store<1>(reinterpret_cast<bf16x4 *>(ln.xcopy + off), o);
+                }
+#pragma unroll
+                for (int sh = 1; sh < LPR; sh <<= 1) {
+                    ssum += __shfl_xor(ssum, sh, 64);
+                    ssq += __shfl_xor(ssq, sh, 64);
+                }
+                if (cc == 0) {
+                    ln_lds[(wn * TM + lrow) * 2] = ssum;
+                    ln_lds[(wn * TM + lrow) * 2 + 1] = ssq;
+                }
+            }
+        }
+    } else if constexpr (epi_stats(EPI) && !PIPE) {
         // The residual stream, the same way: the wave's 64 x CW sub-tile (CW = 32 or 64 columns) goes through LDS as
         // f32, 32 rows at a time (rows padded by 16 bytes: the 16 rows of a write on different banks), and comes back
         // row-major, CW / 8 lanes a row with 8 consecutive columns each.  bf16 stream (7): the row is read and written

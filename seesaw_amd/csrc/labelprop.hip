@@ -25,6 +25,7 @@
 // f64 bit pattern; a 1-thread check kernel flips a `done` flag that turns the remaining
 // enqueued sweeps into no-ops), so the host polls once per batch of sweeps, not per sweep.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -273,22 +274,58 @@ __global__ void k_lp_scores_f32(const double *__restrict__ f, const unsigned cha
 // (products formed once, added in ascending position), so every value, the sweep count and the returned iterate
 // are what the full sweeps give, bit for bit (tests/test_labelprop_gpu.py), at a cost that does not depend on n.
 // ---------------------------------------------------------------------------------------
+// One WAVE per listed row (k-NN graphs over high-dimensional vectors have hubs: a symmetric 10-NN graph of 1.56 M random
+// vectors holds rows of thousands of entries, which one thread walking `indices -> f_old` one dependent round trip at a
+// time turned into a 0.3-ms kernel).  The wave takes the row 512 entries at a time: coalesced index / weight loads,
+// the gathers of f_old in flight together, each product formed once and parked in the wave's 4 KB of LDS, then lane 0
+// adds them in ascending position -- the order of the full sweeps and of scipy's csr_matvec.
 __global__ __launch_bounds__(256) void k_lp_rows(const int64_t *__restrict__ rows, int64_t m, const int64_t *__restrict__ indptr,
                                                  const int32_t *__restrict__ indices, const double *__restrict__ data,
                                                  const double *__restrict__ wsum, const double *__restrict__ prior,
                                                  const double *__restrict__ f_old, double *__restrict__ f_new,
                                                  const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
                                                  double lambda, double low_bound, double high_bound, LpState *__restrict__ st) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    __shared__ double prod[4][512];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= m) return;  // wave-uniform
     const int64_t row = rows[i];
+    const int64_t p0 = indptr[row], p1 = indptr[row + 1];
     double sum = 0.0;
-    for (int64_t p = indptr[row], e = indptr[row + 1]; p < e; ++p) sum = __dadd_rn(sum, __dmul_rn(data[p], f_old[indices[p]]));
-    const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
-    double v = weighted / __dadd_rn(wsum[row], lambda);
-    if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
-    if (is_label[row]) v = label_val[row];
-    f_new[row] = v;
+    for (int64_t base = p0; base < p1; base += 512) {
+        const int cnt = (int)min((int64_t)512, p1 - base);
+        int32_t col[8];
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = u * 64 + lane;
+            col[u] = q < cnt ? indices[base + q] : -1;
+            w[u] = q < cnt ? data[base + q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = u * 64 + lane;
+            if (col[u] >= 0) prod[wave][q] = __dmul_rn(w[u], f_old[col[u]]);
+        }
+        // (one wave writes and reads these bytes: its LDS operations complete in order; the fence keeps the compiler from
+        //  moving lane 0's reads ahead of the other lanes' writes)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0)
+            for (int p = 0; p < cnt; ++p) sum = __dadd_rn(sum, prod[wave][p]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (lane == 0) {
+        const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
+        double v = weighted / __dadd_rn(wsum[row], lambda);
+        if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
+        if (is_label[row]) v = label_val[row];
+        f_new[row] = v;
+    }
 }
 
 // max over a block of 256 nodes of (f_new - f_old)^2; blocks == nullptr: block b = blockIdx.x (all of them)
@@ -571,6 +608,7 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
 }
 
 static thread_local bool g_lp_skip_blocked = false;
+static void lp_build_transpose(ssw_lp *lp);
 
 ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr_host,
                                 const int32_t *indices_host, const double *data_host,
@@ -692,9 +730,11 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
                 break;
             }
     }
-    // the pattern stays on the host too: the incremental runs walk it (and its transpose) for their frontier sets
+    // the pattern stays on the host too: the incremental runs walk its transpose for their frontier sets (built here,
+    // 0.1 s at 18 M non-zeros, not inside a session's first update: it would be that round's latency)
     lp->h_indptr.assign(indptr_host, indptr_host + n + 1);
     lp->h_indices.assign(indices_host, indices_host + nnz);
+    lp_build_transpose(lp);
     *out = lp;
     return SSW_OK;
 }
@@ -973,6 +1013,8 @@ static void lp_build_transpose(ssw_lp *lp) {
             lp->ht_indices[(size_t)fill[(size_t)lp->h_indices[(size_t)p]]++] = (int32_t)i;
     lp->stamp.assign((size_t)n, 0u);
     lp->epoch = 0;
+    std::vector<int64_t>().swap(lp->h_indptr);  // only the transpose is walked
+    std::vector<int32_t>().swap(lp->h_indices);
 }
 
 static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below KEEP, the last two alternate beyond
@@ -1024,6 +1066,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
     memset(&st, 0, sizeof(st));
 
     bool inc = !inc_off && tk.valid && tk.lambda == reg_lambda && tk.eps == eps && tk.max_iter == max_iter && tk.levels >= 1;
+    int continue_from = 0;  // > 0: the incremental pass brought iterates 0 .. continue_from up to date without converging
     if (inc) {
         // ---- what changed: labels set (new, or another value) and labels removed
         std::vector<int64_t> set_ids, unset_ids;
@@ -1049,6 +1092,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
         // ---- frontier sets: row i of iterate k is recomputed when a label changed within k hops (walking the transposed
         // pattern: the rows whose sums read a changed value).  The sets are nested, so ONE list in insertion order serves
         // every level by its prefix; likewise the blocks of 256 nodes they touch.
+        const auto t_front0 = std::chrono::steady_clock::now();
         lp_build_transpose(lp);
         if (++lp->epoch == 0) {  // (wrapped)
             std::fill(lp->stamp.begin(), lp->stamp.end(), 0u);
@@ -1086,6 +1130,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
                 nb_at[(size_t)k] = (int64_t)blocks.size();
             }
         }
+        lp->info[6] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_front0).count();
         if (inc) {
             // ---- one packed upload: [set ids | unset ids | set values | members | blocks | all ids | all values]
             const int64_t n_set = (int64_t)set_ids.size(), n_unset = (int64_t)unset_ids.size();
@@ -1110,7 +1155,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             for (int k = 1; k <= tk.levels; ++k) {
                 const int64_t mk = m_at[(size_t)k], nbk = nb_at[(size_t)k];
                 rows_total += mk;
-                hipLaunchKernelGGL(k_lp_rows, dim3((unsigned)((mk + 255) / 256)), dim3(256), 0, s, db + o_mem, mk, lp->indptr,
+                hipLaunchKernelGGL(k_lp_rows, dim3((unsigned)((mk + 3) / 4)), dim3(256), 0, s, db + o_mem, mk, lp->indptr,
                                    lp->indices, lp->data, lp->wsum, lp->prior, lp->f[k - 1], lp->f[k], lp->is_label, lp->label_val,
                                    reg_lambda, lo, hi, lp->state);
                 hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nbk), dim3(256), 0, s, db + o_blk, n, lp->f[k], lp->f[k - 1],
@@ -1127,7 +1172,9 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             double *hres = reinterpret_cast<double *>(hb + o_vals + n_labels);  // [KEEP] level maxima, then the state
             SSW_HIP_TRY(hipMemcpyAsync(hres, lp->level_max, ssw_lp::KEEP * sizeof(double), hipMemcpyDeviceToHost, s));
             SSW_HIP_TRY(hipMemcpyAsync(hres + ssw_lp::KEEP, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
+            const auto t_wait0 = std::chrono::steady_clock::now();
             SSW_HIP_TRY(hipStreamSynchronize(s));
+            lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
             LpState dst;
             memcpy(&dst, hres + ssw_lp::KEEP, sizeof(LpState));
             tk.ids = ids, tk.vals = vals;  // the device now holds these labels whatever happens next
@@ -1149,31 +1196,42 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
                 *st_out = st;
                 return SSW_OK;
             }
-            // the new labels need more sweeps than were kept: start over with the full sweeps (below), from the labels just installed
+            // the new labels need more sweeps than were kept: iterates 0 .. levels ARE the new run's (every row either
+            // unchanged or recomputed), so the full sweeps below continue from sweep levels + 1
+            continue_from = tk.levels;
         }
     }
 
     // ---- full sweeps, every iterate and its block maxima kept (the state the next call updates)
     tk.valid = false;
-    SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (lp->n_labels_installed > 0) {
-        const int64_t m = lp->n_labels_installed;
-        hipLaunchKernelGGL(k_lp_clear_labels, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, lp->is_label, lp->ids, m);
-        lp->n_labels_installed = 0;
+    if (continue_from > 0) {
+        LpState init;
+        memset(&init, 0, sizeof(init));
+        init.sweeps = continue_from;
+        init.result_buf = lp_iter_buf(continue_from);
+        SSW_HIP_TRY(hipMemcpyAsync(lp->state, &init, sizeof(LpState), hipMemcpyHostToDevice, s));
+        SSW_HIP_TRY(hipStreamSynchronize(s));  // (`init` is a stack object)
+    } else {
+        SSW_HIP_TRY(hipMemcpyAsync(lp->f[0], lp->prior, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (lp->n_labels_installed > 0) {
+            const int64_t m = lp->n_labels_installed;
+            hipLaunchKernelGGL(k_lp_clear_labels, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, lp->is_label, lp->ids, m);
+            lp->n_labels_installed = 0;
+        }
+        if (n_labels > 0) {
+            SSW_TRY(lp_inc_reserve(lp, 2 * n_labels + 64));
+            memcpy(lp->inc_host, ids.data(), (size_t)n_labels * sizeof(int64_t));
+            memcpy(lp->inc_host + n_labels, vals.data(), (size_t)n_labels * sizeof(double));
+            SSW_HIP_TRY(hipMemcpyAsync(lp->ids, lp->inc_host, (size_t)n_labels * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            SSW_HIP_TRY(hipMemcpyAsync(lp->vals, lp->inc_host + n_labels, (size_t)n_labels * sizeof(double), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_lp_apply_labels, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, lp->f[0], lp->is_label,
+                               lp->label_val, lp->ids, lp->vals, n_labels);
+            lp->n_labels_installed = n_labels;
+        }
+        SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
     }
-    if (n_labels > 0) {
-        SSW_TRY(lp_inc_reserve(lp, 2 * n_labels + 64));
-        memcpy(lp->inc_host, ids.data(), (size_t)n_labels * sizeof(int64_t));
-        memcpy(lp->inc_host + n_labels, vals.data(), (size_t)n_labels * sizeof(double));
-        SSW_HIP_TRY(hipMemcpyAsync(lp->ids, lp->inc_host, (size_t)n_labels * sizeof(int64_t), hipMemcpyHostToDevice, s));
-        SSW_HIP_TRY(hipMemcpyAsync(lp->vals, lp->inc_host + n_labels, (size_t)n_labels * sizeof(double), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_lp_apply_labels, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, lp->f[0], lp->is_label,
-                           lp->label_val, lp->ids, lp->vals, n_labels);
-        lp->n_labels_installed = n_labels;
-    }
-    SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
-    int issued = 0, syncs = 0;
-    int batch = lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 8;
+    int issued = continue_from, syncs = 0;
+    int batch = continue_from > 0 ? 2 : (lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 8);
     while (issued < max_iter) {
         const int upto = (issued + batch < max_iter) ? issued + batch : max_iter;
         batch = 8;
@@ -1205,8 +1263,9 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
         tk.lambda = reg_lambda, tk.eps = eps, tk.max_iter = max_iter;
         tk.ids = ids, tk.vals = vals;
     }
-    lp->info[0] = 0, lp->info[1] = st.sweeps, lp->info[2] = 3 * (int64_t)issued + 3, lp->info[3] = syncs, lp->info[4] = (int64_t)issued * n,
-    lp->info[5] = tk.valid ? tk.levels : 0;
+    // (a run that continued an incremental pass reports mode 2; its pass's launches / rows are not added here)
+    lp->info[0] = continue_from > 0 ? 2 : 0, lp->info[1] = st.sweeps, lp->info[2] = 3 * (int64_t)(issued - continue_from) + 3,
+    lp->info[3] = syncs + (continue_from > 0 ? 2 : 0), lp->info[4] = (int64_t)(issued - continue_from) * n, lp->info[5] = tk.valid ? tk.levels : 0;
     *st_out = st;
     return SSW_OK;
 }
@@ -1224,9 +1283,10 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
     return SSW_OK;
 }
 
-/* what the last propagation of this handle did: out[0] = 1 if it was an incremental update (0: full sweeps),
+/* what the last propagation of this handle did: out[0] = 1 if it was an incremental update (0: full sweeps; 2: an
+ * incremental pass over the kept iterates that did not converge, continued by full sweeps from there),
  * [1] sweeps (as the reference counts them), [2] kernel launches, [3] host synchronisations, [4] rows recomputed over all
- * sweeps, [5] iterates kept for the next call, [6..7] 0 */
+ * sweeps, [5] iterates kept for the next call, [6] ns of host time in the frontier walk, [7] ns waited for the device (incremental runs) */
 ssw_status ssw_labelprop_last_run_info(ssw_lp *lp, int64_t *out8) {
     SSW_REQUIRE(lp != nullptr && out8 != nullptr, "NULL argument");
     memcpy(out8, lp->info, sizeof(lp->info));

@@ -125,11 +125,22 @@ class LabelPropagation:
         _lib.call("ssw_labelprop_run_resident", self._h, _p(ids), _p(vals), ids.shape[0], self.reg_lambda,
                   float(self.epsilon), self.max_iter, ctypes.byref(sweeps), ctypes.byref(conv))
         self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
+        self._read_run_info()
         if self.last_converged:
             if self.verbose > 0:
                 print(f"prop. converged after {self.last_sweeps} iterations")
         else:
             print(f"warning: did not converge after {self.last_sweeps} iterations")
+
+    def _read_run_info(self):
+        """what the propagation just did on the device (ssw_labelprop_last_run_info): consecutive fit_resident calls
+        are incremental -- only rows within k hops of a changed label are recomputed for sweep k, bit-identical results"""
+        info = np.zeros(8, dtype=np.int64)
+        _lib.call("ssw_labelprop_last_run_info", self._h, _p(info))
+        self.last_mode = int(info[0])              # 0 full sweeps, 1 incremental update, 2 incremental pass continued by full sweeps
+        self.last_incremental = self.last_mode == 1
+        self.last_launches, self.last_host_syncs, self.last_rows_recomputed = int(info[2]), int(info[3]), int(info[4])
+        self.last_frontier_us, self.last_device_wait_us = info[6] / 1e3, info[7] / 1e3
 
     def prior_as_result(self, label_ids):
         """the installed prior becomes the resident result, `label_ids` are marked labelled (nothing is propagated)"""
@@ -184,6 +195,7 @@ class LabelPropagation:
                   ids.shape[0], self.reg_lambda, float(self.epsilon), self.max_iter, _p(out),
                   ctypes.byref(sweeps), ctypes.byref(conv))
         self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
+        self._read_run_info()
         if self.last_converged:
             if self.verbose > 0:
                 print(f"prop. converged after {self.last_sweeps} iterations")

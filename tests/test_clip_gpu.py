@@ -285,12 +285,16 @@ def test_create_multiscale_index_round_trip(models, tmp_path):
 
 
 def test_last_layer_on_the_pooled_rows_only_gives_the_full_forward_vectors(models):
-    """by default the image tower's last fc1 / fc2 run on the pooled (first) row of every image only -- the final LayerNorm
-    and the projection read nothing else; SSW_CLIP_OPT_FULL_LAST_LAYER runs them over every row as the reference's model
-    does.  Same vectors up to the products' summation order (fc2's K is split over workgroups on the pooled rows; fc1 on
-    200 rows takes the 128-square kernel where 10 000 rows take the 256-square one, and a bf16 hidden value may round the
-    other way): measured 1.1e-5 on unit vectors at 200 tiles, held to 5e-5 -- an eighth of the tower's 4e-4 against HF --
-    for a handful of tiles, 200 and a call that crosses the device chunk"""
+    """by default the image tower's LAST LAYER runs for the pooled (first) row of every image only -- the final LayerNorm and
+    the projection read nothing else: the last attention for row 0's query (all keys and values), the out-projection, fc1
+    and fc2 on B rows (round 4: the MLP; round 5: attention and out-projection too).  SSW_CLIP_OPT_FULL_LAST_LAYER runs every
+    row as the reference's model does.  Row 0's attention output, its f32 residual row and its bf16 copy are the full
+    layer's bit for bit; what differs is the order of a few f32 sums (the row statistics are cut into six 128-column pairs
+    instead of two halves, fc2's K is split over workgroups, fc1 on 200 rows takes the 128-square kernel where 10 000 rows
+    take the 256-square one), and now and then a bf16 hidden value that rounds the other way.  Measured on unit vectors:
+    1.1e-5 with the MLP alone (round 4), 2e-5 ... 5.0e-5 with the whole layer, over the collections of round 5; held to
+    1e-4 -- a quarter of the tower's 4e-4 against HF, whose bar (5e-3, cos 0.999) the default form meets on its own in
+    every other test of this file -- for a handful of tiles, 200 and a call that crosses the device chunk"""
     _, ours = models
     rng = np.random.default_rng(123)
     try:
@@ -300,7 +304,7 @@ def test_last_layer_on_the_pooled_rows_only_gives_the_full_forward_vectors(model
             pooled = ours.embed_tiles_u8(tiles, normalize=True)
             ours.set_option(ours.OPT_FULL_LAST_LAYER, True)
             full = ours.embed_tiles_u8(tiles, normalize=True)
-            assert np.isfinite(pooled).all() and np.abs(pooled - full).max() <= 5e-5, (n, float(np.abs(pooled - full).max()))
+            assert np.isfinite(pooled).all() and np.abs(pooled - full).max() <= 1e-4, (n, float(np.abs(pooled - full).max()))
     finally:
         ours.set_option(ours.OPT_FULL_LAST_LAYER, False)
 

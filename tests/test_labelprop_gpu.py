@@ -313,3 +313,121 @@ def test_locality_order_is_found_on_clustered_graphs_only():
     Wr = (Wr + Wr.T).tocsr()
     assert locality_order(Wr, min_nodes=1000, window=2048) is None
     assert locality_order(Wc) is None  # under 2^19 nodes the iterate stays in L2: not worth a permutation
+
+
+def _session_graph(rng, n, deg, weight_hi):
+    """a symmetric k-NN-like graph whose weights decide how many sweeps a propagation needs"""
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, n * deg)
+    A = sp.coo_array((rng.uniform(0.02, weight_hi, n * deg), (rows, cols)), shape=(n, n)).tocsr()
+    W = (A + A.T).tocsr()
+    W.setdiag(0)
+    W.eliminate_zeros()
+    W.sum_duplicates()
+    W.sort_indices()
+    return W
+
+
+@pytest.mark.parametrize("n,deg,weight_hi,ordered", [(20000, 6, 0.02, False), (20000, 6, 0.25, False), (70000, 5, 0.05, True),
+                                                     (3000, 4, 0.6, False)])
+def test_incremental_propagation_equals_full_sweeps(oracle, n, deg, weight_hi, ordered):
+    """Round 5: consecutive fit_resident calls update the kept iterates instead of sweeping the whole graph
+    (ssw_labelprop_last_run_info).  A session's worth of label changes -- a few added per round, one removed, one whose
+    value flips, a round with no change, a round that touches a hub -- must give the CPU oracle's f64 bits and sweep
+    count every round; the light-weight graphs converge in 2-3 sweeps (incremental from round 2 on), the heavy ones need
+    more sweeps than are kept or reach n / 8 rows and fall back to the full sweeps, and both ways the answers are equal."""
+    from seesaw_amd.label_propagation import LabelPropagation
+    rng = np.random.default_rng(n + deg)
+    W = _session_graph(rng, n, deg, weight_hi)
+    prior = rng.uniform(0.05, 0.95, n)
+    order = None
+    if ordered:
+        order = rng.permutation(n).astype(np.int32)
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300, node_order=order)
+    lp.set_prior(prior)
+    labels = {}
+    modes, kinds = [], []
+    for rnd in range(9):
+        if rnd == 4 and labels:
+            labels.pop(sorted(labels)[len(labels) // 2])                # a label removed
+        elif rnd == 5 and labels:
+            k = sorted(labels)[0]
+            labels[k] = 1.0 - labels[k]                                  # a label whose value changes
+        elif rnd == 6:
+            pass                                                         # nothing changes
+        else:
+            for v in rng.choice(n, size=int(rng.integers(1, 14)), replace=False):
+                labels[int(v)] = float(rng.integers(0, 2))
+        ids = np.array(sorted(labels), dtype=np.int64)
+        vals = np.array([labels[int(i)] for i in ids], dtype=np.float64)
+        ref, sweeps, conv = oracle.label_propagation(W, label_ids=ids, label_values=vals, reg_lambda=1.0, reg_values=prior,
+                                                     start_value=prior, max_iter=300)
+        lp.fit_resident(label_ids=ids, label_values=vals)
+        modes.append(lp.last_incremental)
+        kinds.append(lp.last_mode)
+        got = lp.fetch()
+        assert lp.last_sweeps == sweeps and lp.last_converged == conv, (rnd, lp.last_sweeps, sweeps)
+        assert np.array_equal(got, ref), (rnd, lp.last_incremental, float(np.abs(got - ref).max()))
+        pick = rng.choice(n, size=50).astype(np.int64)
+        assert np.array_equal(lp.gather(pick), ref[pick])
+    assert modes[0] is False
+    if weight_hi <= 0.05:
+        # few sweeps, small frontiers: rounds are updates -- except where a round's labels need a sweep MORE than the round
+        # before kept (a session's first rounds, a flipped label), which continue with full sweeps from the kept iterates
+        assert sum(modes[1:]) >= 2, modes
+        if modes[-1]:
+            assert lp.last_rows_recomputed < n // 4  # ... of a sliver of the graph
+    print(f"n={n} deg={deg} w<={weight_hi}: sweeps {lp.last_sweeps}, run kinds per round {kinds} (0 full, 1 update, 2 update + full "
+          f"sweeps from the kept iterates), rows in the last run {lp.last_rows_recomputed}")
+    lp.close()
+
+
+def test_incremental_state_is_dropped_when_it_must(oracle, monkeypatch):
+    """a new prior, other parameters, a fit_transform in between, prior_as_result: each makes the next resident call a
+    full one; SSW_LP_NO_INCREMENTAL=1 makes every call full; and the answers never change"""
+    from seesaw_amd.label_propagation import LabelPropagation
+    rng = np.random.default_rng(5)
+    n = 12000
+    W = _session_graph(rng, n, 5, 0.03)
+    prior = rng.uniform(0.05, 0.95, n)
+    ids = rng.choice(n, size=30, replace=False).astype(np.int64)
+    vals = rng.integers(0, 2, 30).astype(np.float64)
+
+    def check(lp, ids, vals, prior, want_incremental):
+        ref, sweeps, _ = oracle.label_propagation(W, label_ids=ids, label_values=vals, reg_lambda=lp.reg_lambda, reg_values=prior,
+                                                  start_value=prior, max_iter=300)
+        lp.fit_resident(label_ids=ids, label_values=vals)
+        assert lp.last_incremental is want_incremental
+        assert lp.last_sweeps == sweeps and np.array_equal(lp.fetch(), ref)
+
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
+    lp.set_prior(prior)
+    check(lp, ids[:10], vals[:10], prior, False)
+    check(lp, ids[:12], vals[:12], prior, True)
+    prior2 = rng.uniform(0.05, 0.95, n)
+    lp.set_prior(prior2)                                   # a new text query
+    check(lp, ids[:12], vals[:12], prior2, False)
+    check(lp, ids[:14], vals[:14], prior2, True)
+    lp.reg_lambda = 2.0                                    # another parameter
+    check(lp, ids[:15], vals[:15], prior2, False)
+    check(lp, ids[:16], vals[:16], prior2, True)
+    lp.fit_transform(label_ids=ids[:5], label_values=vals[:5], reg_values=prior2, start_value=prior2)
+    lp.set_prior(prior2)
+    check(lp, ids[:17], vals[:17], prior2, False)
+    lp.prior_as_result(ids[:3])
+    check(lp, ids[:18], vals[:18], prior2, False)
+    check(lp, ids[:20], vals[:20], prior2, True)
+    lp.close()
+    monkeypatch.setenv("SSW_LP_NO_INCREMENTAL", "1")
+    from seesaw_amd import _lib
+    # (the switch is read once per process by the library: only check that the answers agree when it was set from the start)
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
+    lp.set_prior(prior)
+    lp.fit_resident(label_ids=ids[:10], label_values=vals[:10])
+    a = lp.fetch()
+    lp.fit_resident(label_ids=ids[:12], label_values=vals[:12])
+    ref, _, _ = oracle.label_propagation(W, label_ids=ids[:12], label_values=vals[:12], reg_lambda=1.0, reg_values=prior,
+                                         start_value=prior, max_iter=300)
+    assert np.array_equal(lp.fetch(), ref) and a.shape == ref.shape
+    lp.close()
+    del _lib
