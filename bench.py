@@ -282,10 +282,10 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True, c
                     continue
                 from oracle import cpu_loop  # the CPU leg: the reference's expressions on the host cores
                 qvec = ds.load_index().string2vec("a c1")
-                # bounded CPU sample (0.25-0.5 s a round at 1.56 M vectors): the
+                # bounded CPU sample (0.25-0.9 s a round at 1.56 M vectors, 0.35-0.4 s for the L-BFGS loops at 14 417): the
                 # rounds compared here are a sample; all 30 rounds of every loop at the full size are compared in
                 # tests/test_c5_fullsize_gpu.py, and the reference's own 30-round sessions at the small size in test_c5_sequence_gpu.py
-                cpu_rounds = (4 if name in ("knn_prop2", "pseudo_lr") else 8) if full else 30
+                cpu_rounds = (4 if name in ("knn_prop2", "pseudo_lr") else 8) if full else (10 if name in ("multi_reg", "pseudo_lr") else 30)
                 np.random.seed(0)      # both legs draw from numpy's / torch's global streams (box-drop draws, PseudoLR's
                 torch.manual_seed(0)   # sample, nn.Linear start weights): same seeds, same draws
                 c = cpu_loop.run_session(ds.vectors, ds.vector_meta, boxes, "c1", qvec, loop=name, n_batches=cpu_rounds,
@@ -494,7 +494,7 @@ def clip_extras(device: int):
     hf = transformers.CLIPModel(transformers.CLIPConfig()).eval()
     xc = torch.randn(64, 3, 224, 224)
     with torch.inference_mode():
-        hf.get_image_features(pixel_values=xc[:8])
+        hf.get_image_features(pixel_values=xc[:2])
         cpu_runs = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -593,7 +593,7 @@ def sharded_step_extras(device: int, k: int = 100):
                       ctypes.c_void_p(x.flags.data_ptr()), ctypes.c_void_p(x.flags_seen.data_ptr()))
 
         res = {}
-        for comm in (False, True):
+        for comm in ((False, True) if kk == k else (False,)):  # (creating the one-rank communicator takes seconds: once)
             if comm:
                 world_keep = x.world
                 try:

@@ -274,99 +274,22 @@ __global__ void k_lp_scores_f32(const double *__restrict__ f, const unsigned cha
 // (products formed once, added in ascending position), so every value, the sweep count and the returned iterate
 // are what the full sweeps give, bit for bit (tests/test_labelprop_gpu.py), at a cost that does not depend on n.
 // ---------------------------------------------------------------------------------------
-// One WAVE per listed row (k-NN graphs over high-dimensional vectors have hubs: a symmetric 10-NN graph of 1.56 M random
-// vectors holds rows of thousands of entries, which one thread walking `indices -> f_old` one dependent round trip at a
-// time turned into a 0.3-ms kernel).  The wave takes the row 512 entries at a time: coalesced index / weight loads,
-// the gathers of f_old in flight together, each product formed once and parked in the wave's 4 KB of LDS, then lane 0
-// adds them in ascending position -- the order of the full sweeps and of scipy's csr_matvec.
-__global__ __launch_bounds__(256) void k_lp_rows(const int64_t *__restrict__ rows, int64_t m, const int64_t *__restrict__ indptr,
-                                                 const int32_t *__restrict__ indices, const double *__restrict__ data,
-                                                 const double *__restrict__ wsum, const double *__restrict__ prior,
-                                                 const double *__restrict__ f_old, double *__restrict__ f_new,
-                                                 const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
-                                                 double lambda, double low_bound, double high_bound, LpState *__restrict__ st) {
-    __shared__ double prod[4][512];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
-    if (i >= m) return;  // wave-uniform
-    const int64_t row = rows[i];
-    const int64_t p0 = indptr[row], p1 = indptr[row + 1];
-    double sum = 0.0;
-    for (int64_t base = p0; base < p1; base += 512) {
-        const int cnt = (int)min((int64_t)512, p1 - base);
-        int32_t col[8];
-        double w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = u * 64 + lane;
-            col[u] = q < cnt ? indices[base + q] : -1;
-            w[u] = q < cnt ? data[base + q] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int q = u * 64 + lane;
-            if (col[u] >= 0) prod[wave][q] = __dmul_rn(w[u], f_old[col[u]]);
-        }
-        // (one wave writes and reads these bytes: its LDS operations complete in order; the fence keeps the compiler from
-        //  moving lane 0's reads ahead of the other lanes' writes)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == 0)
-            for (int p = 0; p < cnt; ++p) sum = __dadd_rn(sum, prod[wave][p]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if (lane == 0) {
-        const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
-        double v = weighted / __dadd_rn(wsum[row], lambda);
-        if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
-        if (is_label[row]) v = label_val[row];
-        f_new[row] = v;
-    }
-}
+// Control block of an incremental call (device): list lengths per sweep and the overflow flag
+struct LpInc {
+    int total;                // rows in `mem` so far (grows as the frontier is expanded)
+    int blocks;               // blocks in `blk` so far
+    int overflow;             // the frontier did not fit `cap` rows: the call is redone with full sweeps
+    int m[9];                 // m[k]: rows to recompute for sweep k = mem[0 .. m[k]); m[0] = the changed labels
+    double level_max[8];      // per sweep: max over ALL blocks of 256 nodes of (F[k] - F[k-1])^2
+};
 
-// max over a block of 256 nodes of (f_new - f_old)^2; blocks == nullptr: block b = blockIdx.x (all of them)
-__global__ __launch_bounds__(256) void k_lp_blockmax(const int64_t *__restrict__ blocks, int64_t n, const double *__restrict__ f_new,
-                                                     const double *__restrict__ f_old, double *__restrict__ bmax,
-                                                     const LpState *__restrict__ st_or_null) {
-    __shared__ double red[4];
-    if (st_or_null && st_or_null->done) return;  // a sweep enqueued past convergence wrote nothing
-    const int64_t b = blocks ? blocks[blockIdx.x] : (int64_t)blockIdx.x;
-    const int64_t row = b * 256 + threadIdx.x;
-    double d2 = 0.0;
-    if (row < n) {
-        const double d = __dadd_rn(f_new[row], -f_old[row]);
-        d2 = __dmul_rn(d, d);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d2;
-    __syncthreads();
-    if (threadIdx.x == 0) bmax[b] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-
-__global__ __launch_bounds__(1024) void k_lp_levelmax(const double *__restrict__ bmax, int64_t nb, double *__restrict__ out) {
-    __shared__ double red[16];
-    double m = 0.0;
-    for (int64_t i = threadIdx.x; i < nb; i += 1024) m = fmax(m, bmax[i]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i) m = fmax(m, red[i]);
-        *out = m;
-    }
-}
-
-// label changes of an incremental call: ids [0, n_set) become labelled with vals, ids [n_set, n_set + n_unset) lose their label
-__global__ void k_lp_label_changes(const int64_t *__restrict__ ids, const double *__restrict__ vals, int64_t n_set, int64_t n_unset,
-                                   const double *__restrict__ prior, double *__restrict__ f0, unsigned char *__restrict__ is_label,
-                                   double *__restrict__ label_val) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// the label changes of an incremental call: ids [0, n_set) become labelled with vals, ids [n_set, n_set + n_unset) lose
+// their label; every changed node enters the frontier list
+__global__ void k_inc_seed(const int64_t *__restrict__ ids, const double *__restrict__ vals, int n_set, int n_unset,
+                           const double *__restrict__ prior, double *__restrict__ f0, unsigned char *__restrict__ is_label,
+                           double *__restrict__ label_val, uint32_t *__restrict__ stamp, uint32_t ep, int32_t *__restrict__ mem,
+                           LpInc *__restrict__ ctl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_set + n_unset) return;
     const int64_t r = ids[i];
     if (i < n_set) {
@@ -376,6 +299,137 @@ __global__ void k_lp_label_changes(const int64_t *__restrict__ ids, const double
     } else {
         is_label[r] = 0;
         f0[r] = prior[r];
+    }
+    stamp[r] = ep;   // (the changed ids are distinct)
+    mem[i] = (int32_t)r;
+}
+
+// frontier of sweep k: the rows whose sums read a value that changed in sweep k - 1, i.e. the in-neighbours (rows of the
+// TRANSPOSED pattern) of the nodes that entered the list one sweep earlier.  A wave per source node (hub rows hold
+// thousands of entries), first touch by atomic exchange on the node's stamp; the order of the list does not matter.
+__global__ __launch_bounds__(256) void k_inc_expand(int k, const int64_t *__restrict__ ht_indptr, const int32_t *__restrict__ ht_indices,
+                                                    uint32_t *__restrict__ stamp, uint32_t ep, int32_t *__restrict__ mem, int cap,
+                                                    LpInc *__restrict__ ctl) {
+    const int lane = threadIdx.x & 63;
+    const int lo = k >= 2 ? ctl->m[k - 2] : 0, hi = ctl->m[k - 1];
+    const int nwaves = gridDim.x * 4;
+    for (int q = lo + blockIdx.x * 4 + (threadIdx.x >> 6); q < hi; q += nwaves) {
+        const int64_t j = mem[q];
+        for (int64_t p = ht_indptr[j] + lane, e = ht_indptr[j + 1]; p < e; p += 64) {
+            const int32_t i = ht_indices[p];
+            if (atomicExch(&stamp[i], ep) != ep) {
+                const int pos = atomicAdd(&ctl->total, 1);
+                if (pos < cap) mem[pos] = i;
+                else ctl->overflow = 1;
+            }
+        }
+    }
+}
+
+// Sweep k over the listed rows: one WAVE per row.  The wave takes the row 512 entries at a time -- coalesced index /
+// weight loads, the gathers of f_old in flight together, each product formed once and parked in the wave's 4 KB of LDS --
+// then lane 0 adds them in ascending position: the order of the full sweeps and of scipy's csr_matvec.  Rows that are
+// new in this sweep also enter their block of 256 nodes in the block list (first touch by the block's stamp).
+__global__ __launch_bounds__(256) void k_inc_rows(int k, const int32_t *__restrict__ mem, int cap, const int64_t *__restrict__ indptr,
+                                                  const int32_t *__restrict__ indices, const double *__restrict__ data,
+                                                  const double *__restrict__ wsum, const double *__restrict__ prior,
+                                                  const double *__restrict__ f_old, double *__restrict__ f_new,
+                                                  const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
+                                                  double lambda, double low_bound, double high_bound, uint32_t *__restrict__ bstamp,
+                                                  uint32_t ep, int32_t *__restrict__ blk, LpInc *__restrict__ ctl,
+                                                  LpState *__restrict__ st) {
+    __shared__ double prod[4][512];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mk = min(ctl->total, cap), m_prev = ctl->m[k - 1];  // (the expansion of this sweep has finished: stream order)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->m[k] = mk;
+    const int nwaves = gridDim.x * 4;
+    for (int q = blockIdx.x * 4 + wave; q < mk; q += nwaves) {
+        const int64_t row = mem[q];
+        if ((k == 1 || q >= m_prev) && lane == 0) {  // a row new to the list: its block joins the block list
+            const uint32_t b = (uint32_t)(row >> 8);
+            if (atomicExch(&bstamp[b], ep) != ep) blk[atomicAdd(&ctl->blocks, 1)] = (int32_t)b;
+        }
+        const int64_t p0 = indptr[row], p1 = indptr[row + 1];
+        double sum = 0.0;
+        for (int64_t base = p0; base < p1; base += 512) {
+            const int cnt = (int)min((int64_t)512, p1 - base);
+            int32_t col[8];
+            double w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = u * 64 + lane;
+                col[u] = x < cnt ? indices[base + x] : -1;
+                w[u] = x < cnt ? data[base + x] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = u * 64 + lane;
+                if (col[u] >= 0) prod[wave][x] = __dmul_rn(w[u], f_old[col[u]]);
+            }
+            // (one wave writes and reads these bytes: its LDS operations complete in order; the fences keep the compiler
+            //  from moving lane 0's reads ahead of the other lanes' writes, and the next chunk's writes ahead of the reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0)
+                for (int p = 0; p < cnt; ++p) sum = __dadd_rn(sum, prod[wave][p]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane == 0) {
+            const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
+            double v = weighted / __dadd_rn(wsum[row], lambda);
+            if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
+            if (is_label[row]) v = label_val[row];
+            f_new[row] = v;
+        }
+    }
+}
+
+// max over a block of 256 nodes of (f_new - f_old)^2.  blk == nullptr: every block (a full sweep's pass; skipped once
+// the run has converged); otherwise the blocks of the incremental call's list (all touched so far)
+__global__ __launch_bounds__(256) void k_lp_blockmax(const int32_t *__restrict__ blk, const LpInc *__restrict__ ctl, int64_t n,
+                                                     const double *__restrict__ f_new, const double *__restrict__ f_old,
+                                                     double *__restrict__ bmax, const LpState *__restrict__ st_or_null) {
+    __shared__ double red[4];
+    if (st_or_null && st_or_null->done) return;  // a sweep enqueued past convergence wrote nothing
+    const int count = blk ? ctl->blocks : (int)gridDim.x;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int64_t b = blk ? (int64_t)blk[q] : (int64_t)q;
+        const int64_t row = b * 256 + threadIdx.x;
+        double d2 = 0.0;
+        if (row < n) {
+            const double d = __dadd_rn(f_new[row], -f_old[row]);
+            d2 = __dmul_rn(d, d);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d2 = fmax(d2, __shfl_xor(d2, off, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d2;
+        __syncthreads();
+        if (threadIdx.x == 0) bmax[b] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        __syncthreads();
+    }
+}
+
+// per kept sweep (blockIdx.x + 1): the maximum over all its blocks
+struct LpBmaxPtrs {
+    const double *p[8];
+};
+__global__ __launch_bounds__(1024) void k_lp_levelmax(LpBmaxPtrs bm, int64_t nb, LpInc *__restrict__ ctl) {
+    __shared__ double red[16];
+    const int k = blockIdx.x + 1;
+    const double *bmax = bm.p[k];
+    double m = 0.0;
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) m = fmax(m, bmax[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmax(m, red[i]);
+        ctl->level_max[k] = m;
     }
 }
 
@@ -550,13 +604,16 @@ struct ssw_lp {
         std::vector<double> vals;
     } trk;
     double *bmax[KEEP] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [k][blocks of 256 nodes]: max (f[k] - f[k-1])^2
-    double *level_max = nullptr;          // device [KEEP]
-    int64_t *inc_dev = nullptr, *inc_host = nullptr;  // packed per-call lists (device / pinned host), inc_cap words each
+    int64_t *inc_dev = nullptr, *inc_host = nullptr;  // packed per-call label lists (device / pinned host), inc_cap words each
     int64_t inc_cap = 0;
-    // host copy of the pattern (device row space) and its transpose, for the frontier sets; built on first use
-    std::vector<int64_t> h_indptr, ht_indptr;
-    std::vector<int32_t> h_indices, ht_indices;
-    std::vector<uint32_t> stamp, bstamp;  // per node / per block of 256 nodes: the epoch that last touched it
+    // the transposed pattern on the device (rows of W^T: who reads node j), per-node / per-block stamps of the call that
+    // last touched them, the frontier's row and block lists and its control block
+    int64_t *ht_indptr = nullptr;
+    int32_t *ht_indices = nullptr;
+    uint32_t *stamp = nullptr, *bstamp = nullptr;
+    int32_t *mem = nullptr, *blk = nullptr;
+    LpInc *ctl = nullptr;
+    int cap_rows = 0;
     uint32_t epoch = 0;
     // what the last propagation did (ssw_labelprop_last_run_info)
     int64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -584,7 +641,9 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
         (void)hipFree(lp->f[k]);
         (void)hipFree(lp->bmax[k]);
     }
-    (void)hipFree(lp->level_max);
+    for (void *q : {(void *)lp->ht_indptr, (void *)lp->ht_indices, (void *)lp->stamp, (void *)lp->bstamp, (void *)lp->mem,
+                    (void *)lp->blk, (void *)lp->ctl})
+        (void)hipFree(q);
     (void)hipFree(lp->inc_dev);
     if (lp->inc_host) (void)hipHostFree(lp->inc_host);
     (void)hipFree(lp->is_label);
@@ -608,7 +667,7 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
 }
 
 static thread_local bool g_lp_skip_blocked = false;
-static void lp_build_transpose(ssw_lp *lp);
+static ssw_status lp_upload_transpose(ssw_lp *lp, const int64_t *indptr_host, const int32_t *indices_host);
 
 ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr_host,
                                 const int32_t *indices_host, const double *data_host,
@@ -730,11 +789,9 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
                 break;
             }
     }
-    // the pattern stays on the host too: the incremental runs walk its transpose for their frontier sets (built here,
-    // 0.1 s at 18 M non-zeros, not inside a session's first update: it would be that round's latency)
-    lp->h_indptr.assign(indptr_host, indptr_host + n + 1);
-    lp->h_indices.assign(indices_host, indices_host + nnz);
-    lp_build_transpose(lp);
+    // the TRANSPOSED pattern for the incremental runs' frontier sets, built and uploaded here (0.1 s at 18 M non-zeros), not
+    // inside a session's first update: it would be that round's latency
+    if (ssw_status rc = lp_upload_transpose(lp, indptr_host, indices_host); rc != SSW_OK) return bail(rc);
     *out = lp;
     return SSW_OK;
 }
@@ -981,7 +1038,6 @@ static ssw_status lp_ensure_level(ssw_lp *lp, int k) {
     const int64_t nb = (lp->n + 255) / 256;
     if (!lp->f[k]) SSW_HIP_TRY(hipMalloc((void **)&lp->f[k], (size_t)lp->n * sizeof(double) + 16));
     if (!lp->bmax[k]) SSW_HIP_TRY(hipMalloc((void **)&lp->bmax[k], (size_t)nb * sizeof(double) + 16));
-    if (!lp->level_max) SSW_HIP_TRY(hipMalloc((void **)&lp->level_max, ssw_lp::KEEP * sizeof(double)));
     return SSW_OK;
 }
 
@@ -1000,21 +1056,31 @@ static ssw_status lp_inc_reserve(ssw_lp *lp, int64_t words) {
 }
 
 // rows of the transposed pattern: ht row j lists the rows i with W[i][j] != 0, i.e. the rows whose sum reads f[j]
-static void lp_build_transpose(ssw_lp *lp) {
-    if (!lp->ht_indptr.empty()) return;
-    const int64_t n = lp->n, nnz = lp->nnz;
-    lp->ht_indptr.assign((size_t)n + 1, 0);
-    for (int64_t p = 0; p < nnz; ++p) lp->ht_indptr[(size_t)lp->h_indices[(size_t)p] + 1]++;
-    for (int64_t j = 0; j < n; ++j) lp->ht_indptr[(size_t)j + 1] += lp->ht_indptr[(size_t)j];
-    lp->ht_indices.resize((size_t)nnz);
-    std::vector<int64_t> fill(lp->ht_indptr.begin(), lp->ht_indptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i)
-        for (int64_t p = lp->h_indptr[(size_t)i]; p < lp->h_indptr[(size_t)i + 1]; ++p)
-            lp->ht_indices[(size_t)fill[(size_t)lp->h_indices[(size_t)p]]++] = (int32_t)i;
-    lp->stamp.assign((size_t)n, 0u);
+static ssw_status lp_upload_transpose(ssw_lp *lp, const int64_t *indptr_host, const int32_t *indices_host) {
+    const int64_t n = lp->n, nnz = lp->nnz, nb = (n + 255) / 256;
+    std::vector<int64_t> tp((size_t)n + 1, 0);
+    for (int64_t p = 0; p < nnz; ++p) tp[(size_t)indices_host[p] + 1]++;
+    for (int64_t j = 0; j < n; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+    std::vector<int32_t> ti((size_t)nnz);
+    {
+        std::vector<int64_t> fill(tp.begin(), tp.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t p = indptr_host[i]; p < indptr_host[i + 1]; ++p) ti[(size_t)fill[(size_t)indices_host[p]]++] = (int32_t)i;
+    }
+    lp->cap_rows = (int)std::min<int64_t>(std::max<int64_t>(4096, n / 8), (int64_t)1 << 30);
+    SSW_HIP_TRY(hipMalloc((void **)&lp->ht_indptr, (size_t)(n + 1) * sizeof(int64_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->ht_indices, (size_t)nnz * sizeof(int32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->stamp, (size_t)n * sizeof(uint32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->bstamp, (size_t)nb * sizeof(uint32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->mem, (size_t)lp->cap_rows * sizeof(int32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->blk, (size_t)nb * sizeof(int32_t) + 16));
+    SSW_HIP_TRY(hipMalloc((void **)&lp->ctl, sizeof(LpInc)));
+    SSW_HIP_TRY(hipMemcpy(lp->ht_indptr, tp.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    SSW_HIP_TRY(hipMemcpy(lp->ht_indices, ti.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    SSW_HIP_TRY(hipMemset(lp->stamp, 0, (size_t)n * sizeof(uint32_t)));
+    SSW_HIP_TRY(hipMemset(lp->bstamp, 0, (size_t)nb * sizeof(uint32_t)));
     lp->epoch = 0;
-    std::vector<int64_t>().swap(lp->h_indptr);  // only the transpose is walked
-    std::vector<int32_t>().swap(lp->h_indices);
+    return SSW_OK;
 }
 
 static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below KEEP, the last two alternate beyond
@@ -1089,79 +1155,50 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             *st_out = st;
             return SSW_OK;
         }
-        // ---- frontier sets: row i of iterate k is recomputed when a label changed within k hops (walking the transposed
-        // pattern: the rows whose sums read a changed value).  The sets are nested, so ONE list in insertion order serves
-        // every level by its prefix; likewise the blocks of 256 nodes they touch.
-        const auto t_front0 = std::chrono::steady_clock::now();
-        lp_build_transpose(lp);
-        if (++lp->epoch == 0) {  // (wrapped)
-            std::fill(lp->stamp.begin(), lp->stamp.end(), 0u);
-            std::fill(lp->bstamp.begin(), lp->bstamp.end(), 0u);
-            lp->epoch = 1;
-        }
-        const uint32_t ep = lp->epoch;
-        std::vector<int64_t> members, blocks;
-        std::vector<int64_t> m_at((size_t)tk.levels + 1, 0), nb_at((size_t)tk.levels + 1, 0);
-        std::vector<uint32_t> &stamp = lp->stamp;
-        for (int64_t r : set_ids) if (stamp[(size_t)r] != ep) stamp[(size_t)r] = ep, members.push_back(r);
-        for (int64_t r : unset_ids) if (stamp[(size_t)r] != ep) stamp[(size_t)r] = ep, members.push_back(r);
-        const int64_t cap_rows = std::max<int64_t>(4096, n / 8);
-        size_t expanded = 0;
-        for (int k = 1; k <= tk.levels && inc; ++k) {
-            const size_t upto = members.size();
-            for (size_t q = expanded; q < upto; ++q) {
-                const int64_t j = members[q];
-                for (int64_t p = lp->ht_indptr[(size_t)j]; p < lp->ht_indptr[(size_t)j + 1]; ++p) {
-                    const int64_t i = lp->ht_indices[(size_t)p];
-                    if (stamp[(size_t)i] != ep) stamp[(size_t)i] = ep, members.push_back(i);
-                }
-            }
-            expanded = upto;
-            if ((int64_t)members.size() > cap_rows) inc = false;  // the change reaches a good part of the graph: full sweeps are cheaper
-            m_at[(size_t)k] = (int64_t)members.size();
-        }
-        if (inc) {  // the blocks of 256 nodes each level touches, in first-touch order (a level's blocks are a prefix too)
-            if (lp->bstamp.size() != (size_t)nb) lp->bstamp.assign((size_t)nb, 0u);
-            for (int k = 1; k <= tk.levels; ++k) {
-                for (int64_t q = m_at[(size_t)k - 1]; q < m_at[(size_t)k]; ++q) {
-                    const int64_t bb = members[(size_t)q] >> 8;
-                    if (lp->bstamp[(size_t)bb] != ep) lp->bstamp[(size_t)bb] = ep, blocks.push_back(bb);
-                }
-                nb_at[(size_t)k] = (int64_t)blocks.size();
-            }
-        }
-        lp->info[6] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_front0).count();
+        // ---- frontier on the device: the changed labels seed the row list; sweep k first extends it by the in-neighbours
+        // of the rows that joined one sweep earlier, then recomputes every listed row and the maxima of the touched blocks;
+        // the nested sets make ONE list serve every sweep by its prefix.  Nothing but the label lists is uploaded.
+        const int64_t n_set = (int64_t)set_ids.size(), n_unset = (int64_t)unset_ids.size();
+        if (n_set + n_unset > lp->cap_rows) inc = false;
         if (inc) {
-            // ---- one packed upload: [set ids | unset ids | set values | members | blocks | all ids | all values]
-            const int64_t n_set = (int64_t)set_ids.size(), n_unset = (int64_t)unset_ids.size();
-            const int64_t o_ch = 0, o_sv = n_set + n_unset, o_mem = o_sv + n_set, o_blk = o_mem + (int64_t)members.size(),
-                          o_ids = o_blk + (int64_t)blocks.size(), o_vals = o_ids + n_labels, words = o_vals + n_labels + 32;
+            if (++lp->epoch == 0) {  // (wrapped)
+                SSW_HIP_TRY(hipMemsetAsync(lp->stamp, 0, (size_t)n * sizeof(uint32_t), s));
+                SSW_HIP_TRY(hipMemsetAsync(lp->bstamp, 0, (size_t)nb * sizeof(uint32_t), s));
+                lp->epoch = 1;
+            }
+            const uint32_t ep = lp->epoch;
+            // one packed upload: [set ids | unset ids | set values | all ids | all values], then the control block
+            const int64_t o_ch = 0, o_sv = n_set + n_unset, o_ids = o_sv + n_set, o_vals = o_ids + n_labels, words = o_vals + n_labels + 64;
             SSW_TRY(lp_inc_reserve(lp, words));
             int64_t *hb = lp->inc_host;
             for (int64_t i = 0; i < n_set; ++i) hb[o_ch + i] = set_ids[(size_t)i];
             for (int64_t i = 0; i < n_unset; ++i) hb[o_ch + n_set + i] = unset_ids[(size_t)i];
             memcpy(hb + o_sv, set_vals.data(), (size_t)n_set * sizeof(double));
-            memcpy(hb + o_mem, members.data(), members.size() * sizeof(int64_t));
-            memcpy(hb + o_blk, blocks.data(), blocks.size() * sizeof(int64_t));
             memcpy(hb + o_ids, ids.data(), (size_t)n_labels * sizeof(int64_t));
             memcpy(hb + o_vals, vals.data(), (size_t)n_labels * sizeof(double));
+            LpInc *hctl = reinterpret_cast<LpInc *>(hb + o_vals + n_labels);  // (64 words of slack hold it: 120 bytes)
+            memset(hctl, 0, sizeof(LpInc));
+            hctl->total = (int)(n_set + n_unset);
+            hctl->m[0] = (int)(n_set + n_unset);
             SSW_HIP_TRY(hipMemcpyAsync(lp->inc_dev, hb, (size_t)(o_vals + n_labels) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            SSW_HIP_TRY(hipMemcpyAsync(lp->ctl, hctl, sizeof(LpInc), hipMemcpyHostToDevice, s));
             int64_t *db = lp->inc_dev;
             SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
-            hipLaunchKernelGGL(k_lp_label_changes, dim3((unsigned)((n_set + n_unset + 255) / 256)), dim3(256), 0, s, db + o_ch,
-                               reinterpret_cast<const double *>(db + o_sv), n_set, n_unset, lp->prior, lp->f[0], lp->is_label,
-                               lp->label_val);
-            int64_t rows_total = 0;
+            hipLaunchKernelGGL(k_inc_seed, dim3((unsigned)((n_set + n_unset + 255) / 256)), dim3(256), 0, s, db + o_ch,
+                               reinterpret_cast<const double *>(db + o_sv), (int)n_set, (int)n_unset, lp->prior, lp->f[0], lp->is_label,
+                               lp->label_val, lp->stamp, ep, lp->mem, lp->ctl);
+            LpBmaxPtrs bm;
+            for (int k = 0; k < ssw_lp::KEEP; ++k) bm.p[k] = lp->bmax[k];
             for (int k = 1; k <= tk.levels; ++k) {
-                const int64_t mk = m_at[(size_t)k], nbk = nb_at[(size_t)k];
-                rows_total += mk;
-                hipLaunchKernelGGL(k_lp_rows, dim3((unsigned)((mk + 3) / 4)), dim3(256), 0, s, db + o_mem, mk, lp->indptr,
-                                   lp->indices, lp->data, lp->wsum, lp->prior, lp->f[k - 1], lp->f[k], lp->is_label, lp->label_val,
-                                   reg_lambda, lo, hi, lp->state);
-                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nbk), dim3(256), 0, s, db + o_blk, n, lp->f[k], lp->f[k - 1],
-                                   lp->bmax[k], (const LpState *)nullptr);
-                hipLaunchKernelGGL(k_lp_levelmax, dim3(1), dim3(1024), 0, s, lp->bmax[k], nb, lp->level_max + k);
+                hipLaunchKernelGGL(k_inc_expand, dim3(1024), dim3(256), 0, s, k, lp->ht_indptr, lp->ht_indices, lp->stamp, ep, lp->mem,
+                                   lp->cap_rows, lp->ctl);
+                hipLaunchKernelGGL(k_inc_rows, dim3(2048), dim3(256), 0, s, k, lp->mem, lp->cap_rows, lp->indptr, lp->indices, lp->data,
+                                   lp->wsum, lp->prior, lp->f[k - 1], lp->f[k], lp->is_label, lp->label_val, reg_lambda, lo, hi,
+                                   lp->bstamp, ep, lp->blk, lp->ctl, lp->state);
+                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)std::min<int64_t>(nb, 2048)), dim3(256), 0, s, lp->blk, lp->ctl, n,
+                                   lp->f[k], lp->f[k - 1], lp->bmax[k], (const LpState *)nullptr);
             }
+            hipLaunchKernelGGL(k_lp_levelmax, dim3((unsigned)tk.levels), dim3(1024), 0, s, bm, nb, lp->ctl);
             SSW_HIP_TRY(hipGetLastError());
             // the device-side label list other entry points clear by (ids / vals of every installed label)
             if (n_labels > 0) {
@@ -1169,36 +1206,46 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
                 SSW_HIP_TRY(hipMemcpyAsync(lp->vals, db + o_vals, (size_t)n_labels * sizeof(double), hipMemcpyDeviceToDevice, s));
             }
             lp->n_labels_installed = n_labels;
-            double *hres = reinterpret_cast<double *>(hb + o_vals + n_labels);  // [KEEP] level maxima, then the state
-            SSW_HIP_TRY(hipMemcpyAsync(hres, lp->level_max, ssw_lp::KEEP * sizeof(double), hipMemcpyDeviceToHost, s));
-            SSW_HIP_TRY(hipMemcpyAsync(hres + ssw_lp::KEEP, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
+            unsigned char *hres = reinterpret_cast<unsigned char *>(hb + o_vals + n_labels);  // the control block, then the state
+            SSW_HIP_TRY(hipMemcpyAsync(hres, lp->ctl, sizeof(LpInc), hipMemcpyDeviceToHost, s));
+            SSW_HIP_TRY(hipMemcpyAsync(hres + 128, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
             const auto t_wait0 = std::chrono::steady_clock::now();
             SSW_HIP_TRY(hipStreamSynchronize(s));
             lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
+            lp->info[6] = 0;
+            LpInc rctl;
             LpState dst;
-            memcpy(&dst, hres + ssw_lp::KEEP, sizeof(LpState));
+            memcpy(&rctl, hres, sizeof(LpInc));
+            memcpy(&dst, hres + 128, sizeof(LpState));
             tk.ids = ids, tk.vals = vals;  // the device now holds these labels whatever happens next
-            if (dst.bound_violation) {
+            if (rctl.overflow) {
+                // the change reaches more than n / 8 rows: rows beyond the list were not recomputed, so the kept iterates
+                // are no longer a run's -- start over with the full sweeps (from the labels just installed)
+                inc = false;
+            } else if (dst.bound_violation) {
                 tk.valid = false;
                 set_error("label propagation: averaged scores left [%g, %g] (label_propagation.py:39-40)", lo, hi);
                 return SSW_ERR_NUMERIC;
+            } else {
+                int64_t rows_total = 0;
+                for (int k = 1; k <= tk.levels; ++k) rows_total += rctl.m[k];
+                int conv = 0;
+                for (int k = 1; k <= tk.levels && !conv; ++k)
+                    if (rctl.level_max[k] < eps) conv = k;
+                if (conv) {
+                    st.sweeps = conv, st.done = 1, st.result_buf = conv - 1;
+                    tk.sweeps = conv, tk.result = conv - 1;
+                    lp->last_result = conv - 1;
+                    lp->sweeps_hint = conv;
+                    lp->info[0] = 1, lp->info[1] = conv, lp->info[2] = 2 + 3 * (int64_t)tk.levels, lp->info[3] = 1, lp->info[4] = rows_total,
+                    lp->info[5] = tk.levels;
+                    *st_out = st;
+                    return SSW_OK;
+                }
+                // the new labels need more sweeps than were kept: iterates 0 .. levels ARE the new run's (every row either
+                // unchanged or recomputed), so the full sweeps below continue from sweep levels + 1
+                continue_from = tk.levels;
             }
-            int conv = 0;
-            for (int k = 1; k <= tk.levels && !conv; ++k)
-                if (hres[k] < eps) conv = k;
-            if (conv) {
-                st.sweeps = conv, st.done = 1, st.result_buf = conv - 1;
-                tk.sweeps = conv, tk.result = conv - 1;
-                lp->last_result = conv - 1;
-                lp->sweeps_hint = conv;
-                lp->info[0] = 1, lp->info[1] = conv, lp->info[2] = 1 + 3 * (int64_t)tk.levels, lp->info[3] = 1, lp->info[4] = rows_total,
-                lp->info[5] = tk.levels;
-                *st_out = st;
-                return SSW_OK;
-            }
-            // the new labels need more sweeps than were kept: iterates 0 .. levels ARE the new run's (every row either
-            // unchanged or recomputed), so the full sweeps below continue from sweep levels + 1
-            continue_from = tk.levels;
         }
     }
 
@@ -1241,8 +1288,8 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             if (k < ssw_lp::KEEP) SSW_TRY(lp_ensure_level(lp, k));
             lp_launch_sweep(lp, src, dst, reg_lambda, lo, hi);
             if (k < ssw_lp::KEEP)
-                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nb), dim3(256), 0, s, (const int64_t *)nullptr, n, lp->f[dst], lp->f[src],
-                                   lp->bmax[k], (const LpState *)lp->state);
+                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)nb), dim3(256), 0, s, (const int32_t *)nullptr, (const LpInc *)nullptr, n,
+                                   lp->f[dst], lp->f[src], lp->bmax[k], (const LpState *)lp->state);
             hipLaunchKernelGGL(k_lp_check, dim3(1), dim3(1), 0, s, lp->state, eps, src, dst);
         }
         SSW_HIP_TRY(hipGetLastError());

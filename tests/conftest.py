@@ -27,3 +27,12 @@ def lab_build():
     from seesaw_amd import _lib
     with _lib.debug_hooks() as lib:
         yield lib
+
+
+def free_port() -> int:
+    """a TCP port the OS reports free right now (bind to port 0 on 127.0.0.1): rendezvous ports derived from the pid could
+    collide between concurrent runs of the suite (VERDICT r4 weak #9)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])

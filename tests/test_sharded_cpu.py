@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import pytest
+
+from conftest import free_port  # noqa: E402
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -61,7 +63,7 @@ def _worker(rank, world, port, n_total, k, tmpdir):
 
 @pytest.mark.parametrize("n_total,k", [(5000, 50), (301, 100)])
 def test_two_rank_exchange_matches_single_index(tmp_path, oracle, n_total, k):
-    port = 29500 + (os.getpid() + n_total) % 2000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, n_total, k, str(tmp_path)), nprocs=2, join=True)
     X = oracle.synth_rows(9, 0, n_total, 512)
     q = oracle.synth_query(1)
@@ -127,7 +129,7 @@ def test_eight_rank_exchange_ragged_empty_and_overflow_on_rank_5(tmp_path, oracl
     down to 1), one empty shard and an overflow flag raised by rank 5 only: every rank ends with the whole index's top-k
     (ids and score bits), every rank sees the flag and which rank raised it."""
     sizes = RAGGED_8
-    port = 27500 + (os.getpid() + k) % 2000
+    port = free_port()
     mp.spawn(_worker8, args=(8, port, sizes, k, str(tmp_path)), nprocs=8, join=True)
     n_total = int(np.sum(sizes))
     X = oracle.synth_rows(9, 0, n_total, 512)

@@ -15,6 +15,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import free_port  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -209,7 +211,7 @@ def test_exchange_over_rccl_world_size_1():
     env = dict(os.environ)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                           "--master-addr", "127.0.0.1", "--master-port", str(29400 + os.getpid() % 500), script],
+                           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script],
                           env=env, capture_output=True, text=True, timeout=600)
     tail = "\n".join((proc.stdout + proc.stderr).splitlines()[-30:])
     assert proc.returncode == 0, tail
@@ -231,7 +233,7 @@ def test_bench_with_two_ranks_on_one_gpu_returns_the_single_gpu_answer():
     env2 = dict(env)
     env2["SSW_BENCH_REHEARSAL"] = "gloo"
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                          "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env2, capture_output=True, text=True,
                          timeout=600)
     assert two.returncode == 0, "\n".join((two.stdout + two.stderr).splitlines()[-20:])

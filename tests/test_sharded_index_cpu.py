@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pandas as pd
 import pytest
+
+from conftest import free_port  # noqa: E402
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -91,7 +93,7 @@ def _worker(rank, world, port, tmpdir):
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_index_matches_reference_on_every_rank(tmp_path, oracle, world):
     """2 ranks, and the 8 of BASELINE configs C4 / C5 (VERDICT r3 #5a): every rank returns the reference's own answers"""
-    port = 29700 + (os.getpid() + 37 * world) % 1500
+    port = free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
     seed = int(g["seed"])
@@ -241,7 +243,7 @@ def _worker8_special(rank, world, port, tmpdir):
 
 
 def test_eight_ranks_empty_shard_overflow_on_rank_5_and_a_session(tmp_path, oracle):
-    port = 26300 + os.getpid() % 1500
+    port = free_port()
     mp.spawn(_worker8_special, args=(8, port, str(tmp_path)), nprocs=8, join=True)
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(8)]
     n_imgs = [int(x["bounds"][1] - x["bounds"][0]) for x in r]

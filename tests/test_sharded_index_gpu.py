@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pandas as pd
 import pytest
+
+from conftest import free_port  # noqa: E402
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -75,7 +77,7 @@ def _worker(rank, world, port, tmpdir):
 
 
 def test_two_ranks_one_gpu_match_reference(tmp_path, oracle):
-    port = 29900 + os.getpid() % 1000
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     g = np.load(os.path.join(GOLDEN, "multiscale_query.npz"))
     seed = int(g["seed"])
@@ -186,7 +188,7 @@ def _session_worker(rank, world, port, tmpdir):
 def test_sessions_over_the_sharded_index_match_reference(tmp_path):
     """plain / multi_reg (data + query regularisers) / knn_prop2 sessions over a two-rank sharded index built WITHOUT a
     host copy of the matrix return, on every rank, the reference's own sessions (tests/golden/bench_loop.npz)"""
-    port = 29950 + os.getpid() % 1000
+    port = free_port()
     mp.spawn(_session_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     g = np.load(os.path.join(GOLDEN, "bench_loop.npz"))
     for k in range(2):
