@@ -279,6 +279,7 @@ struct LpInc {
     int total;                // rows in `mem` so far (grows as the frontier is expanded)
     int blocks;               // blocks in `blk` so far
     int overflow;             // the frontier did not fit `cap` rows: the call is redone with full sweeps
+    int bound_violation;      // a recomputed value left the reference's bounds (label_propagation.py:36-40)
     int m[9];                 // m[k]: rows to recompute for sweep k = mem[0 .. m[k]); m[0] = the changed labels
     double level_max[8];      // per sweep: max over ALL blocks of 256 nodes of (F[k] - F[k-1])^2
 };
@@ -288,8 +289,13 @@ struct LpInc {
 __global__ void k_inc_seed(const int64_t *__restrict__ ids, const double *__restrict__ vals, int n_set, int n_unset,
                            const double *__restrict__ prior, double *__restrict__ f0, unsigned char *__restrict__ is_label,
                            double *__restrict__ label_val, uint32_t *__restrict__ stamp, uint32_t ep, int32_t *__restrict__ mem,
-                           LpInc *__restrict__ ctl) {
+                           const int64_t *__restrict__ all_ids, const double *__restrict__ all_vals, int n_all,
+                           int64_t *__restrict__ ids_out, double *__restrict__ vals_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_all) {  // the device-side list of every installed label (what the other entry points clear by)
+        ids_out[i] = all_ids[i];
+        vals_out[i] = all_vals[i];
+    }
     if (i >= n_set + n_unset) return;
     const int64_t r = ids[i];
     if (i < n_set) {
@@ -336,8 +342,7 @@ __global__ __launch_bounds__(256) void k_inc_rows(int k, const int32_t *__restri
                                                   const double *__restrict__ f_old, double *__restrict__ f_new,
                                                   const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
                                                   double lambda, double low_bound, double high_bound, uint32_t *__restrict__ bstamp,
-                                                  uint32_t ep, int32_t *__restrict__ blk, LpInc *__restrict__ ctl,
-                                                  LpState *__restrict__ st) {
+                                                  uint32_t ep, int32_t *__restrict__ blk, LpInc *__restrict__ ctl) {
     __shared__ double prod[4][512];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void k_inc_rows(int k, const int32_t *__restri
         if (lane == 0) {
             const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
             double v = weighted / __dadd_rn(wsum[row], lambda);
-            if (!(v >= low_bound) || !(v <= high_bound)) st->bound_violation = 1;
+            if (!(v >= low_bound) || !(v <= high_bound)) ctl->bound_violation = 1;
             if (is_label[row]) v = label_val[row];
             f_new[row] = v;
         }
@@ -1074,7 +1079,6 @@ static ssw_status lp_upload_transpose(ssw_lp *lp, const int64_t *indptr_host, co
     SSW_HIP_TRY(hipMalloc((void **)&lp->bstamp, (size_t)nb * sizeof(uint32_t) + 16));
     SSW_HIP_TRY(hipMalloc((void **)&lp->mem, (size_t)lp->cap_rows * sizeof(int32_t) + 16));
     SSW_HIP_TRY(hipMalloc((void **)&lp->blk, (size_t)nb * sizeof(int32_t) + 16));
-    SSW_HIP_TRY(hipMalloc((void **)&lp->ctl, sizeof(LpInc)));
     SSW_HIP_TRY(hipMemcpy(lp->ht_indptr, tp.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     SSW_HIP_TRY(hipMemcpy(lp->ht_indices, ti.data(), (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
     SSW_HIP_TRY(hipMemset(lp->stamp, 0, (size_t)n * sizeof(uint32_t)));
@@ -1176,47 +1180,42 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             memcpy(hb + o_sv, set_vals.data(), (size_t)n_set * sizeof(double));
             memcpy(hb + o_ids, ids.data(), (size_t)n_labels * sizeof(int64_t));
             memcpy(hb + o_vals, vals.data(), (size_t)n_labels * sizeof(double));
-            LpInc *hctl = reinterpret_cast<LpInc *>(hb + o_vals + n_labels);  // (64 words of slack hold it: 120 bytes)
+            const int64_t o_ctl = o_vals + n_labels;  // the control block travels with the lists (64 words of slack hold its 128 bytes)
+            LpInc *hctl = reinterpret_cast<LpInc *>(hb + o_ctl);
             memset(hctl, 0, sizeof(LpInc));
             hctl->total = (int)(n_set + n_unset);
             hctl->m[0] = (int)(n_set + n_unset);
-            SSW_HIP_TRY(hipMemcpyAsync(lp->inc_dev, hb, (size_t)(o_vals + n_labels) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-            SSW_HIP_TRY(hipMemcpyAsync(lp->ctl, hctl, sizeof(LpInc), hipMemcpyHostToDevice, s));
+            SSW_HIP_TRY(hipMemcpyAsync(lp->inc_dev, hb, (size_t)(o_ctl + 16) * sizeof(int64_t), hipMemcpyHostToDevice, s));
             int64_t *db = lp->inc_dev;
-            SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
-            hipLaunchKernelGGL(k_inc_seed, dim3((unsigned)((n_set + n_unset + 255) / 256)), dim3(256), 0, s, db + o_ch,
-                               reinterpret_cast<const double *>(db + o_sv), (int)n_set, (int)n_unset, lp->prior, lp->f[0], lp->is_label,
-                               lp->label_val, lp->stamp, ep, lp->mem, lp->ctl);
+            LpInc *dctl = reinterpret_cast<LpInc *>(db + o_ctl);
+            hipLaunchKernelGGL(k_inc_seed, dim3((unsigned)((std::max<int64_t>(n_set + n_unset, n_labels) + 255) / 256)), dim3(256), 0, s,
+                               db + o_ch, reinterpret_cast<const double *>(db + o_sv), (int)n_set, (int)n_unset, lp->prior, lp->f[0],
+                               lp->is_label, lp->label_val, lp->stamp, ep, lp->mem, db + o_ids,
+                               reinterpret_cast<const double *>(db + o_vals), (int)n_labels, lp->ids, lp->vals);
             LpBmaxPtrs bm;
             for (int k = 0; k < ssw_lp::KEEP; ++k) bm.p[k] = lp->bmax[k];
             for (int k = 1; k <= tk.levels; ++k) {
                 hipLaunchKernelGGL(k_inc_expand, dim3(1024), dim3(256), 0, s, k, lp->ht_indptr, lp->ht_indices, lp->stamp, ep, lp->mem,
-                                   lp->cap_rows, lp->ctl);
+                                   lp->cap_rows, dctl);
                 hipLaunchKernelGGL(k_inc_rows, dim3(2048), dim3(256), 0, s, k, lp->mem, lp->cap_rows, lp->indptr, lp->indices, lp->data,
                                    lp->wsum, lp->prior, lp->f[k - 1], lp->f[k], lp->is_label, lp->label_val, reg_lambda, lo, hi,
-                                   lp->bstamp, ep, lp->blk, lp->ctl, lp->state);
-                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)std::min<int64_t>(nb, 2048)), dim3(256), 0, s, lp->blk, lp->ctl, n,
+                                   lp->bstamp, ep, lp->blk, dctl);
+                hipLaunchKernelGGL(k_lp_blockmax, dim3((unsigned)std::min<int64_t>(nb, 2048)), dim3(256), 0, s, lp->blk, dctl, n,
                                    lp->f[k], lp->f[k - 1], lp->bmax[k], (const LpState *)nullptr);
             }
-            hipLaunchKernelGGL(k_lp_levelmax, dim3((unsigned)tk.levels), dim3(1024), 0, s, bm, nb, lp->ctl);
+            hipLaunchKernelGGL(k_lp_levelmax, dim3((unsigned)tk.levels), dim3(1024), 0, s, bm, nb, dctl);
             SSW_HIP_TRY(hipGetLastError());
-            // the device-side label list other entry points clear by (ids / vals of every installed label)
-            if (n_labels > 0) {
-                SSW_HIP_TRY(hipMemcpyAsync(lp->ids, db + o_ids, (size_t)n_labels * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-                SSW_HIP_TRY(hipMemcpyAsync(lp->vals, db + o_vals, (size_t)n_labels * sizeof(double), hipMemcpyDeviceToDevice, s));
-            }
-            lp->n_labels_installed = n_labels;
-            unsigned char *hres = reinterpret_cast<unsigned char *>(hb + o_vals + n_labels);  // the control block, then the state
-            SSW_HIP_TRY(hipMemcpyAsync(hres, lp->ctl, sizeof(LpInc), hipMemcpyDeviceToHost, s));
-            SSW_HIP_TRY(hipMemcpyAsync(hres + 128, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
+            lp->n_labels_installed = n_labels;  // (k_inc_seed refreshed lp->ids / lp->vals)
+            SSW_HIP_TRY(hipMemcpyAsync(hctl, dctl, sizeof(LpInc), hipMemcpyDeviceToHost, s));  // ONE copy back: the control block
             const auto t_wait0 = std::chrono::steady_clock::now();
             SSW_HIP_TRY(hipStreamSynchronize(s));
             lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
             lp->info[6] = 0;
             LpInc rctl;
+            memcpy(&rctl, hctl, sizeof(LpInc));
             LpState dst;
-            memcpy(&rctl, hres, sizeof(LpInc));
-            memcpy(&dst, hres + 128, sizeof(LpState));
+            memset(&dst, 0, sizeof(dst));
+            dst.bound_violation = rctl.bound_violation;
             tk.ids = ids, tk.vals = vals;  // the device now holds these labels whatever happens next
             if (rctl.overflow) {
                 // the change reaches more than n / 8 rows: rows beyond the list were not recomputed, so the kept iterates

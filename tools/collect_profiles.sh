@@ -18,6 +18,8 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
     python3 tools/perf_clip_b200.py 200 > "$OUT/clip_pmc.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/text_trace" -o text -- \
     python3 tools/perf_text.py > "$OUT/text_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/text16_trace" -o text16 -- \
+    python3 tools/perf_text_batch.py > "$OUT/text16_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn -- \
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
@@ -25,7 +27,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn 
 python3 tools/perf_gemm.py 15 14 --lib > "$OUT/gemm_ab.txt" 2> "$OUT/gemm_ab.err" || true
 ( echo "# f32 rows (default)"; SSW_AO_STAMPS=1 python3 tools/attn_out_stamps.py; echo "# bf16 rows"; SSW_AO_STAMPS=1 SSW_CLIP_BF16_STREAM=1 python3 tools/attn_out_stamps.py ) 2>/dev/null | grep -v amdgpu > "$OUT/attn_out_stamps.txt" || true
 
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"   # after the PMC passes: its roofline.traffic reads the file just made
+( time python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" ) 2> "$OUT/bench.time"   # after the PMC passes: its roofline.traffic reads the file just made
 python3 tools/summarise_pmc.py "$OUT/bench_fetch" scan_scores > "$OUT/fetch_summary.csv"
 python3 tools/summarise_pmc.py "$OUT/bench_write" scan_scores > "$OUT/write_summary.csv"
 ( echo "# mean per launch of scan_scores_kernel, rocprofv3 --pmc (two passes), bench.py --steps 3 --warmup 1"; cat "$OUT/fetch_summary.csv"; grep WRITE_SIZE "$OUT/write_summary.csv" ) > "profiles/${R}_bench_100M_pmc_fetch_write.csv"
@@ -36,6 +38,7 @@ cp "$OUT/bench_trace/bench_kernel_stats.csv" "profiles/${R}_bench_100M_kernel_st
 cp "$OUT/clip_trace/clip_kernel_stats.csv" "profiles/${R}_clip_b200_kernel_stats.csv"
 cp "$OUT/knn_trace/knn_kernel_stats.csv" "profiles/${R}_knn_1560k_kernel_stats.csv"
 cp "$OUT/text_trace/text_kernel_stats.csv" "profiles/${R}_clip_text_1x8_kernel_stats.csv"
+cp "$OUT/text16_trace/text16_kernel_stats.csv" "profiles/${R}_clip_text_16x77_kernel_stats.csv"
 cp "$OUT/gemm_ab.txt" "profiles/${R}_gemm_ab.txt"
 cp "$OUT/attn_out_stamps.txt" "profiles/${R}_attn_out_stamps.txt"
 for f in profiles/${R}_*; do cp "$f" "gpurun_out/collect/$(basename "$f")"; done   # the box's profiles/ does not travel back
