@@ -55,7 +55,11 @@ ssw_status ssw_debug_gemm_pw4_wg(uint64_t *out4116);
  *   3 + bias + residual (f32)         -> C f32          7 xcopy += A W^T + bias in place (bf16 stream), stats_out
  * A [M,K], W [N,K] (K-contiguous, nn.Linear's layout), bias / c2 [N], residual [M,N] f32, xcopy [M,N] bf16,
  * stats_in [M][np_in][2] partial (sum, sum of squares) of the un-normalised f32 rows, c1 [N], stats_out [M][N/128][2].
- * variant: the kernel (ssw_tune_gemm's numbers; -1 = the library's default choice). */
+ * variant: the kernel (ssw_tune_gemm's numbers; -1 = the library's default choice).
+ * Three more forms take another meaning of `variant`: 8 = the split-K product (launch_gemm_splitk_f32; variant = splits);
+ * 9 = epilogue 6 behind a split-K product (launch_gemm_splitk_stats: the text tower's fc2; variant = splits); 10 = epilogue 6
+ * with the residual rows at a stride (GemmLn::res_ld: the pooled last layer's out-projection; variant = S, residual holds
+ * M * S rows and row m * S is added to row m). */
 ssw_status ssw_debug_gemm_run(int32_t epi, int32_t variant, int32_t M, int32_t N, int32_t K, const uint16_t *A_bf16,
                               const uint16_t *W_bf16, const float *bias_or_c2, const float *residual_or_null,
                               uint16_t *xcopy_inout_or_null, const float *stats_in_or_null, int32_t np_in,

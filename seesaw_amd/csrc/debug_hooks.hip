@@ -198,7 +198,39 @@ extern "C" ssw_status ssw_debug_gemm_run(int32_t epi, int32_t variant, int32_t M
                                          const float *c1_or_null, float inv_dim, float eps, void *C_out_or_null,
                                          float *stats_out_or_null) {
     using namespace ssw;
-    SSW_REQUIRE(epi >= 0 && epi <= 8 && M > 0 && N > 0 && K > 0 && A_bf16 && W_bf16, "ssw_debug_gemm_run: bad arguments");
+    SSW_REQUIRE(epi >= 0 && epi <= 10 && M > 0 && N > 0 && K > 0 && A_bf16 && W_bf16, "ssw_debug_gemm_run: bad arguments");
+    if (epi == 9 || epi == 10) {
+        // 9: the producer epilogue behind a split-K product (launch_gemm_splitk_stats: the text tower's fc2), `variant` = splits;
+        // 10: the producer epilogue with the residual rows at a stride (GemmLn::res_ld: the pooled last layer's out-projection),
+        //     `variant` = S: residual_or_null holds M * S rows of N, row m S is added to row m of the product
+        SSW_REQUIRE(bias_or_c2 && residual_or_null && xcopy_inout_or_null && C_out_or_null && stats_out_or_null && variant >= 1,
+                    "ssw_debug_gemm_run: the producer forms need bias, residual, the copy, the output, the statistics and splits / S >= 1");
+        DevBufs d9;
+        void *A9, *W9, *b9, *r9, *x9, *C9, *s9, *P9 = nullptr;
+        const int64_t res_rows = epi == 10 ? (int64_t)M * variant : M;
+        SSW_TRY(d9.up(A_bf16, (size_t)M * K * 2, &A9));
+        SSW_TRY(d9.up(W_bf16, (size_t)N * K * 2, &W9));
+        SSW_TRY(d9.up(bias_or_c2, (size_t)N * 4, &b9));
+        SSW_TRY(d9.up(residual_or_null, (size_t)res_rows * N * 4, &r9));
+        SSW_TRY(d9.up(nullptr, (size_t)M * N * 2, &x9));
+        SSW_TRY(d9.up(nullptr, (size_t)M * N * 4, &C9));
+        SSW_TRY(d9.up(nullptr, (size_t)M * (N / 128) * 2 * 4, &s9));
+        GemmLn ln;
+        ln.xcopy = (__bf16 *)x9;
+        ln.stats_out = (float *)s9;
+        if (epi == 9) {
+            SSW_TRY(d9.up(nullptr, (size_t)variant * M * N * 4, &P9));
+            SSW_TRY(launch_gemm_splitk_stats(0, A9, W9, (const float *)b9, (const float *)r9, (float *)C9, (float *)P9, M, N, K, variant, ln));
+        } else {
+            ln.res_ld = (int64_t)variant * N;
+            SSW_TRY(launch_gemm_bf16_ln(6, 0, A9, W9, (const float *)b9, (const float *)r9, C9, M, N, K, ln));
+        }
+        SSW_HIP_TRY(hipDeviceSynchronize());
+        SSW_HIP_TRY(hipMemcpy(C_out_or_null, C9, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        SSW_HIP_TRY(hipMemcpy(xcopy_inout_or_null, x9, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+        SSW_HIP_TRY(hipMemcpy(stats_out_or_null, s9, (size_t)M * (N / 128) * 2 * 4, hipMemcpyDeviceToHost));
+        return SSW_OK;
+    }
     if (epi == 8) {  // the split-K product of few-tile shapes (launch_gemm_splitk_f32): `variant` = number of splits
         SSW_REQUIRE(bias_or_c2 && C_out_or_null && variant >= 1, "ssw_debug_gemm_run: split-K needs bias, an output and the split count");
         DevBufs d8;

@@ -116,6 +116,47 @@ def test_split_k_product_against_torch_f32(lab_build, M):
                                   _p(C), None) != 0  # 768 is not a multiple of 64 x 8
 
 
+@pytest.mark.parametrize("M", [1, 77, 129, 1232])
+def test_split_k_producer_and_strided_residual_against_torch_f32(lab_build, M):
+    """round 5's two producer forms: epilogue 6 (f32 row + bf16 copy + the 128-column partial statistics) behind a product
+    split over K (launch_gemm_splitk_stats: the text tower's fc2, 2 / 4 / 8 slices added in ascending order), and epilogue 6
+    with the residual rows taken at a stride (GemmLn::res_ld: the pooled last layer's out-projection adds row m S of the
+    stack to row m) -- same bars as the plain producer: 2e-4 on the f32 row, the copy is the row rounded, statistics of
+    the row as stored"""
+    lib = lab_build
+    rng = np.random.default_rng(7000 + M)
+    for N, K in [(512, 2048), (768, 3072), (768, 768)]:
+        Ab, A = _bf16_bits(rng.standard_normal((M, K)))
+        Wb, W = _bf16_bits(rng.standard_normal((N, K)) * 0.05)
+        bias = (rng.standard_normal(N) * 0.5).astype(np.float32)
+        prod = A.astype(np.float64) @ W.astype(np.float64).T + bias
+
+        def check(got, xc, st, ref, what):
+            assert np.isfinite(got).all() and (np.abs(got - ref) <= 2e-4).all(), (what, M, N, K, float(np.abs(got - ref).max()))
+            assert np.array_equal(xc, _bf16_bits(got)[0]), what
+            t = got.reshape(M, N // 128, 128).astype(np.float64)
+            assert np.allclose(st[:, :, 0], t.sum(2), rtol=0, atol=2e-3) and np.allclose(st[:, :, 1], (t * t).sum(2), rtol=2e-5, atol=2e-3), what
+
+        res = rng.standard_normal((M, N)).astype(np.float32)
+        for splits in (2, 4, 8) if K % 512 == 0 else (2, 4):
+            C, xc, st = np.zeros((M, N), np.float32), np.zeros((M, N), np.uint16), np.zeros((M, N // 128, 2), np.float32)
+            rc = lib.ssw_debug_gemm_run(9, splits, M, N, K, _p(Ab), _p(Wb), _p(bias), _p(res), _p(xc), None, 0, None, 0.0, 0.0, _p(C), _p(st))
+            assert rc == 0, lib.ssw_last_error().decode()
+            check(C, xc, st, prod + res, f"split {splits}")
+        S = 50
+        big = rng.standard_normal((M * S, N)).astype(np.float32)
+        C, xc, st = np.zeros((M, N), np.float32), np.zeros((M, N), np.uint16), np.zeros((M, N // 128, 2), np.float32)
+        rc = lib.ssw_debug_gemm_run(10, S, M, N, K, _p(Ab), _p(Wb), _p(bias), _p(big), _p(xc), None, 0, None, 0.0, 0.0, _p(C), _p(st))
+        assert rc == 0, lib.ssw_last_error().decode()
+        check(C, xc, st, prod + big[::S], "strided residual")
+        # ... and the same rows with the residual compacted: the stride changes nothing but the addresses
+        C2, xc2, st2 = np.zeros((M, N), np.float32), np.zeros((M, N), np.uint16), np.zeros((M, N // 128, 2), np.float32)
+        compact = np.ascontiguousarray(big[::S])  # (a named reference: _p keeps only the address)
+        rc = lib.ssw_debug_gemm_run(10, 1, M, N, K, _p(Ab), _p(Wb), _p(bias), _p(compact), _p(xc2), None, 0, None, 0.0, 0.0,
+                                    _p(C2), _p(st2))
+        assert rc == 0 and np.array_equal(C, C2) and np.array_equal(xc, xc2) and np.array_equal(st, st2)
+
+
 def _ln_case(rng, M, N, K):
     """a residual row block x (f32), LayerNorm parameters and a Linear; what the consumer product needs (GemmLn)"""
     x = (rng.standard_normal((M, K)) * 1.5 + rng.standard_normal((M, 1)) * 0.7).astype(np.float32)
