@@ -1183,6 +1183,7 @@ struct ssw_clip {
     float *pixels = nullptr, *out = nullptr;
     float *splitk = nullptr;  // [8][min(rows, SPLITK_MAX_ROWS)][D] f32: partial products of the text tower's split-K producers
     int *ids = nullptr, *rows = nullptr;
+    int64_t rows_key = -1;  // what `rows` holds: (B << 32 | stride) of the image tower's pooled-row list, -1 = something else
     // ssw_clip_set_option: bit 0 = bf16 residual rows in the image tower's tile path, bit 1 = bf16 rows in the text tower's,
     // bit 2 = the tile path's attention with its K / Q fragments straight from memory (attention_mfma) for S <= 64 too,
     // bit 3 = attention and out-projection as two launches (round 3's layer) where attn_out.hip's one launch applies
@@ -1344,6 +1345,7 @@ ssw_status reserve(ssw_clip *c, int64_t batch) {
     SSW_HIP_TRY(hipMalloc((void **)&c->out, batch * h.proj * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&c->ids, batch * h.t_maxpos * sizeof(int)));
     SSW_HIP_TRY(hipMalloc((void **)&c->rows, batch * sizeof(int)));
+    c->rows_key = -1;
     SSW_HIP_TRY(hipMalloc((void **)&c->stats_a, rows * (D / 128 + 1) * 2 * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&c->stats_b, rows * (D / 128 + 1) * 2 * sizeof(float)));
     SSW_HIP_TRY(hipMalloc((void **)&c->splitk, 8 * std::min<int64_t>(rows, SPLITK_MAX_ROWS) * D * sizeof(float)));
@@ -1648,7 +1650,14 @@ ssw_status image_forward_from_patches(ssw_clip *c, int B, int normalize, float *
                        c->pre_b, h.ln_eps, bf16_rows(c, c->vis, 0) ? (float *)nullptr : c->hidden, c->xn, c->stats_a,
                        D / 128 > 0 ? D / 128 : 1, c->cls, c->vpos, T);
     SSW_TRY(run_tower(c, c->vis, B, T, 0));
-    hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, c->pooled_compact ? 1 : T, c->rows);
+    {   // the pooled rows' list depends on (B, stride) only: a launch (~5 us of a small forward) the first time, none after
+        const int stride = c->pooled_compact ? 1 : T;
+        const int64_t key = ((int64_t)B << 32) | (uint32_t)stride;
+        if (c->rows_key != key) {
+            hipLaunchKernelGGL(cls_rows, dim3((B + 255) / 256), dim3(256), 0, s, B, stride, c->rows);
+            c->rows_key = key;
+        }
+    }
     return pool_and_project(c, c->vis, B, D, normalize, out_dev);
 }
 
@@ -1680,6 +1689,7 @@ ssw_status text_forward(ssw_clip *c, const int *ids_dev, int B, int L, int norma
                            D / 128 > 0 ? D / 128 : 1);
     SSW_TRY(run_tower(c, c->txt, B, L, 1));
     hipLaunchKernelGGL(eos_rows, dim3((B + 255) / 256), dim3(256), 0, s, ids_dev, B, L, h.eos, c->rows);
+    c->rows_key = -1;
     return pool_and_project(c, c->txt, B, D, normalize, out_dev);
 }
 

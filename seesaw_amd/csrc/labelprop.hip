@@ -332,10 +332,12 @@ __global__ __launch_bounds__(256) void k_inc_expand(int k, const int64_t *__rest
     }
 }
 
-// Sweep k over the listed rows: one WAVE per row.  The wave takes the row 512 entries at a time -- coalesced index /
-// weight loads, the gathers of f_old in flight together, each product formed once and parked in the wave's 4 KB of LDS --
-// then lane 0 adds them in ascending position: the order of the full sweeps and of scipy's csr_matvec.  Rows that are
-// new in this sweep also enter their block of 256 nodes in the block list (first touch by the block's stamp).
+// Sweep k over the listed rows: a wave takes FOUR rows at a time, 16 lanes a row (a row of this graph holds ~12 entries;
+// hub rows hold thousands and keep their 16 lanes busy for more trips while the other three groups idle).  A group takes
+// its row 128 entries at a time -- coalesced index / weight loads, the gathers of f_old in flight together, each product
+// formed once and parked in the group's 1 KB of LDS -- then the group's first lane adds them in ascending position: the
+// order of the full sweeps and of scipy's csr_matvec.  Rows that are new in this sweep also enter their block of 256
+// nodes in the block list (first touch by the block's stamp).
 __global__ __launch_bounds__(256) void k_inc_rows(int k, const int32_t *__restrict__ mem, int cap, const int64_t *__restrict__ indptr,
                                                   const int32_t *__restrict__ indices, const double *__restrict__ data,
                                                   const double *__restrict__ wsum, const double *__restrict__ prior,
@@ -343,47 +345,52 @@ __global__ __launch_bounds__(256) void k_inc_rows(int k, const int32_t *__restri
                                                   const unsigned char *__restrict__ is_label, const double *__restrict__ label_val,
                                                   double lambda, double low_bound, double high_bound, uint32_t *__restrict__ bstamp,
                                                   uint32_t ep, int32_t *__restrict__ blk, LpInc *__restrict__ ctl) {
-    __shared__ double prod[4][512];
-    const int lane = threadIdx.x & 63;
+    __shared__ double prod[4][4][128];
+    const int lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mk = min(ctl->total, cap), m_prev = ctl->m[k - 1];  // (the expansion of this sweep has finished: stream order)
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->m[k] = mk;
     const int nwaves = gridDim.x * 4;
-    for (int q = blockIdx.x * 4 + wave; q < mk; q += nwaves) {
-        const int64_t row = mem[q];
-        if ((k == 1 || q >= m_prev) && lane == 0) {  // a row new to the list: its block joins the block list
+    for (int q0 = (blockIdx.x * 4 + wave) * 4; q0 < mk; q0 += nwaves * 4) {  // (q0 is wave-uniform)
+        const int q = q0 + g;
+        const bool live = q < mk;
+        const int64_t row = live ? (int64_t)mem[q] : 0;
+        if (live && gl == 0 && (k == 1 || q >= m_prev)) {  // a row new to the list: its block joins the block list
             const uint32_t b = (uint32_t)(row >> 8);
             if (atomicExch(&bstamp[b], ep) != ep) blk[atomicAdd(&ctl->blocks, 1)] = (int32_t)b;
         }
-        const int64_t p0 = indptr[row], p1 = indptr[row + 1];
+        const int64_t p0 = live ? indptr[row] : 0, p1 = live ? indptr[row + 1] : 0;
+        int64_t len = p1 - p0, longest = len;
+        longest = max(longest, (int64_t)__shfl_xor((long long)longest, 16, 64));
+        longest = max(longest, (int64_t)__shfl_xor((long long)longest, 32, 64));
         double sum = 0.0;
-        for (int64_t base = p0; base < p1; base += 512) {
-            const int cnt = (int)min((int64_t)512, p1 - base);
+        for (int64_t base = 0; base < longest; base += 128) {  // (wave-uniform trip count: the longest of the four rows)
+            const int cnt = (int)max((int64_t)0, min((int64_t)128, len - base));
             int32_t col[8];
             double w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int x = u * 64 + lane;
-                col[u] = x < cnt ? indices[base + x] : -1;
-                w[u] = x < cnt ? data[base + x] : 0.0;
+                const int x = u * 16 + gl;
+                col[u] = x < cnt ? indices[p0 + base + x] : -1;
+                w[u] = x < cnt ? data[p0 + base + x] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int x = u * 64 + lane;
-                if (col[u] >= 0) prod[wave][x] = __dmul_rn(w[u], f_old[col[u]]);
+                const int x = u * 16 + gl;
+                if (col[u] >= 0) prod[wave][g][x] = __dmul_rn(w[u], f_old[col[u]]);
             }
             // (one wave writes and reads these bytes: its LDS operations complete in order; the fences keep the compiler
-            //  from moving lane 0's reads ahead of the other lanes' writes, and the next chunk's writes ahead of the reads)
+            //  from moving the adding lanes' reads ahead of the other lanes' writes, and the next trip's writes ahead of the reads)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane == 0)
-                for (int p = 0; p < cnt; ++p) sum = __dadd_rn(sum, prod[wave][p]);
+            if (gl == 0)
+                for (int p = 0; p < cnt; ++p) sum = __dadd_rn(sum, prod[wave][g][p]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (lane == 0) {
+        if (live && gl == 0) {
             const double weighted = __dadd_rn(sum, __dmul_rn(lambda, prior[row]));
             double v = weighted / __dadd_rn(wsum[row], lambda);
             if (!(v >= low_bound) || !(v <= high_bound)) ctl->bound_violation = 1;
