@@ -269,8 +269,8 @@ __global__ void k_lp_scores_f32(const double *__restrict__ f, const unsigned cha
 // installed prior and differs from the call before it in a handful of labels, so row i of iterate k can differ from
 // the previous call's only if a label changed within k hops of i.  The handle keeps the previous call's iterates
 // F[0..s] and, per sweep, the maximum of (F[k] - F[k-1])^2 over each block of 256 nodes; a call recomputes the rows
-// whose inputs changed (host: frontier sets through the transposed pattern), the maxima of the blocks they sit in,
-// and the per-sweep maximum over all blocks -- the same per-row arithmetic in the same order as the full sweeps
+// whose inputs changed (the frontier is grown on the device through the transposed pattern: k_inc_expand), the maxima of
+// the blocks they sit in, and the per-sweep maximum over all blocks -- the same per-row arithmetic in the same order as the full sweeps
 // (products formed once, added in ascending position), so every value, the sweep count and the returned iterate
 // are what the full sweeps give, bit for bit (tests/test_labelprop_gpu.py), at a cost that does not depend on n.
 // ---------------------------------------------------------------------------------------
@@ -624,7 +624,6 @@ struct ssw_lp {
     int32_t *ht_indices = nullptr;
     uint32_t *stamp = nullptr, *bstamp = nullptr;
     int32_t *mem = nullptr, *blk = nullptr;
-    LpInc *ctl = nullptr;
     int cap_rows = 0;
     uint32_t epoch = 0;
     // what the last propagation did (ssw_labelprop_last_run_info)
@@ -654,7 +653,7 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
         (void)hipFree(lp->bmax[k]);
     }
     for (void *q : {(void *)lp->ht_indptr, (void *)lp->ht_indices, (void *)lp->stamp, (void *)lp->bstamp, (void *)lp->mem,
-                    (void *)lp->blk, (void *)lp->ctl})
+                    (void *)lp->blk})
         (void)hipFree(q);
     (void)hipFree(lp->inc_dev);
     if (lp->inc_host) (void)hipHostFree(lp->inc_host);
@@ -1045,7 +1044,7 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
     return SSW_OK;
 }
 
-// ---- the tracked run behind ssw_labelprop_run_resident (see k_lp_rows above) ------------------------------------
+// ---- the tracked run behind ssw_labelprop_run_resident (see k_inc_seed / k_inc_expand / k_inc_rows above) ----------
 static ssw_status lp_ensure_level(ssw_lp *lp, int k) {
     const int64_t nb = (lp->n + 255) / 256;
     if (!lp->f[k]) SSW_HIP_TRY(hipMalloc((void **)&lp->f[k], (size_t)lp->n * sizeof(double) + 16));
