@@ -914,7 +914,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
     // the host buffers above must be consumed before this call returns: we synchronise below
     LpState st;
     memset(&st, 0, sizeof(st));
-    int issued = 0;
+    int issued = 0, syncs = 0;
     // Sweeps are enqueued in batches and the host looks at the state once per batch; sweeps enqueued past convergence
     // are no-ops but still cost their launch and their check (~13 us a pair).  Consecutive rounds of a session converge
     // in about the same number of sweeps, so the first batch is what the previous call needed plus one (8 at first).
@@ -930,6 +930,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
         SSW_HIP_TRY(hipGetLastError());
         SSW_HIP_TRY(hipMemcpyAsync(&st, lp->state, sizeof(LpState), hipMemcpyDeviceToHost, s));
         SSW_HIP_TRY(hipStreamSynchronize(s));
+        ++syncs;
         if (st.done) break;
     }
     if (max_iter == 0) SSW_HIP_TRY(hipStreamSynchronize(s));
@@ -939,7 +940,7 @@ static ssw_status lp_run_core(ssw_lp *lp, const double *prior_host_or_null, bool
     }
     lp->last_result = (st.sweeps > 0) ? st.result_buf : 0;
     lp->sweeps_hint = st.done ? (int)st.sweeps : 0;
-    lp->info[0] = 0, lp->info[1] = st.sweeps, lp->info[2] = 2 * (int64_t)issued + 2, lp->info[3] = (issued + 7) / 8 + 0,
+    lp->info[0] = 0, lp->info[1] = st.sweeps, lp->info[2] = 2 * (int64_t)issued + 2, lp->info[3] = syncs,
     lp->info[4] = (int64_t)issued * n, lp->info[5] = 0;
     *st_out = st;
     return SSW_OK;
@@ -1097,7 +1098,8 @@ static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below K
     return k < ssw_lp::KEEP ? k : ssw_lp::KEEP - 2 + ((k - (ssw_lp::KEEP - 2)) & 1);
 }
 
-static ssw_status lp_upload_label_list(ssw_lp *lp, const std::vector<int64_t> &ids, const std::vector<double> &vals) {
+// room for `ids.size()` installed labels in lp->ids / lp->vals (the device-side list the other entry points clear by)
+static ssw_status lp_reserve_labels(ssw_lp *lp, const std::vector<int64_t> &ids) {
     const int64_t m = (int64_t)ids.size();
     if (m > lp->ids_cap) {
         SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
@@ -1136,7 +1138,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
     std::vector<int64_t> ids((size_t)n_labels);
     std::vector<double> vals((size_t)n_labels);
     for (size_t i = 0; i < lab.size(); ++i) ids[i] = lab[i].first, vals[i] = lab[i].second;
-    SSW_TRY(lp_upload_label_list(lp, ids, vals));
+    SSW_TRY(lp_reserve_labels(lp, ids));
     ssw_lp::Track &tk = lp->trk;
     LpState st;
     memset(&st, 0, sizeof(st));
