@@ -58,3 +58,58 @@ def test_committed_traffic_record_matches_the_committed_kernel():
         val, note = mod.measured_traffic(rows)
         assert val is not None, note
         assert 0.98 < val / tj["shapes"][str(rows)]["algorithmic_bytes_per_launch"] < 1.10
+
+
+def _strict_loads(line):
+    def refuse(name):
+        raise ValueError(f"non-finite constant {name} in the bench line")
+    return json.loads(line, parse_constant=refuse)
+
+
+@pytest.mark.parametrize("stored", ["r05_bench_100M_output.json", "r05_rehearsal_gloo_world4_12p5M_rows_per_rank.json"])
+def test_the_stdout_line_is_short_strict_json_with_the_contract_fields(stored):
+    """the driver keeps 8 000 characters of stdout and could not parse round 5's 20.8-KB line.  The line
+    is built from the full result (which goes to bench_detail.json): < 6 000 characters, strict JSON, numbers only in
+    `extras`, and it still carries the contract's fields + roofline + cpu_baseline (+ allgather_us at N > 1)."""
+    spec = importlib.util.spec_from_file_location("bench_line", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    full = json.load(open(os.path.join(ROOT, "profiles", stored)))
+    assert len(json.dumps(full)) > 2000          # the stored record is a full one
+    line = mod.compact_line(full)
+    assert "\n" not in line and len(line) < mod.LINE_LIMIT <= 6000
+    assert line.isascii()
+    d = _strict_loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "allgather_us", "extras"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5) and d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-3)
+    assert r["traffic"] is not None and r["traffic"] == pytest.approx(full["roofline"]["traffic"], rel=1e-5)
+    assert "workload" in d["config"] and "model" not in d["config"]
+    if full["n_gpus"] == 1:
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and len(c["sample"]) <= 120
+        assert d["extras"]["c5_knn_prop2_hip_iters_per_s"] > 0 and d["extras"]["c3_image_b200_ms"] > 0
+    else:
+        assert d["allgather_us"]["steps"] == full["steps"] and d["cpu_baseline"] is None
+        assert any(k.endswith("_iters_per_s_all_gpus") for k in d["extras"])
+    assert all(isinstance(v, (int, float)) and not isinstance(v, bool) for v in d["extras"].values()), "extras: numbers only"
+
+
+def test_the_line_never_outgrows_the_limit_and_never_carries_non_finite_numbers():
+    spec = importlib.util.spec_from_file_location("bench_line2", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_100M_output.json")))
+    big = full["extras"]["feedback_loop"]
+    for i in range(200):   # a run that grew many more loops: the line drops extras from the end instead of growing
+        big["full_120000x13"][f"loop{i}"] = dict(big["full_120000x13"]["plain"])
+    full["roofline"]["avg_launch_ms"] = float("nan")
+    full["extras"]["clip"]["image_ms_per_batch"] = float("inf")
+    line = mod.compact_line(full)
+    assert len(line) < mod.LINE_LIMIT
+    d = _strict_loads(line)
+    assert d["roofline"]["avg_launch_ms"] is None and "c3_image_b200_ms" not in d["extras"]
+    assert d["roofline"]["frac"] is not None and d["cpu_baseline"]["value"] > 0
