@@ -100,12 +100,14 @@ class PhaseTimers:
         self.t = {"topk_call": 0.0, "label_prop": 0.0, "fit": 0.0, "sample_draw": 0.0}
         # the label-propagation phase by entry point, and what the propagation calls did on the device
         self.lp = {"propagate": 0.0, "scores_to_index": 0.0, "fetch": 0.0, "calls": 0, "sweeps": 0, "launches": 0, "host_syncs": 0,
-                   "incremental": 0, "rows": 0, "frontier_us": 0.0, "device_wait_us": 0.0}
+                   "incremental": 0, "fused": 0, "rows": 0, "frontier_us": 0.0, "device_wait_us": 0.0}
         self._saved = []
 
     def _wrap_lp(self, cls, name, key):
         orig = getattr(cls, name)
         timers, lp = self.t, self.lp
+
+        timed_name = name
 
         def timed(obj, *a, **k):
             t0 = time.perf_counter()
@@ -121,6 +123,7 @@ class PhaseTimers:
                     lp["launches"] += int(getattr(obj, "last_launches", 0))
                     lp["host_syncs"] += int(getattr(obj, "last_host_syncs", 0))
                     lp["incremental"] += int(getattr(obj, "last_mode", 0) == 1)
+                    lp["fused"] += int(timed_name == "round")
                     lp["rows"] += int(getattr(obj, "last_rows_recomputed", 0))
                     lp["frontier_us"] += float(getattr(obj, "last_frontier_us", 0.0))
                     lp["device_wait_us"] += float(getattr(obj, "last_device_wait_us", 0.0))
@@ -163,9 +166,11 @@ class PhaseTimers:
         from seesaw_amd.logistic_regression import LogisticRegressionPT
         from seesaw_amd.loops.multi_reg import RegModule
         self._wrap(DeviceIndex, "topk", "topk_call")
-        for m, key in (("fit_transform", "propagate"), ("fit_resident", "propagate"), ("scores_to_index", "scores_to_index"),
-                       ("fetch", "fetch")):
+        for m, key in (("fit_transform", "propagate"), ("fit_resident", "propagate"), ("round", "propagate"),
+                       ("scores_to_index", "scores_to_index"), ("fetch", "fetch")):
             self._wrap_lp(LabelPropagation, m, key)
+        self._saved.append((LabelPropagation, "collect_run_info", LabelPropagation.collect_run_info))
+        LabelPropagation.collect_run_info = True
         self._wrap(RegModule, "fit", "fit")
         self._wrap(LogisticRegressionPT, "fit", "fit")
         self._wrap_function(loops_util, "permutation_prefix", "sample_draw")  # PseudoLR's np.random.permutation(n)[:k], drawn by the library
@@ -188,11 +193,13 @@ class PhaseTimers:
         lp_detail = {"propagate_ms": 1e3 * d["propagate"] / n, "scores_to_index_ms": 1e3 * d["scores_to_index"] / n,
                      "fetch_ms": 1e3 * d["fetch"] / n, "propagations": d["calls"], "sweeps_per_propagation": d["sweeps"] / calls,
                      "launches_per_propagation": d["launches"] / calls, "host_syncs_per_propagation": d["host_syncs"] / calls,
-                     "incremental_propagations": d["incremental"], "rows_recomputed_per_propagation": d["rows"] / calls,
+                     "incremental_propagations": d["incremental"], "fused_rounds": d["fused"],
+                     "rows_recomputed_per_propagation": d["rows"] / calls,
                      "host_frontier_us_per_propagation": d["frontier_us"] / calls, "device_wait_us_per_propagation": d["device_wait_us"] / calls}
         return {"iteration": total, "scan_kernel": scan_ms, "select_and_fetch": max(0.0, topk - scan_ms),
                 "label_prop": lp, "label_prop_detail": lp_detail if d["calls"] else None,
                 "fit": fit, "sample_draw": draw, "host_other": max(0.0, total - topk - lp - fit - draw),
+                "host_syncs_per_round": (d["host_syncs"] / calls) if d["calls"] else None,
                 "note": "ms per iteration of the reported session; scan_kernel by HIP events around the scan launches, the "
                         "other phases by host wall time around the C-ABI calls (they synchronise); the timed session is a "
                         "third one, run after the reported one (the wrappers cost ~1 us per call)"}

@@ -266,8 +266,8 @@ ssw_status ssw_labelprop_run_resident(ssw_lp *lp, const int64_t *label_ids, cons
  * out8: [0] 1 = the last propagation was an incremental update (0 = full sweeps, 2 = an incremental pass over the kept
  * iterates that did not converge within them, continued by full sweeps from there), [1] sweeps as the reference counts
  * them, [2] kernel launches, [3] host synchronisations, [4] rows recomputed over all sweeps, [5] iterates kept for the
- * next call, [6] nanoseconds of host time in the frontier walk, [7] nanoseconds waited for the device (incremental
- * runs).  Environment SSW_LP_NO_INCREMENTAL=1: every call runs the full sweeps (A/B, tests). */
+ * next call, [6] nanoseconds of host time from entry until everything was enqueued, [7] nanoseconds waited for the device
+ * (incremental runs).  Environment SSW_LP_NO_INCREMENTAL=1: every call runs the full sweeps (A/B, tests). */
 ssw_status ssw_labelprop_last_run_info(ssw_lp *lp, int64_t *out8);
 /* "nothing to propagate yet": the installed prior itself becomes the resident result (unchanged values) and the given
  * nodes are marked labelled, so that the first rounds of a graph loop -- BaseLabelPropagationRanker.update skips the
@@ -279,6 +279,19 @@ ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host);
  * (seesaw/loops/util.py:19, `lr.current_scores()[~is_labeled][randsel]`) -- 8 m bytes back instead of 8 n. */
 ssw_status ssw_labelprop_gather(ssw_lp *lp, const int64_t *rows_host, int64_t m, double *out_host);
 ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t mask_labeled);
+/* One feedback round of a graph loop in ONE call -- KnnProp2.refine + next_batch (seesaw/loops/graph_based.py:73-121;
+ * LabelPropagationRanker2.update, seesaw/research/knn_methods.py:176-199):
+ *   propagate != 0: ssw_labelprop_run_resident(label_ids, label_vals, ...);  == 0: ssw_labelprop_prior_as_result(label_ids)
+ *   then ssw_labelprop_scores_to_index(mask_labeled) and ssw_index_topk(index, q = NULL, excluded_images, n_excluded, k, out_*)
+ * with the results of the three calls.  When the propagation is an incremental update (every round of a session after the
+ * first that propagates) the whole round is enqueued on one stream -- the scores kernel takes the converged iterate's
+ * number from the device-side control block -- and the host waits ONCE, on the selection's sequence word in pinned memory
+ * (ssw_labelprop_last_run_info: [3] = 1).  info[0] = 3 for propagate == 0. */
+ssw_status ssw_labelprop_round(ssw_lp *lp, ssw_index *index, int32_t propagate, const int64_t *label_ids,
+                               const double *label_vals, int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
+                               int32_t mask_labeled, const int64_t *excluded_images, int64_t n_excluded, int32_t k,
+                               int64_t *out_images, float *out_scores, int64_t *out_best_rows, int32_t *out_count,
+                               int32_t *out_sweeps, int32_t *out_converged);
 /* device address of the [n] f64 result of the last propagation (valid until the next run on this handle). */
 ssw_status ssw_labelprop_device_scores(ssw_lp *lp, const double **out_dev_scores);
 

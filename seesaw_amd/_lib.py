@@ -93,6 +93,8 @@ _SIGNATURES = {
     "ssw_labelprop_last_run_info": (c_i32, [c_void_p, c_void_p]),
     "ssw_labelprop_scores_to_index": (c_i32, [c_void_p, c_void_p, c_i32]),
     "ssw_labelprop_device_scores": (c_i32, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "ssw_labelprop_round": (c_i32, [c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, ctypes.c_double, ctypes.c_double, c_i32,
+                                    c_i32, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ssw_xlx": (c_i32, [c_void_p, c_void_p, c_void_p]),
     "ssw_knn_build": (c_i32, [c_void_p, c_i32, ctypes.c_uint64, c_void_p, c_void_p, c_void_p]),
     "ssw_fb_set_xlx": (c_i32, [c_void_p, c_void_p]),

@@ -96,6 +96,7 @@ struct ssw_index {
     unsigned char *small_host = nullptr;
     unsigned small_seq = 0;
     unsigned res_pending_seq = 0;  // != 0: the selection in flight publishes into res_host under this sequence number
+    unsigned small_pending_seq = 0;  // the same for the small form (topk_small_enqueue / _collect)
     float *q2_dev = nullptr;  // second query vector (score_rows)
     PinnedStage q2_stage;
     // tile geometry + staging of the avg_score aggregation (rescore.hip)
@@ -719,9 +720,10 @@ static bool small_path_ok(const ssw_index *idx, int64_t n_excluded) {
            n_excluded <= SMALL_EXCL_CAP;
 }
 
-static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t *excluded_images, int64_t n_excluded,
-                             int32_t k, int64_t *out_images, float *out_scores, int64_t *out_best_rows,
-                             int32_t *out_count) {
+// enqueue half: [stage the query, scan,] exclusion list into the pinned block, ONE selection launch that publishes the
+// packed result under a fresh sequence number (idx->small_pending_seq)
+static ssw_status topk_small_enqueue(ssw_index *idx, const float *q_host, const int64_t *excluded_images, int64_t n_excluded,
+                                     int32_t k) {
     const size_t q_bytes = (size_t)idx->dim * sizeof(float), ex_bytes = (size_t)SMALL_EXCL_CAP * sizeof(int64_t);
     const size_t res_bytes = 16 + (size_t)SSW_MAX_TOPK * 12;
     if (!idx->small_host) {
@@ -750,27 +752,22 @@ static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t 
     if (n_excluded > 0) memcpy(idx->small_host + q_bytes, excluded_images, (size_t)n_excluded * sizeof(int64_t));
     unsigned seq = ++idx->small_seq;
     if (seq == 0) seq = ++idx->small_seq;
-    unsigned char *res = idx->small_host + q_bytes + ex_bytes;
     SSW_TRY(launch_select_small(idx->ws, idx->scores, idx->has_map ? idx->row_start : nullptr, idx->n_images,
                                 reinterpret_cast<const int64_t *>(dev_view + q_bytes), n_excluded, k,
                                 dev_view + q_bytes + ex_bytes, seq, idx->stream));
-    const unsigned *flag = reinterpret_cast<const unsigned *>(res) + 3;
-    bool seen = false;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned it = 0;; ++it) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) {
-            seen = true;
-            break;
-        }
-        if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
-    }
-    if (!seen) {
-        SSW_HIP_TRY(hipStreamSynchronize(idx->stream));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-            set_error("topk: the selection kernel finished without publishing its result");
-            return SSW_ERR_HIP;
-        }
-    }
+    idx->small_pending_seq = seq;
+    return SSW_OK;
+}
+
+// collect half: spin on the sequence word, decode the packed result
+static ssw_status topk_small_collect(ssw_index *idx, int32_t k, int64_t *out_images, float *out_scores, int64_t *out_best_rows,
+                                     int32_t *out_count) {
+    const size_t q_bytes = (size_t)idx->dim * sizeof(float), ex_bytes = (size_t)SMALL_EXCL_CAP * sizeof(int64_t);
+    const unsigned seq = idx->small_pending_seq;
+    SSW_REQUIRE(seq != 0 && idx->small_host != nullptr, "topk: no small selection in flight");
+    idx->small_pending_seq = 0;
+    unsigned char *res = idx->small_host + q_bytes + ex_bytes;
+    SSW_TRY(wait_host_seq(idx->stream, reinterpret_cast<const unsigned *>(res) + 3, seq));
     const int32_t *hdr = reinterpret_cast<const int32_t *>(res);
     int32_t count = hdr[0];
     if (count > k) count = k;
@@ -785,6 +782,62 @@ static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t 
     *out_count = count;
     return SSW_OK;
 }
+
+static ssw_status topk_small(ssw_index *idx, const float *q_host, const int64_t *excluded_images, int64_t n_excluded,
+                             int32_t k, int64_t *out_images, float *out_scores, int64_t *out_best_rows,
+                             int32_t *out_count) {
+    SSW_TRY(topk_small_enqueue(idx, q_host, excluded_images, n_excluded, k));
+    return topk_small_collect(idx, k, out_images, out_scores, out_best_rows, out_count);
+}
+
+// ---- the two halves of ssw_index_topk(q = NULL) for callers that put more work on the stream in between or ahead
+// (ssw_labelprop_round: propagation -> scores -> this selection, ONE wait).  `on_stream` replaces the handle's stream for
+// the duration of the call; the caller has made sure the handle's own stream is idle (ssw_index_sync).
+extern "C++" {
+namespace ssw {
+struct StreamSwap {
+    ssw_index *idx;
+    hipStream_t keep;
+    StreamSwap(ssw_index *i, hipStream_t s) : idx(i), keep(i->stream) { idx->stream = s; }
+    ~StreamSwap() { idx->stream = keep; }
+};
+
+ssw_status index_enqueue_topk_resident(ssw_index *idx, hipStream_t on_stream, const int64_t *excluded_images, int64_t n_excluded,
+                                       int32_t k) {
+    SSW_REQUIRE(idx != nullptr, "NULL argument");
+    SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    SSW_REQUIRE(n_excluded == 0 || excluded_images != nullptr, "excluded_images is NULL");
+    StreamSwap sw(idx, on_stream);
+    if (small_path_ok(idx, n_excluded)) return topk_small_enqueue(idx, nullptr, excluded_images, n_excluded, k);
+    if (idx->n_images == 0) return SSW_OK;
+    SSW_TRY(ssw_index_set_excluded(idx, excluded_images, n_excluded));
+    SSW_TRY(arm_host_result(idx));
+    const ssw_status st = do_select(idx, k);
+    if (st != SSW_OK) {
+        idx->ws.host_packed = nullptr;
+        idx->res_pending_seq = 0;
+    }
+    return st;
+}
+
+ssw_status index_collect_topk(ssw_index *idx, hipStream_t on_stream, int32_t k, int64_t *out_images, float *out_scores,
+                              int64_t *out_best_rows, int32_t *out_count) {
+    SSW_REQUIRE(idx != nullptr && out_count != nullptr, "NULL argument");
+    *out_count = 0;
+    StreamSwap sw(idx, on_stream);
+    if (idx->small_pending_seq != 0) return topk_small_collect(idx, k, out_images, out_scores, out_best_rows, out_count);
+    return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
+}
+
+// drop a selection that was enqueued but whose input turned out not to be ready (the caller enqueues it again)
+void index_abandon_topk(ssw_index *idx, hipStream_t on_stream) {
+    (void)hipStreamSynchronize(on_stream);
+    idx->small_pending_seq = 0;
+    idx->res_pending_seq = 0;
+    idx->ws.host_packed = nullptr;
+}
+}  // namespace ssw
+}  // extern "C++"
 
 ssw_status ssw_index_topk(ssw_index *idx, const float *q_host, const int64_t *excluded_images,
                           int64_t n_excluded, int32_t k, int64_t *out_images, float *out_scores,

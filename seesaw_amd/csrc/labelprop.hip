@@ -445,6 +445,38 @@ __global__ __launch_bounds__(1024) void k_lp_levelmax(LpBmaxPtrs bm, int64_t nb,
     }
 }
 
+// The tail of a fused round (ssw_labelprop_round): the incremental pass's answer is iterate conv - 1, conv = the first
+// sweep whose maximum over all blocks is below eps (the host's rule, lp_run_tracked) -- decided HERE from the control
+// block, so the f32 scores for the selection can be written without the host looking at the control block first.  Thread 0
+// leaves a copy of the block in pinned host memory (m[8] carries conv); when the pass did not converge / overflowed /
+// left the bounds nothing is written and the host redoes the round the slow way.
+struct LpFPtrs {
+    const double *p[8];
+};
+__global__ void k_lp_scores_sel(LpFPtrs fp, const LpInc *__restrict__ ctl, int levels, double eps,
+                                const unsigned char *__restrict__ is_label_or_null, const int32_t *__restrict__ perm_or_null,
+                                int64_t n, float *__restrict__ out, LpInc *__restrict__ host_copy) {
+    int conv = 0;
+    if (!ctl->overflow && !ctl->bound_violation)
+        for (int k = 1; k <= levels; ++k)
+            if (ctl->level_max[k] < eps) {
+                conv = k;
+                break;
+            }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        LpInc c = *ctl;
+        c.m[8] = conv;
+        *host_copy = c;
+        __threadfence_system();
+    }
+    if (!conv) return;
+    const double *__restrict__ f = fp.p[conv - 1];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = perm_or_null ? (int64_t)perm_or_null[i] : i;
+    out[i] = (is_label_or_null && is_label_or_null[r]) ? -INFINITY : (float)f[r];
+}
+
 __global__ void k_lp_clear_labels(unsigned char *is_label, const int64_t *ids, int64_t n_labels) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_labels) is_label[ids[i]] = 0;
@@ -556,6 +588,14 @@ __global__ void k_lp_scores_f32_perm(const double *__restrict__ f, const unsigne
     out[i] = (is_label_or_null && is_label_or_null[r]) ? -INFINITY : (float)f[r];
 }
 
+__global__ void k_lp_scores_f32_perm_or_plain(const double *__restrict__ f, const unsigned char *__restrict__ is_label_or_null,
+                                              const int32_t *__restrict__ perm_or_null, int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = perm_or_null ? (int64_t)perm_or_null[i] : i;
+    out[i] = (is_label_or_null && is_label_or_null[r]) ? -INFINITY : (float)f[r];
+}
+
 __global__ void k_lp_gather(const double *__restrict__ f, const int64_t *__restrict__ rows, int64_t m,
                             double *__restrict__ out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -628,6 +668,22 @@ struct ssw_lp {
     uint32_t epoch = 0;
     // what the last propagation did (ssw_labelprop_last_run_info)
     int64_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LpInc *round_host = nullptr;  // pinned, device-mapped: the control block as the fused round's scores kernel saw it
+};
+
+// the rest of a feedback round behind the propagation (ssw_labelprop_round): f32 scores into the index + the selection
+struct LpRoundTail {
+    ssw_index *index = nullptr;
+    float *index_scores = nullptr;
+    bool mask_labeled = true;
+    const int64_t *excluded = nullptr;
+    int64_t n_excluded = 0;
+    int32_t k = 0;
+    int64_t *out_images = nullptr;
+    float *out_scores = nullptr;
+    int64_t *out_best_rows = nullptr;
+    int32_t *out_count = nullptr;
+    bool valid = false;  // the selection's result was produced from the propagation's answer and sits in out_*
 };
 
 extern "C" {
@@ -657,6 +713,7 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
         (void)hipFree(q);
     (void)hipFree(lp->inc_dev);
     if (lp->inc_host) (void)hipHostFree(lp->inc_host);
+    if (lp->round_host) (void)hipHostFree(lp->round_host);
     (void)hipFree(lp->is_label);
     (void)hipFree(lp->g_rows);
     (void)hipFree(lp->g_vals);
@@ -679,6 +736,9 @@ ssw_status ssw_labelprop_destroy(ssw_lp *lp) {
 
 static thread_local bool g_lp_skip_blocked = false;
 static ssw_status lp_upload_transpose(ssw_lp *lp, const int64_t *indptr_host, const int32_t *indices_host);
+static ssw_status lp_ensure_transpose(ssw_lp *lp);
+static ssw_status lp_session_buffers(ssw_lp *lp);
+static ssw_status lp_reserve_labels(ssw_lp *lp, const std::vector<int64_t> &ids);
 
 ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr_host,
                                 const int32_t *indices_host, const double *data_host,
@@ -800,9 +860,8 @@ ssw_status ssw_labelprop_create(int32_t device, int64_t n, const int64_t *indptr
                 break;
             }
     }
-    // the TRANSPOSED pattern for the incremental runs' frontier sets, built and uploaded here (0.1 s at 18 M non-zeros), not
-    // inside a session's first update: it would be that round's latency
-    if (ssw_status rc = lp_upload_transpose(lp, indptr_host, indices_host); rc != SSW_OK) return bail(rc);
+    // (the TRANSPOSED pattern for the incremental runs' frontier sets is built by the first ssw_labelprop_set_prior -- the
+    // per-session call -- so handles that only ever run ssw_labelprop_run pay neither its 0.1 s nor its memory: ADVICE r5)
     *out = lp;
     return SSW_OK;
 }
@@ -1038,6 +1097,8 @@ ssw_status ssw_labelprop_set_prior(ssw_lp *lp, const double *prior_host) {
                                    lp->stream));
     }
     SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
+    SSW_TRY(lp_ensure_transpose(lp));  // first session on this handle: what the incremental updates walk (0.1 s at 18 M non-zeros)
+    SSW_TRY(lp_session_buffers(lp));   // ... and what its first propagation would otherwise allocate inside a timed round
     lp->prior_lo = lo;
     lp->prior_hi = hi;
     lp->prior_installed = true;
@@ -1094,6 +1155,32 @@ static ssw_status lp_upload_transpose(ssw_lp *lp, const int64_t *indptr_host, co
     return SSW_OK;
 }
 
+// Allocations a session's propagations need, made by ssw_labelprop_set_prior (the per-session call) instead of by the
+// first round that propagates (round 5: that round was 3 ms of a 0.46 ms mean -- hipMalloc / hipHostMalloc of the kept
+// iterates, the block maxima and the packed label lists): iterates 0 .. 4 (a run of the benchmark's graph needs 2-3
+// sweeps and a run without a hint issues 4 before it looks; deeper levels still come on demand), the label-list staging, the fused round's pinned control block.
+static ssw_status lp_session_buffers(ssw_lp *lp) {
+    for (int k = 1; k <= 4; ++k) SSW_TRY(lp_ensure_level(lp, k));
+    SSW_TRY(lp_inc_reserve(lp, 1 << 16));
+    if (lp->ids_cap == 0) SSW_TRY(lp_reserve_labels(lp, std::vector<int64_t>(1)));
+    if (!lp->round_host) {
+        SSW_HIP_TRY(hipHostMalloc((void **)&lp->round_host, sizeof(LpInc), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(lp->round_host, 0, sizeof(LpInc));
+    }
+    return SSW_OK;
+}
+
+// built once per handle, from the pattern as the device holds it (device order under a permutation), and not at all
+// when the incremental path is switched off
+static ssw_status lp_ensure_transpose(ssw_lp *lp) {
+    if (lp->ht_indptr || getenv("SSW_LP_NO_INCREMENTAL")) return SSW_OK;
+    std::vector<int64_t> ip((size_t)lp->n + 1);
+    std::vector<int32_t> ix((size_t)lp->nnz);
+    SSW_HIP_TRY(hipMemcpy(ip.data(), lp->indptr, ip.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (lp->nnz) SSW_HIP_TRY(hipMemcpy(ix.data(), lp->indices, ix.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return lp_upload_transpose(lp, ip.data(), ix.data());
+}
+
 static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below KEEP, the last two alternate beyond
     return k < ssw_lp::KEEP ? k : ssw_lp::KEEP - 2 + ((k - (ssw_lp::KEEP - 2)) & 1);
 }
@@ -1102,21 +1189,34 @@ static int lp_iter_buf(int k) {  // buffer of iterate k: kept one by one below K
 static ssw_status lp_reserve_labels(ssw_lp *lp, const std::vector<int64_t> &ids) {
     const int64_t m = (int64_t)ids.size();
     if (m > lp->ids_cap) {
+        // The installed list (n_labels_installed entries) is what the full path clears is_label[] by: it moves into the
+        // larger buffers (freeing it here left the clear kernel reading uninitialised ids past 1024 labels).
         SSW_HIP_TRY(hipStreamSynchronize(lp->stream));
-        (void)hipFree(lp->ids);
-        (void)hipFree(lp->vals);
-        lp->ids = nullptr, lp->vals = nullptr;
         int64_t cap = 1024;
         while (cap < m) cap <<= 1;
-        SSW_HIP_TRY(hipMalloc((void **)&lp->ids, (size_t)cap * sizeof(int64_t)));
-        SSW_HIP_TRY(hipMalloc((void **)&lp->vals, (size_t)cap * sizeof(double)));
+        int64_t *nids = nullptr;
+        double *nvals = nullptr;
+        SSW_HIP_TRY(hipMalloc((void **)&nids, (size_t)cap * sizeof(int64_t)));
+        if (hipMalloc((void **)&nvals, (size_t)cap * sizeof(double)) != hipSuccess) {
+            (void)hipFree(nids);
+            set_error("label propagation: out of device memory for %lld labels", (long long)cap);
+            return SSW_ERR_NOMEM;
+        }
+        const int64_t keep = std::min<int64_t>(lp->n_labels_installed, lp->ids_cap);
+        if (keep > 0 && lp->ids && lp->vals) {
+            SSW_HIP_TRY(hipMemcpy(nids, lp->ids, (size_t)keep * sizeof(int64_t), hipMemcpyDeviceToDevice));
+            SSW_HIP_TRY(hipMemcpy(nvals, lp->vals, (size_t)keep * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+        (void)hipFree(lp->ids);
+        (void)hipFree(lp->vals);
+        lp->ids = nids, lp->vals = nvals;
         lp->ids_cap = cap;
     }
     return SSW_OK;
 }
 
 static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const double *label_vals, int64_t n_labels,
-                                 double reg_lambda, double eps, int32_t max_iter, LpState *st_out) {
+                                 double reg_lambda, double eps, int32_t max_iter, LpState *st_out, LpRoundTail *tail = nullptr) {
     SSW_REQUIRE(reg_lambda >= 0.0, "reg_lambda < 0");
     SSW_REQUIRE(max_iter >= 0, "max_iter < 0");
     SSW_REQUIRE(n_labels == 0 || (label_ids && label_vals), "NULL labels");
@@ -1125,6 +1225,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
     const int64_t n = lp->n, nb = (n + 255) / 256;
     hipStream_t s = lp->stream;
     const double lo = lp->prior_lo, hi = lp->prior_hi;
+    const auto t_entry = std::chrono::steady_clock::now();
     // the labels in device positions, ascending; duplicate ids (numpy: the last assignment wins) take the untracked path
     const int64_t *mapped = lp_map_ids(lp, label_ids, n_labels);
     std::vector<std::pair<int64_t, double>> lab((size_t)n_labels);
@@ -1132,7 +1233,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
     std::sort(lab.begin(), lab.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     bool unique = true;
     for (size_t i = 1; i < lab.size(); ++i) unique = unique && lab[i].first != lab[i - 1].first;
-    static const bool inc_off = getenv("SSW_LP_NO_INCREMENTAL") != nullptr;  // A/B and tests: every call runs the full sweeps
+    const bool inc_off = getenv("SSW_LP_NO_INCREMENTAL") != nullptr;  // A/B and tests: every call runs the full sweeps (read per call)
     if (!unique || max_iter == 0)
         return lp_run_core(lp, nullptr, true, nullptr, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, st_out);
     std::vector<int64_t> ids((size_t)n_labels);
@@ -1143,7 +1244,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
     LpState st;
     memset(&st, 0, sizeof(st));
 
-    bool inc = !inc_off && tk.valid && tk.lambda == reg_lambda && tk.eps == eps && tk.max_iter == max_iter && tk.levels >= 1;
+    bool inc = !inc_off && lp->ht_indptr != nullptr && tk.valid && tk.lambda == reg_lambda && tk.eps == eps && tk.max_iter == max_iter && tk.levels >= 1;
     int continue_from = 0;  // > 0: the incremental pass brought iterates 0 .. continue_from up to date without converging
     if (inc) {
         // ---- what changed: labels set (new, or another value) and labels removed
@@ -1214,13 +1315,40 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             hipLaunchKernelGGL(k_lp_levelmax, dim3((unsigned)tk.levels), dim3(1024), 0, s, bm, nb, dctl);
             SSW_HIP_TRY(hipGetLastError());
             lp->n_labels_installed = n_labels;  // (k_inc_seed refreshed lp->ids / lp->vals)
-            SSW_HIP_TRY(hipMemcpyAsync(hctl, dctl, sizeof(LpInc), hipMemcpyDeviceToHost, s));  // ONE copy back: the control block
-            const auto t_wait0 = std::chrono::steady_clock::now();
-            SSW_HIP_TRY(hipStreamSynchronize(s));
-            lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
-            lp->info[6] = 0;
             LpInc rctl;
-            memcpy(&rctl, hctl, sizeof(LpInc));
+            if (tail) {
+                // fused round: the scores kernel picks the converged iterate itself and leaves the control block in pinned
+                // memory, the selection follows on the same stream, and the host waits ONCE -- on the selection's word
+                LpFPtrs fp;
+                for (int k = 0; k < ssw_lp::KEEP; ++k) fp.p[k] = lp->f[k];
+                LpInc *host_view = nullptr;
+                SSW_HIP_TRY(hipHostGetDevicePointer((void **)&host_view, lp->round_host, 0));
+                lp->round_host->m[8] = -1;
+                hipLaunchKernelGGL(k_lp_scores_sel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fp, dctl, tk.levels, eps,
+                                   tail->mask_labeled ? lp->is_label : (const unsigned char *)nullptr, (const int32_t *)lp->perm, n,
+                                   tail->index_scores, host_view);
+                SSW_HIP_TRY(hipGetLastError());
+                SSW_TRY(index_enqueue_topk_resident(tail->index, s, tail->excluded, tail->n_excluded, tail->k));
+                const auto t_wait0 = std::chrono::steady_clock::now();
+                lp->info[6] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_wait0 - t_entry).count();
+                SSW_TRY(index_collect_topk(tail->index, s, tail->k, tail->out_images, tail->out_scores, tail->out_best_rows,
+                                           tail->out_count));
+                lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
+                memcpy(&rctl, lp->round_host, sizeof(LpInc));
+                if (rctl.m[8] < 0) {  // (the word the kernel always writes did not arrive: should not happen -- wait the plain way)
+                    SSW_HIP_TRY(hipStreamSynchronize(s));
+                    memcpy(&rctl, lp->round_host, sizeof(LpInc));
+                    SSW_REQUIRE(rctl.m[8] >= 0, "labelprop round: the scores kernel did not publish its control block");
+                }
+                tail->valid = rctl.m[8] > 0;
+            } else {
+                SSW_HIP_TRY(hipMemcpyAsync(hctl, dctl, sizeof(LpInc), hipMemcpyDeviceToHost, s));  // ONE copy back: the control block
+                const auto t_wait0 = std::chrono::steady_clock::now();
+                lp->info[6] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_wait0 - t_entry).count();
+                SSW_HIP_TRY(hipStreamSynchronize(s));
+                lp->info[7] = (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_wait0).count();
+                memcpy(&rctl, hctl, sizeof(LpInc));
+            }
             LpState dst;
             memset(&dst, 0, sizeof(dst));
             dst.bound_violation = rctl.bound_violation;
@@ -1285,7 +1413,12 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
         SSW_HIP_TRY(hipMemsetAsync(lp->state, 0, sizeof(LpState), s));
     }
     int issued = continue_from, syncs = 0;
-    int batch = continue_from > 0 ? 2 : (lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 8);
+    if (continue_from >= max_iter) {
+        // (max_iter <= kept levels: the incremental pass already produced iterate max_iter; the reference returns it
+        // after max_iter sweeps, not converged -- ADVICE r5)
+        st.sweeps = continue_from, st.done = 0, st.result_buf = lp_iter_buf(continue_from);
+    }
+    int batch = continue_from > 0 ? 2 : (lp->sweeps_hint > 0 ? std::min(8, lp->sweeps_hint + 1) : 4);
     while (issued < max_iter) {
         const int upto = (issued + batch < max_iter) ? issued + batch : max_iter;
         batch = 8;
@@ -1347,7 +1480,7 @@ ssw_status ssw_labelprop_last_run_info(ssw_lp *lp, int64_t *out8) {
     return SSW_OK;
 }
 
-ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels) {
+static ssw_status lp_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels, bool wait) {
     SSW_REQUIRE(lp != nullptr, "NULL argument");
     SSW_REQUIRE(lp->prior_installed, "ssw_labelprop_prior_as_result: no prior installed (ssw_labelprop_set_prior)");
     SSW_REQUIRE(n_labels == 0 || label_ids, "NULL labels");
@@ -1382,9 +1515,13 @@ ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, i
         lp->n_labels_installed = n_labels;
     }
     SSW_HIP_TRY(hipGetLastError());
-    SSW_HIP_TRY(hipStreamSynchronize(s));
+    if (wait) SSW_HIP_TRY(hipStreamSynchronize(s));
     lp->last_result = 0;
     return SSW_OK;
+}
+
+ssw_status ssw_labelprop_prior_as_result(ssw_lp *lp, const int64_t *label_ids, int64_t n_labels) {
+    return lp_prior_as_result(lp, label_ids, n_labels, true);
 }
 
 ssw_status ssw_labelprop_fetch(ssw_lp *lp, double *out_f_host) {
@@ -1485,6 +1622,60 @@ ssw_status ssw_labelprop_scores_to_index(ssw_lp *lp, ssw_index *index, int32_t m
     return SSW_OK;
 }
 
+
+/* One feedback round of a graph loop in ONE call (KnnProp2.refine + next_batch, seesaw/loops/graph_based.py:73-121;
+ * LabelPropagationRanker2.update, research/knn_methods.py:176-199):
+ *   propagate != 0:  ssw_labelprop_run_resident(labels)      propagate == 0:  ssw_labelprop_prior_as_result(label_ids)
+ *   then ssw_labelprop_scores_to_index(mask_labeled) and ssw_index_topk(q = NULL, excluded_images, k)
+ * with the same results as the three calls.  When the propagation is an incremental update (every round of a session but
+ * its first), everything is enqueued back to back on the graph handle's stream -- the scores kernel reads the converged
+ * iterate's number from the control block on the device -- and the host waits once, on the selection's sequence word. */
+ssw_status ssw_labelprop_round(ssw_lp *lp, ssw_index *index, int32_t propagate, const int64_t *label_ids,
+                               const double *label_vals, int64_t n_labels, double reg_lambda, double eps, int32_t max_iter,
+                               int32_t mask_labeled, const int64_t *excluded_images, int64_t n_excluded, int32_t k,
+                               int64_t *out_images, float *out_scores, int64_t *out_best_rows, int32_t *out_count,
+                               int32_t *out_sweeps, int32_t *out_converged) {
+    SSW_REQUIRE(lp != nullptr && index != nullptr && out_count != nullptr, "NULL argument");
+    SSW_REQUIRE(lp->prior_installed, "ssw_labelprop_round: no prior installed (ssw_labelprop_set_prior)");
+    SSW_REQUIRE(k >= 1 && k <= SSW_MAX_TOPK, "k=%d outside [1, %d]", k, SSW_MAX_TOPK);
+    SSW_REQUIRE(n_excluded == 0 || excluded_images != nullptr, "excluded_images is NULL");
+    *out_count = 0;
+    int64_t n = 0, n_images = 0;
+    int32_t D = 0;
+    void *Xv = nullptr, *scores = nullptr;
+    SSW_TRY(ssw_index_shape(index, &n, &D, &n_images));
+    SSW_TRY(ssw_index_device_ptrs(index, &Xv, &scores));
+    SSW_REQUIRE(n == lp->n, "the index has %lld rows, the graph %lld nodes", (long long)n, (long long)lp->n);
+    for (int64_t i = 0; i < n_excluded; ++i)  // (checked before anything is enqueued)
+        SSW_REQUIRE(excluded_images[i] >= 0 && excluded_images[i] < n_images, "excluded image %lld outside [0, %lld)",
+                    (long long)excluded_images[i], (long long)n_images);
+    SSW_TRY(ssw_index_sync(index));  // nothing of the index's own stream still touches the score buffer / the workspace
+    DeviceGuard guard(lp->device);
+    SSW_TRY(lp_session_buffers(lp));
+    LpRoundTail tail;
+    tail.index = index, tail.index_scores = (float *)scores, tail.mask_labeled = mask_labeled != 0;
+    tail.excluded = excluded_images, tail.n_excluded = n_excluded, tail.k = k;
+    tail.out_images = out_images, tail.out_scores = out_scores, tail.out_best_rows = out_best_rows, tail.out_count = out_count;
+    LpState st;
+    memset(&st, 0, sizeof(st));
+    if (propagate) {
+        SSW_TRY(lp_run_tracked(lp, label_ids, label_vals, n_labels, reg_lambda, eps, max_iter, &st, &tail));
+    } else {
+        lp->info[0] = 3, lp->info[1] = 0, lp->info[2] = 3, lp->info[3] = 0, lp->info[4] = 0, lp->info[5] = 0, lp->info[6] = 0, lp->info[7] = 0;
+        SSW_TRY(lp_prior_as_result(lp, label_ids, n_labels, false));
+    }
+    if (out_sweeps) *out_sweeps = st.sweeps;
+    if (out_converged) *out_converged = st.done;
+    if (tail.valid) return SSW_OK;
+    // the propagation took another path (a session's first run, more sweeps than were kept, ...): its answer is
+    // lp->f[lp->last_result] by now -- scores and selection behind it, one more wait
+    hipLaunchKernelGGL(k_lp_scores_f32_perm_or_plain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, lp->stream,
+                       lp->f[lp->last_result], mask_labeled ? lp->is_label : (const unsigned char *)nullptr, (const int32_t *)lp->perm, n,
+                       (float *)scores);
+    SSW_HIP_TRY(hipGetLastError());
+    SSW_TRY(index_enqueue_topk_resident(index, lp->stream, excluded_images, n_excluded, k));
+    return index_collect_topk(index, lp->stream, k, out_images, out_scores, out_best_rows, out_count);
+}
 
 ssw_status ssw_xlx(ssw_index *index, ssw_lp *lap, double *out_host) {
     SSW_REQUIRE(index != nullptr && lap != nullptr && out_host != nullptr, "NULL argument");

@@ -286,6 +286,16 @@ class MultiscaleIndex(AccessMethod):
         keep = np.isfinite(scores)
         return _Candidates(self._dbidx[pos[keep]], scores[keep], pos[keep], best_rows[keep])  # (`.df` for a frame)
 
+    def topk_after_update(self, model, idxs, labels, *, topk_dbidx, exclude_dbidx=None):
+        """model.update(idxs, labels) + topk_from_device_scores(model.lp.scores_to_index ...) as one device call
+        (LabelPropagationRanker2.update_and_select): the shortlist the next next_batch() of a graph loop asks for"""
+        excl_pos = self._excluded_positions(exclude_dbidx)
+        self._resident_q = None
+        pos, scores, best_rows = model.update_and_select(idxs, labels, self._dev, excluded=excl_pos,
+                                                         k=max(1, min(int(topk_dbidx), self._dbidx.shape[0])))
+        keep = np.isfinite(scores)
+        return _Candidates(self._dbidx[pos[keep]], scores[keep], pos[keep], best_rows[keep])
+
     def _activations_from_best(self, candidate_df: pd.DataFrame, topk: int):
         rows = np.asarray(candidate_df.attrs["best_rows"][:topk], dtype=np.int64)
         scores = np.asarray(candidate_df.max_score)[:topk]

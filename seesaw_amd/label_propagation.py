@@ -58,6 +58,8 @@ def ordered_csr(W, weight_sum, new_of_old):
 
 
 class LabelPropagation:
+    collect_run_info = False  # round(): also read ssw_labelprop_last_run_info (bench.py's phase timers; one more C call)
+
     def __init__(self, weight_matrix, *, reg_lambda: float, max_iter: int, epsilon=1e-5, verbose=0, device: int = 0,
                  node_order=None):
         """node_order: optional permutation new_of_old (locality_order(weight_matrix)) -- the graph is then stored on the
@@ -131,6 +133,37 @@ class LabelPropagation:
                 print(f"prop. converged after {self.last_sweeps} iterations")
         else:
             print(f"warning: did not converge after {self.last_sweeps} iterations")
+
+    def round(self, device_index, *, propagate: bool, label_ids, label_values, mask_labeled: bool, excluded, k: int):
+        """One feedback round in one C-ABI call (ssw_labelprop_round): propagate the labels over the installed prior
+        (or, propagate=False, make the prior the result with `label_ids` marked), write the f32 scores into the index's
+        score buffer and select the top k distinct non-excluded images there.  Same results as fit_resident /
+        prior_as_result + scores_to_index + DeviceIndex.topk(None, k, excluded); one host wait when the propagation is
+        an incremental update.  -> (image positions, scores f32, best rows)"""
+        ids = np.ascontiguousarray(np.asarray(label_ids).reshape(-1), dtype=np.int64)
+        vals = np.ascontiguousarray(np.asarray(label_values).reshape(-1), dtype=np.float64)
+        assert ids.shape == vals.shape
+        ex = None if excluded is None else np.ascontiguousarray(excluded, dtype=np.int64)
+        n_ex = 0 if ex is None else ex.shape[0]
+        k = int(k)
+        buf = self.__dict__.get("_round_out")
+        if buf is None or buf[0].shape[0] < k:
+            buf = self._round_out = (np.empty(k, dtype=np.int64), np.empty(k, dtype=np.float32), np.empty(k, dtype=np.int64))
+        imgs, scs, rows = buf
+        cnt, sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("ssw_labelprop_round", self._h, device_index._h, int(bool(propagate)), _p(ids), _p(vals), ids.shape[0],
+                  self.reg_lambda, float(self.epsilon), self.max_iter, int(bool(mask_labeled)), _p(ex) if n_ex else None, n_ex, k,
+                  _p(imgs), _p(scs), _p(rows), ctypes.byref(cnt), ctypes.byref(sweeps), ctypes.byref(conv))
+        if propagate:
+            self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
+            if not self.last_converged:
+                print(f"warning: did not converge after {self.last_sweeps} iterations")
+            elif self.verbose > 0:
+                print(f"prop. converged after {self.last_sweeps} iterations")
+        if self.collect_run_info:
+            self._read_run_info()
+        c = cnt.value
+        return imgs[:c].copy(), scs[:c].copy(), rows[:c].copy()
 
     def _read_run_info(self):
         """what the propagation just did on the device (ssw_labelprop_last_run_info): consecutive fit_resident calls

@@ -130,7 +130,11 @@ class KnnProp2(LoopBase):
         avg_on_device = resident and p.agg_method != "plain_score" and getattr(q.index, "_has_tile_meta", False) \
             and getattr(p, "aug_weight", None) in (None, "level_max") and hasattr(q.index, "rescore_avg_from_device_scores")
         on_device = resident and (p.agg_method == "plain_score" or avg_on_device)
-        if on_device:  # propagated scores go from the graph handle to the index's score buffer on the GPU
+        pending, self._pending = getattr(self, "_pending", None), None
+        if on_device and pending is not None and pending[1] == len(q.returned) and pending[2] == p.shortlist_size:
+            cand = pending[0]  # refine() propagated AND selected in one device call (ssw_labelprop_round)
+            scores = None
+        elif on_device:  # propagated scores go from the graph handle to the index's score buffer on the GPU
             cand = q.index.topk_from_device_scores(lambda dev: model.lp.scores_to_index(dev, mask_labeled=True),
                                                    topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned)
             scores = None
@@ -153,4 +157,13 @@ class KnnProp2(LoopBase):
         pos, neg = self.q.getXy(get_positions=True)
         idxs = np.concatenate([pos, neg])
         labels = np.concatenate([np.ones_like(pos), np.zeros_like(neg)])
-        self.state.knn_model.update(idxs, labels)
+        model, q, p = self.state.knn_model, self.q, self.params
+        self._pending = None
+        if not os.environ.get("SSW_NO_FUSED_ROUND") and callable(getattr(q.index, "topk_after_update", None)) \
+                and getattr(q.index, "_dev", None) is not None and getattr(model, "can_fuse_round", lambda: False)():
+            # the update and the selection the next next_batch() will ask for, in ONE device call and one wait: nothing
+            # next_batch's selection depends on (labels, returned images, shortlist size) changes in between
+            cand = q.index.topk_after_update(model, idxs, labels, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned)
+            self._pending = (cand, len(q.returned), p.shortlist_size)
+        else:
+            model.update(idxs, labels)

@@ -79,8 +79,19 @@ class LoopBase:
             return True
         if policy == "after_first_reversal":
             return self.reversal
-        xy = self.q.getXy()
-        if isinstance(xy, tuple):  # coarse query: (X, y)
+        fast = getattr(self.q, "_matched_arrays", None)
+        if callable(fast):  # per-image max of ys without building the frame + groupby (1 ms of a session's first round)
+            rows, miou = fast(None)
+            ys = miou > 0
+            dbidx = self.q.index._row_dbidx[rows]
+            pos_images = np.unique(dbidx[ys])
+            len_pos, len_neg = int(pos_images.shape[0]), int(np.setdiff1d(np.unique(dbidx), pos_images).shape[0])
+            xy = None
+        else:
+            xy = self.q.getXy()
+        if xy is None:
+            pass
+        elif isinstance(xy, tuple):  # coarse query: (X, y)
             ys = np.asarray(xy[1])
             len_pos, len_neg = int((ys == 1).sum()), int((ys == 0).sum())
         else:

@@ -134,6 +134,34 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
             self.lp.set_prior(self.prior_scores)  # re-install for the following rounds
         return out
 
+    def can_fuse_round(self) -> bool:
+        """True when update() + the next selection can run as ONE device call (LabelPropagation.round): the loop's case
+        -- the prior installed on the device is the start iterate of every propagation"""
+        return bool(self.lp._prior_installed and self.lp.reg_values is self.prior_scores and self.prior_scores is not None)
+
+    def update_and_select(self, idxs, labels, device_index, *, excluded, k):
+        """update(idxs, labels) and, in the same device call, the selection the next next_batch() would ask for:
+        the top k distinct non-excluded images by propagated score over the unlabelled vectors (graph_based.py:88-101).
+        Follows update()'s rule: no propagation before a negative label exists -- the prior ranks.
+        -> (image positions, scores, best rows); the propagated scores stay on the device as after update()."""
+        self.update_labels(idxs, labels)
+        stamp = self._labels_stamp
+        if getattr(self, "_neg_stamp", None) != stamp:
+            self._has_negative = any(v == 0 for v in self._label_map.values())
+            self._neg_stamp = stamp
+        ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))
+        if self._has_negative:
+            print(" propagating")
+            vals = self.labels.reshape(-1)[ids]
+        else:
+            print(" no negatives yet, skipping propagation")
+            vals = np.zeros(ids.shape[0])
+        out = self.lp.round(device_index, propagate=self._has_negative, label_ids=ids, label_values=vals, mask_labeled=True,
+                            excluded=excluded, k=k)
+        self._resident = True
+        self._current_scores = None
+        return out
+
     def _no_negatives_yet(self):
         # the reference serves the prior until a negative label exists; here the prior is in the graph handle already
         # (set_prior): it becomes the resident result with the labelled nodes marked, so these rounds select and

@@ -418,16 +418,171 @@ def test_incremental_state_is_dropped_when_it_must(oracle, monkeypatch):
     check(lp, ids[:18], vals[:18], prior2, False)
     check(lp, ids[:20], vals[:20], prior2, True)
     lp.close()
-    monkeypatch.setenv("SSW_LP_NO_INCREMENTAL", "1")
-    from seesaw_amd import _lib
-    # (the switch is read once per process by the library: only check that the answers agree when it was set from the start)
+    monkeypatch.setenv("SSW_LP_NO_INCREMENTAL", "1")       # read per call (round 6): every call runs the full sweeps
     lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
     lp.set_prior(prior)
-    lp.fit_resident(label_ids=ids[:10], label_values=vals[:10])
-    a = lp.fetch()
-    lp.fit_resident(label_ids=ids[:12], label_values=vals[:12])
-    ref, _, _ = oracle.label_propagation(W, label_ids=ids[:12], label_values=vals[:12], reg_lambda=1.0, reg_values=prior,
-                                         start_value=prior, max_iter=300)
-    assert np.array_equal(lp.fetch(), ref) and a.shape == ref.shape
+    check(lp, ids[:10], vals[:10], prior, False)
+    check(lp, ids[:12], vals[:12], prior, False)
+    assert lp.last_mode == 0
+    monkeypatch.delenv("SSW_LP_NO_INCREMENTAL")
+    check(lp, ids[:14], vals[:14], prior, False)           # (no transposed pattern was built under the switch ...)
+    lp.set_prior(prior)                                    # ... the next session's set_prior builds it
+    check(lp, ids[:15], vals[:15], prior, False)
+    check(lp, ids[:16], vals[:16], prior, True)
     lp.close()
-    del _lib
+
+
+@pytest.mark.parametrize("weight_hi,no_inc", [(0.02, False), (1.5, False), (0.02, True)])
+def test_label_list_growth_past_its_capacity_keeps_the_installed_labels(oracle, monkeypatch, weight_hi, no_inc):
+    """the device-side label list starts with room for 1024 entries; growing it used to free the
+    installed list before the full path cleared is_label[] by it (a clear over uninitialised ids: an out-of-bounds
+    write, or stale clamps).  Labels go 1000 -> 1100 -> 2100 (two growths) with some removed on the way, on a graph
+    whose propagation converges in 2-3 sweeps (incremental path), on one that needs >= 8 sweeps (full tracked path
+    every call) and with the incremental path switched off: the oracle's bits every call."""
+    from seesaw_amd.label_propagation import LabelPropagation
+    if no_inc:
+        monkeypatch.setenv("SSW_LP_NO_INCREMENTAL", "1")
+    rng = np.random.default_rng(77)
+    n = 30000
+    W = _session_graph(rng, n, 5, weight_hi)
+    prior = rng.uniform(0.05, 0.95, n)
+    pool = rng.permutation(n).astype(np.int64)
+    vals_all = rng.integers(0, 2, n).astype(np.float64)
+    lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300)
+    lp.set_prior(prior)
+    sweeps_seen = []
+    for step, (lo, hi) in enumerate([(0, 1000), (0, 1020), (0, 1100), (40, 1100), (40, 2100), (1500, 2100), (1500, 2105)]):
+        ids = np.sort(pool[lo:hi])
+        vals = vals_all[ids]
+        ref, sweeps, conv = oracle.label_propagation(W, label_ids=ids, label_values=vals, reg_lambda=1.0, reg_values=prior,
+                                                     start_value=prior, max_iter=300)
+        lp.fit_resident(label_ids=ids, label_values=vals)
+        sweeps_seen.append(sweeps)
+        assert lp.last_sweeps == sweeps and lp.last_converged == conv, (step, lp.last_sweeps, sweeps)
+        assert np.array_equal(lp.fetch(), ref), (step, lp.last_mode)
+        if no_inc:
+            assert lp.last_mode == 0
+    if weight_hi >= 1.0:
+        assert min(sweeps_seen) >= 8, sweeps_seen          # more sweeps than are kept: the full tracked path every call
+    # and the handle still serves the other entry points (the untracked run clears by the same list)
+    ids = np.sort(pool[5000:5010])
+    ref, sweeps, _ = oracle.label_propagation(W, label_ids=ids, label_values=vals_all[ids], reg_lambda=1.0, reg_values=prior,
+                                              start_value=prior, max_iter=300)
+    out = lp.fit_transform(label_ids=ids, label_values=vals_all[ids], reg_values=prior, start_value=prior)
+    assert np.array_equal(out, ref)
+    lp.close()
+
+
+@pytest.mark.parametrize("max_iter", [1, 2, 3, 4])
+def test_resident_runs_with_a_small_sweep_budget(oracle, max_iter):
+    """with max_iter no larger than the kept levels an incremental pass that does not converge has
+    nothing left to sweep; the call must still report max_iter sweeps, not converged, and return iterate max_iter as
+    the reference does.  Whatever path each call takes, values / sweep counts / convergence are the oracle's."""
+    from seesaw_amd.label_propagation import LabelPropagation
+    rng = np.random.default_rng(100 + max_iter)
+    n = 8000
+    kinds = []
+    for weight_hi in (0.02, 0.08):
+        W = _session_graph(rng, n, 5, weight_hi)
+        prior = rng.uniform(0.05, 0.95, n)
+        lp = LabelPropagation(W, reg_lambda=1.0, max_iter=max_iter)
+        lp.set_prior(prior)
+        labels = {}
+        for rnd in range(8):
+            for v in rng.choice(n, size=int(rng.integers(1, 30)), replace=False):
+                labels[int(v)] = float(rng.integers(0, 2))
+            ids = np.array(sorted(labels), dtype=np.int64)
+            vals = np.array([labels[int(i)] for i in ids], dtype=np.float64)
+            ref, sweeps, conv = oracle.label_propagation(W, label_ids=ids, label_values=vals, reg_lambda=1.0, reg_values=prior,
+                                                         start_value=prior, max_iter=max_iter)
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                lp.fit_resident(label_ids=ids, label_values=vals)
+            kinds.append(lp.last_mode)
+            assert (lp.last_sweeps, lp.last_converged) == (sweeps, conv), (rnd, lp.last_mode, lp.last_sweeps, sweeps, conv)
+            assert np.array_equal(lp.fetch(), ref), (rnd, lp.last_mode)
+        lp.close()
+    print(f"max_iter={max_iter}: run kinds {kinds}")
+
+
+@pytest.mark.parametrize("n_images,tiles,weight_hi,ordered", [(900, 5, 0.03, False), (9000, 9, 0.03, False), (9000, 9, 0.25, False),
+                                                              (8000, 10, 0.04, True)])
+def test_fused_round_equals_the_three_calls(oracle, n_images, tiles, weight_hi, ordered):
+    """Round 6: ssw_labelprop_round = run_resident (or prior_as_result) + scores_to_index + topk(q = NULL) in one call
+    and -- when the propagation is an incremental update -- one host wait.  Over a session (rounds without a negative
+    label, the first full propagation, updates, a label removed, a big change that overflows the frontier) the images,
+    scores and best rows are those of the three calls on a second pair of handles, the propagated f64 scores are the CPU
+    oracle's bits, on the small index form (<= 65 536 rows: one selection launch) and the general one."""
+    from seesaw_amd.device_index import DeviceIndex
+    from seesaw_amd.label_propagation import LabelPropagation
+    rng = np.random.default_rng(n_images + tiles)
+    n = n_images * tiles
+    W = _session_graph(rng, n, 5, weight_hi)
+    prior = rng.uniform(0.05, 0.95, n)
+    X = rng.standard_normal((n, 256)).astype(np.float32)
+    row2image = np.repeat(np.arange(n_images, dtype=np.int32), tiles)
+    order = rng.permutation(n).astype(np.int32) if ordered else None
+    pairs = []
+    for _ in range(2):
+        idx = DeviceIndex.from_numpy(X, row2image=row2image)
+        lp = LabelPropagation(W, reg_lambda=1.0, max_iter=300, node_order=order)
+        lp.set_prior(prior)
+        pairs.append((idx, lp))
+    (idx_a, lp_a), (idx_b, lp_b) = pairs
+    labels, excluded = {}, []
+    kinds = []
+    k = 50
+    for rnd in range(10):
+        if rnd == 6 and labels:
+            labels.pop(sorted(labels)[1])
+        elif rnd == 8:
+            for v in rng.choice(n, size=n // 6, replace=False):      # a change that reaches more than n / 8 rows
+                labels[int(v)] = float(rng.integers(0, 2))
+        else:
+            for v in rng.choice(n, size=int(rng.integers(1, 14)), replace=False):
+                labels[int(v)] = 1.0 if rnd < 2 else float(rng.integers(0, 2))   # no negative label in the first two rounds
+        excluded = sorted(set(excluded) | set(int(v) for v in rng.choice(n_images, size=3, replace=False)))
+        ids = np.array(sorted(labels), dtype=np.int64)
+        vals = np.array([labels[int(i)] for i in ids], dtype=np.float64)
+        propagate = bool((vals == 0).any())
+        ex = np.asarray(excluded, dtype=np.int64)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            got = lp_a.round(idx_a, propagate=propagate, label_ids=ids, label_values=vals, mask_labeled=True, excluded=ex, k=k)
+            lp_a._read_run_info()
+            kinds.append((lp_a.last_mode, lp_a.last_host_syncs))
+            if propagate:
+                lp_b.fit_resident(label_ids=ids, label_values=vals)
+            else:
+                lp_b.prior_as_result(ids)
+            lp_b.scores_to_index(idx_b, mask_labeled=True)
+            want = idx_b.topk(None, k, excluded=ex)
+        for g, w, what in zip(got, want, ("images", "scores", "rows")):
+            assert np.array_equal(g, w), (rnd, what, kinds[-1])
+        if propagate:
+            ref, sweeps, conv = oracle.label_propagation(W, label_ids=ids, label_values=vals, reg_lambda=1.0, reg_values=prior,
+                                                         start_value=prior, max_iter=300)
+            assert (lp_a.last_sweeps, lp_a.last_converged) == (sweeps, conv)
+            assert np.array_equal(lp_a.fetch(), ref), (rnd, kinds[-1])
+            # the selection is the reference's: unlabelled vectors, best tile per image, excluded images out, (score desc, image asc)
+            s32 = ref.astype(np.float32)
+            s32[ids] = -np.inf
+            per_image = s32.reshape(n_images, tiles).max(1)
+            per_image[ex] = -np.inf
+            top = np.lexsort((np.arange(n_images), -per_image.astype(np.float64)))[:k]
+            top = top[np.isfinite(per_image[top])]
+            assert np.array_equal(got[0], top), rnd
+        else:
+            assert np.array_equal(lp_a.fetch(), prior)
+    modes = [m for m, _ in kinds]
+    assert modes[0] == 3 and modes[1] == 3                      # the prior served as the result
+    assert 0 in modes                                            # a first full propagation
+    if weight_hi <= 0.05:
+        assert modes.count(1) >= 3, kinds                        # updates ...
+        assert all(s == 1 for m, s in kinds if m == 1), kinds    # ... with ONE host wait each
+    print(f"n={n} w<={weight_hi} ordered={ordered}: (run kind, host waits) per round {kinds}")
+    for idx, lp in pairs:
+        lp.close()
+        idx.close()

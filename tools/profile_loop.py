@@ -48,5 +48,6 @@ for rep in range(2):
         g = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
         pr.disable()
 print("mean latency ms", 1e3 * np.mean(g["latencies"]))
+print("per-round ms", [round(1e3 * v, 3) for v in g["latencies"]])
 st = pstats.Stats(pr)
 st.sort_stats(os.environ.get("SSW_PROFILE_SORT", "cumulative")).print_stats(35)
