@@ -76,3 +76,50 @@ def test_full_size_session_equals_the_cpu_oracle(full, name):
     assert g["nfound"] == c["nfound"]
     print(f"C5 full size, {name}: {rounds} rounds identical; HIP {1e3 * float(np.mean(g['latencies'])):.2f} ms / round, "
           f"CPU oracle {1e3 * float(np.mean(c['latencies'])):.0f} ms / round")
+
+
+def test_graph_loop_rounds_are_fused_incremental_updates(full, monkeypatch):
+    """at the benchmark's size a knn_prop2 session must actually TAKE the fast path -- of its 29
+    propagating rounds at least 27 are incremental updates, each of them one C-ABI call (ssw_labelprop_round) with one host
+    wait -- and the session it shows is the one the three-call path (SSW_NO_FUSED_ROUND=1) shows."""
+    import torch
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
+    from seesaw_amd.bitmap import BitMap
+    from seesaw_amd.label_propagation import LabelPropagation
+    from seesaw_amd.seesaw_bench import benchmark_loop
+    from seesaw_amd.seesaw_session import make_session
+    gdm, ds = full
+    boxes, _ = ds.load_ground_truth()
+    p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale"), interactive="knn_prop2", interactive_options=OPTIONS["knn_prop2"],
+                      batch_size=1, shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                      start_policy="after_first_batch", index_options={"use_vec_index": False})
+    b = BenchParams(name="knn_prop2", ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
+    kinds = []
+    for entry in ("round", "fit_resident"):
+        orig = getattr(LabelPropagation, entry)
+
+        def recorded(self, *a, _orig=orig, _entry=entry, **k):
+            out = _orig(self, *a, **k)
+            self._read_run_info()
+            kinds.append((_entry, self.last_mode, self.last_host_syncs))
+            return out
+        monkeypatch.setattr(LabelPropagation, entry, recorded)
+    shown = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("SSW_NO_FUSED_ROUND", "1")
+        kinds.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            ret = make_session(gdm, p, b=b)
+            np.random.seed(0)
+            torch.manual_seed(0)
+            benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+        shown[fused] = [int(v) for a in ret["session"].acc_indices for v in np.asarray(a).reshape(-1)]
+        if fused:
+            assert len(kinds) == 29 and all(e == "round" for e, _, _ in kinds), kinds
+            propagating = [(m, s) for _, m, s in kinds if m != 3]
+            assert sum(m == 1 for m, _ in propagating) >= len(propagating) - 2 >= 25, kinds
+            assert all(s == 1 for m, s in propagating if m == 1), kinds
+        else:
+            assert all(e == "fit_resident" for e, _, _ in kinds) and len(kinds) >= 27, kinds
+    assert shown[True] == shown[False] and len(shown[True]) == 30
