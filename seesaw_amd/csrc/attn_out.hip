@@ -24,6 +24,7 @@
 // Replaces, like the kernels it fuses, the attention + out_proj of transformers' CLIPEncoderLayer that the reference
 // calls through HGFaceWrapper.forward (seesaw/models/model.py:50-57).
 #include "ssw_common.h"
+#include <algorithm>
 #include <cstdlib>
 #ifndef SSW_AO_NT
 #define SSW_AO_NT 1  // non-temporal: bit 0 the qkv loads (each byte is read once), bit 1 the residual loads, bit 2 the row stores.
@@ -88,17 +89,37 @@ template <bool BF, int PD, bool STAMP = false>
 __global__ __launch_bounds__(512) void attn_outproj_image(const bf16 *__restrict__ qkv, const bf16 *__restrict__ Wo,
                                                           const float *__restrict__ bo, bf16 *__restrict__ xcopy,
                                                           const float *__restrict__ res_in, float *__restrict__ res_out,
-                                                          float *__restrict__ stats_out, int S, float scale) {
+                                                          float *__restrict__ stats_out, int S, float scale, int B, int aff_tiles) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     auto g_off = [](int row, int c16) { return row * 64 + ((c16 ^ ((row >> 1) & 7)) << 3); };
     auto v_off = [](int key, int c32) { return key * 64 + ((c32 ^ (((key >> 1) & 1) | (((key >> 3) & 1) << 1))) << 4); };
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (aff_tiles > 0) {
+        // round 6 experiment: workgroup ids b and b + 8 share an XCD, and XCD x produced row tiles [x per, (x + 1) per) of
+        // the qkv rows (GemmLn::xcd_contig): it takes the images whose middle row lies there
+        const int xcd = b & 7, idx = b >> 3, per = (aff_tiles + 7) >> 3;
+        const int lo = xcd * per * 128, hi = min((xcd + 1) * per, aff_tiles) * 128;  // rows [lo, hi)
+        const int half = S >> 1;
+        const int i0 = lo <= half ? 0 : (lo - half + S - 1) / S;
+        int i1 = (hi - 1 - half) / S;
+        if (xcd == 7 || hi >= B * S) i1 = B - 1;
+        b = i0 + idx;
+        if (hi <= lo || b > i1 || b >= B) return;
+    }
     const int64_t row_base = (int64_t)b * S;
     const int n0 = wave * (AO_NJ * 16);
     AO_STAMP(0)
+#ifdef SSW_DEBUG_HOOKS
+    if (STAMP && t == 0 && blockIdx.x < 1024) {  // which XCD this workgroup runs on, and which image it took
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_ao_stamps[blockIdx.x * 32 + 21] = xcc & 0xf;
+        g_ao_stamps[blockIdx.x * 32 + 22] = (unsigned long long)b + 1;
+    }
+#endif
 
     // ---- Wo fragments of the first PD K-steps (64 deep), in flight under phase 1.  Wo arrives PACKED (pack_wo below):
     // the 1 KB a wave-instruction loads for one fragment is contiguous in lane order -- 8 whole 128-byte lines.  Straight
@@ -410,7 +431,31 @@ __global__ void k_pack_wo(const bf16 *__restrict__ Wo, bf16 *__restrict__ out) {
 
 template <bool BF, int PD>
 ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float *bo, bf16 *xcopy, const float *res_in,
-                     float *res_out, float *stats_out, int B, int S, float scale) {
+                     float *res_out, float *stats_out, int B, int S, float scale, int aff_tiles) {
+    int grid = B;
+    if (aff_tiles > 0) {  // 8 x the largest number of images an XCD takes (the kernel's own rule, restated)
+        const int per = (aff_tiles + 7) >> 3, half = S >> 1;
+        int most = 0, prev_i1 = -1;
+        for (int xcd = 0; xcd < 8; ++xcd) {
+            const int lo = xcd * per * 128, hi = std::min((xcd + 1) * per, aff_tiles) * 128;
+            if (hi <= lo) continue;
+            const int i0 = lo <= half ? 0 : (lo - half + S - 1) / S;
+            int i1 = (hi - 1 - half) / S;
+            if (xcd == 7 || hi >= B * S) i1 = B - 1;
+            i1 = std::min(i1, B - 1);
+            if (i0 != prev_i1 + 1 && i0 <= i1) {
+                set_error("attn_outproj: affinity map leaves a gap at image %d", i0);
+                return SSW_ERR_INVALID;
+            }
+            if (i1 >= i0) prev_i1 = i1;
+            most = std::max(most, i1 - i0 + 1);
+        }
+        if (prev_i1 != B - 1) {
+            set_error("attn_outproj: affinity map ends at image %d of %d", prev_i1, B);
+            return SSW_ERR_INVALID;
+        }
+        grid = 8 * most;
+    }
     static bool attr_set[64] = {false};
     int dev = 0;
     SSW_HIP_TRY(hipGetDevice(&dev));
@@ -424,14 +469,14 @@ ssw_status launch_ao(hipStream_t s, const bf16 *qkv, const bf16 *Wo, const float
     if (stamps) {
         SSW_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_outproj_image<BF, PD, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, AO_LDS));
-        hipLaunchKernelGGL((attn_outproj_image<BF, PD, true>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in,
-                           res_out, stats_out, S, scale);
+        hipLaunchKernelGGL((attn_outproj_image<BF, PD, true>), dim3(grid), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in,
+                           res_out, stats_out, S, scale, B, aff_tiles);
         SSW_HIP_TRY(hipGetLastError());
         return SSW_OK;
     }
 #endif
-    hipLaunchKernelGGL((attn_outproj_image<BF, PD>), dim3(B), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in, res_out,
-                       stats_out, S, scale);
+    hipLaunchKernelGGL((attn_outproj_image<BF, PD>), dim3(grid), dim3(512), AO_LDS, s, qkv, Wo, bo, xcopy, res_in, res_out,
+                       stats_out, S, scale, B, aff_tiles);
     SSW_HIP_TRY(hipGetLastError());
     return SSW_OK;
 }
@@ -456,7 +501,7 @@ bool attn_outproj_supports(int S, int D, int H) { return D == AO_D && H == AO_H 
 // stats_out [B*S][2][2]: partial (sum, sum of squares) of the new row's columns [0, 384) and [384, 768).
 ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, const float *bo, void *xcopy,
                                const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
-                               float scale) {
+                               float scale, int affinity_row_tiles) {
     if (!attn_outproj_supports(S, D, H) || B < 1) {
         set_error("attn_outproj: S=%d D=%d H=%d unsupported (ViT-B/32: S <= 64, D = 768, H = 12)", S, D, H);
         return SSW_ERR_UNSUPPORTED;
@@ -466,8 +511,8 @@ ssw_status launch_attn_outproj(hipStream_t s, const void *qkv, const void *Wo, c
     const bool bf = res_in == nullptr;
     // (two K-steps of fragments ahead spill at the 256 registers of an eight-wave workgroup, and one is enough:
                     //  the product waits for the L1's fill rate, not for latency -- 27 k cycles either way)
-    return bf ? launch_ao<true, 1>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale)
-              : launch_ao<false, 1>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale);
+    return bf ? launch_ao<true, 1>(s, q, w, bo, x, nullptr, nullptr, stats_out, B, S, scale, affinity_row_tiles)
+              : launch_ao<false, 1>(s, q, w, bo, x, res_in, res_out, stats_out, B, S, scale, affinity_row_tiles);
 }
 
 }  // namespace ssw

@@ -1463,6 +1463,11 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
     c->pooled_compact = false;
     const int np = D / 128;
     float *st_h = c->stats_a, *st_h2 = c->stats_b;
+    // Round 6 experiment (SSW_XCD_AFFINITY=1, A/B only): the QKV product deals CONTIGUOUS runs of row tiles to the XCDs and the
+    // fused attention launch puts an image's workgroup on the XCD that produced its qkv rows (what it measured)
+    static const bool xcd_affinity_env = getenv("SSW_XCD_AFFINITY") != nullptr;
+    const bool xcd_affinity = xcd_affinity_env && !causal && !unfused_ln && D % 256 == 0 && (c->flags & 8) == 0 &&
+                              attn_outproj_supports(S, D, tw.H);
     for (int l = 0; l < tw.L && !skinny; ++l) {
         const Layer &ly = tw.layers[l];
         GemmLn cons, prod;
@@ -1477,7 +1482,9 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
         } else {
             cons.stats_in = st_h;
             cons.c1 = ly.c1qkv;
+            cons.xcd_contig = xcd_affinity ? 1 : 0;
             SSW_TRY(launch_gemm_bf16_ln(EPI_BF16_LN, s, c->xn, ly.wqkv_ln, ly.c2qkv, nullptr, c->qkv, R, 3 * D, D, cons));
+            cons.xcd_contig = 0;
         }
         const int n_heads = B * tw.H;
         const float att_scale = 1.0f / sqrtf((float)(D / tw.H));
@@ -1524,7 +1531,7 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             }
             if (bf16_stream) c->stream_in_xn = true;
             SSW_TRY(launch_attn_outproj(s, c->qkv, ly.wo_pk, ly.bo, c->xn, bf16_stream ? nullptr : h, h2, st_h2, B, S, D, tw.H,
-                                        att_scale));
+                                        att_scale, xcd_affinity ? (R + 127) / 128 : 0));
             cons.stats_in = st_h2;
             // round 4's form (SSW_CLIP_POOLED_MLP_ONLY=1): attention and out-projection for every row, then the rows are
             // compacted (residual row, bf16 copy, statistics), fc1 runs on them as it is, fc2 -- 12 tiles with 48 K-steps

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(TM * WN) void gemm_glds(const bf16 *__restrict__ A,
     // XCD-aware tile order: ids b and b + 8 share an XCD; XCD x takes row-tiles x, x + 8, ...
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
-    const int mt = (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
+    const int per_xcd = (m_tiles + 7) >> 3;
+    const int mt = ln.xcd_contig ? xcd * per_xcd + idx / n_tiles : (idx / n_tiles) * 8 + xcd, nt = idx % n_tiles;
     if (mt >= m_tiles) return;
     const int m0 = mt * TM, n0 = nt * BN;
     const int wm = wave / WN, wn = wave % WN;
@@ -1146,6 +1147,7 @@ ssw_status launch_auto(hipStream_t s, const bf16 *A, const bf16 *W, const float 
                        int N, int K, const GemmLn &ln) {
     // variants 16 / 17 (lab build): 256 x 128 tiles, 8 waves of 64 x 64 (16 fragment reads per 32 MFMAs where the 64 x 32
     // waves of the 128-square kernel read 12 per 16), one workgroup per CU, three- / two-stage ring
+    if (ln.xcd_contig) return launch_glds<EPI, 2, 128, false, 4>(s, A, W, bias, res, C, M, N, K, ln);  // (the consumer counts on 128-row tiles)
     if (g_gemm_variant == 16) return launch_glds<EPI, 3, 256, false, 2>(s, A, W, bias, res, C, M, N, K, ln);
     if (g_gemm_variant == 17) return launch_glds<EPI, 2, 256, false, 2>(s, A, W, bias, res, C, M, N, K, ln);
     if constexpr (epi_bf16_out(EPI)) {  // (f32 outputs leave through LDS in the 128 x 128 kernel only)

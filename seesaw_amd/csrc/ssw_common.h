@@ -162,6 +162,8 @@ struct GemmLn {
     float *stats_out = nullptr;       // producer: [M][N / 128][2]
     int64_t res_ld = 0;               // producer (f32 rows): elements between consecutive residual rows, 0 = N (round 5: the
                                       // pooled last layer adds row b S of the stack to row b of the product)
+    int xcd_contig = 0;               // 128 x 128 kernel: XCD x takes a CONTIGUOUS run of row tiles instead of x, x + 8, ...
+                                      // (round 6 experiment: the rows of an image then sit in one XCD's L2 for the attention launch)
 };
 ssw_status launch_gemm_bf16_ln(int epi, hipStream_t stream, const void *A, const void *W, const float *bias,
                                const float *residual, void *C, int M, int N, int K, const GemmLn &ln);
@@ -179,9 +181,11 @@ ssw_status launch_gemm_splitk_partials(hipStream_t stream, const void *A, const 
 // attn_out.hip: attention + out-projection (+ residual, + LayerNorm partial sums) of a ViT-B/32 layer, a workgroup per image
 bool attn_outproj_supports(int S, int D, int H);
 ssw_status pack_attn_outproj_weight(hipStream_t stream, const void *Wo_768x768, void *out_same_size);
+// affinity_row_tiles > 0 (round 6 experiment): the qkv rows were produced by the 128-row tile kernel with
+// GemmLn::xcd_contig over that many row tiles; the workgroup of image i is then launched on the XCD that produced its rows
 ssw_status launch_attn_outproj(hipStream_t stream, const void *qkv, const void *Wo, const float *bo, void *xcopy,
                                const float *res_in, float *res_out, float *stats_out, int B, int S, int D, int H,
-                               float scale);
+                               float scale, int affinity_row_tiles = 0);
 #ifdef SSW_DEBUG_HOOKS
 ssw_status read_ao_stamps(uint64_t *out, int n_words);
 int gemm_variant();

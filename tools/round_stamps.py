@@ -78,11 +78,25 @@ def round_with_info(self, *a, **k):
     return out
 
 
+from seesaw_amd.feedback import FeedbackEngine
+_fit = FeedbackEngine.fit
+
+
+def fit_with_info(self, *a, **k):
+    t0 = time.perf_counter()
+    w, info = _fit(self, *a, **k)
+    dt = time.perf_counter() - t0
+    events.append((time.perf_counter(), 0.0, f"   fit info: rows {self.n}, evals {info['func_evals']}, iterations {info['n_iter']}, "
+                                             f"{1e6 * dt / max(1, info['func_evals']):.1f} us per evaluation, on device {info['on_device']}"))
+    return w, info
+
+
 for rep in range(3):
     ret = make_session(gdm, p, b=b)
     sess = ret["session"]
     if rep == 2:
         LabelPropagation.collect_run_info = True
+        FeedbackEngine.fit = fit_with_info
         LabelPropagation.round = round_with_info
         _lib.call = traced_call
         for mod in list(sys.modules.values()):  # modules that bound `call` by name
