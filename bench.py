@@ -789,6 +789,8 @@ def compact_line(full: dict) -> str:
                                               "kind": c.get("kind"), "sample": c.get("sample_short") or str(c.get("sample"))[:120],
                                               "blas_threads": c.get("blas_threads"),
                                               "argpartition_value": _num(_get(c, "argpartition_variant", "value"), 6)}
+    t1 = full.get("top1") or {}
+    out["top1"] = {"image": t1.get("image"), "score": t1.get("score")}  # the last query's best image: the N = 1 / N > 1 sanity anchor
     a = full.get("allgather_us")
     out["allgather_us"] = None if not a else {k: _num(a.get(k)) for k in ("mean", "median", "max", "steps", "bytes_per_rank")}
     ex = full.get("extras") or {}
