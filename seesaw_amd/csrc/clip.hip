@@ -1596,7 +1596,11 @@ ssw_status run_tower(ssw_clip *c, const Tower &tw, int B, int S, int causal) {
             static const bool no_splitk = getenv("SSW_CLIP_NO_SPLITK") != nullptr;  // A/B
             const int cus = num_cus(c->device);
             const int sp_o = 1;  // (the out-projection's 8 steps split 4 ways: 9.2 + 5.3 us for the two launches against 8.5)
-            const int sp_2 = (causal && !no_splitk && R <= SPLITK_MAX_ROWS) ? splitk_choice(R, D, M, cus) : 1;
+            // (round 6, ADVICE r5: the split is a function of the product's shape alone -- 8 ways whenever fc2's K allows --
+            //  not of the row count or the CU count: a query's vector then does not depend on the device or, up to
+            //  SPLITK_MAX_ROWS rows, on what shares its call; splitk_choice would have said 8 at every size that matters)
+            (void)cus;
+            const int sp_2 = (causal && !no_splitk && R <= SPLITK_MAX_ROWS && M % (8 * 128) == 0) ? 8 : 1;
             prod.stats_out = st_h2;
             if (sp_o > 1) SSW_TRY(launch_gemm_splitk_stats(s, c->att, ly.wo, ly.bo, h, h2, c->splitk, R, D, D, sp_o, prod));
             else SSW_TRY(launch_gemm_bf16_ln(EPI_F32_BIAS_RESIDUAL_STATS, s, c->att, ly.wo, ly.bo, h, h2, R, D, D, prod));

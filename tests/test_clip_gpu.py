@@ -169,6 +169,23 @@ def test_single_query_text_path_vs_hf(models, B, L):
     assert np.abs(_unit(got) - _unit(tiled)).max() <= 1e-3
 
 
+def test_a_texts_vector_does_not_depend_on_the_texts_that_share_its_call(models):
+    """the text tower's fc2 is split over K; the split count used to come from the row count and the CU count,
+    so a query's vector depended (1e-7) on its batch.  The split is now a function of the product's shape alone: the same
+    sequences embedded 2, 8, 16 and 24 to a call (all on the tile kernels) give the same bytes.  What remains, stated and
+    bounded: the final LayerNorm + projection of at most 32 pooled rows is the skinny kernel, of more rows the tile GEMM
+    (f32 sums in another order): 48 sequences a call differ from the same sequences 24 a call by <= 5e-6 on the
+    unnormalised features (measured 1.4e-6)."""
+    _, ours = models
+    rng = np.random.default_rng(11)
+    ids = rng.integers(0, 49405, size=(48, 77)).astype(np.int32)
+    ids[:, 0] = 49406
+    ids[:, -1] = 49407
+    per_call = {n: np.concatenate([ours.embed_text(ids[a:a + n], normalize=False) for a in range(0, 48, n)]) for n in (2, 8, 16, 24, 48)}
+    assert per_call[2].tobytes() == per_call[8].tobytes() == per_call[16].tobytes() == per_call[24].tobytes()
+    assert np.abs(per_call[48] - per_call[24]).max() <= 5e-6
+
+
 def test_text_pooling_legacy_eos_token_id_2():
     """The published openai/clip-vit-* configs still say text_config.eos_token_id = 2; transformers then pools
     at argmax(input_ids) (modeling_clip.py, CLIPTextTransformer.forward).  A tokenised string never contains
@@ -293,7 +310,7 @@ def test_last_layer_on_the_pooled_rows_only_gives_the_full_forward_vectors(model
     instead of two halves, fc2's K is split over workgroups, fc1 on 200 rows takes the 128-square kernel where 10 000 rows
     take the 256-square one), and now and then a bf16 hidden value that rounds the other way.  Measured on unit vectors:
     1.1e-5 with the MLP alone (round 4), 2e-5 ... 5.0e-5 with the whole layer, over the collections of round 5; held to
-    1e-4 -- a quarter of the tower's 4e-4 against HF, whose bar (5e-3, cos 0.999) the default form meets on its own in
+    7e-5 (round 6, ADVICE r5: the measured worst case plus a margin, not twice it) -- a sixth of the tower's 4e-4 against HF, whose bar (5e-3, cos 0.999) the default form meets on its own in
     every other test of this file -- for a handful of tiles, 200 and a call that crosses the device chunk"""
     _, ours = models
     rng = np.random.default_rng(123)
@@ -304,7 +321,7 @@ def test_last_layer_on_the_pooled_rows_only_gives_the_full_forward_vectors(model
             pooled = ours.embed_tiles_u8(tiles, normalize=True)
             ours.set_option(ours.OPT_FULL_LAST_LAYER, True)
             full = ours.embed_tiles_u8(tiles, normalize=True)
-            assert np.isfinite(pooled).all() and np.abs(pooled - full).max() <= 1e-4, (n, float(np.abs(pooled - full).max()))
+            assert np.isfinite(pooled).all() and np.abs(pooled - full).max() <= 7e-5, (n, float(np.abs(pooled - full).max()))
     finally:
         ours.set_option(ours.OPT_FULL_LAST_LAYER, False)
 
