@@ -23,6 +23,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/text16_trace" -o t
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/knn_trace" -o knn -- \
     python3 tools/perf_knn.py 1560000 > "$OUT/knn_trace.log" 2>&1
 
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/loop_trace" -o loop -- \
+    python3 tools/profile_loop.py knn_prop2 120000 > "$OUT/loop_trace.log" 2>&1
+python3 tools/round_trace.py "$OUT/loop_trace" > "$OUT/knn_prop2_round_timeline.txt" 2>&1 || true
+
 # tower GEMM shapes against hipBLASLt (lab build: ssw_debug_gemm), and the fused attention launch's in-kernel phase stamps
 python3 tools/perf_gemm.py 15 14 --lib > "$OUT/gemm_ab.txt" 2> "$OUT/gemm_ab.err" || true
 ( echo "# f32 rows (default)"; SSW_AO_STAMPS=1 python3 tools/attn_out_stamps.py; echo "# bf16 rows"; SSW_AO_STAMPS=1 SSW_CLIP_BF16_STREAM=1 python3 tools/attn_out_stamps.py ) 2>/dev/null | grep -v amdgpu > "$OUT/attn_out_stamps.txt" || true
@@ -33,7 +37,10 @@ python3 tools/summarise_pmc.py "$OUT/bench_write" scan_scores > "$OUT/write_summ
 ( echo "# mean per launch of scan_scores_kernel, rocprofv3 --pmc (two passes), bench.py --steps 3 --warmup 1"; cat "$OUT/fetch_summary.csv"; grep WRITE_SIZE "$OUT/write_summary.csv" ) > "profiles/${R}_bench_100M_pmc_fetch_write.csv"
 python3 tools/summarise_pmc.py "$OUT/clip_pmc" "" > "profiles/${R}_clip_b200_pmc_summary.csv"
 mkdir -p gpurun_out/traffic && cp profiles/traffic.json gpurun_out/traffic/traffic.json   # profiles/ is not merged back: copy out
-cp "$OUT/bench.json" "profiles/${R}_bench_100M_output.json"
+cp "$OUT/bench.json" "profiles/${R}_bench_100M_output.json"          # the ONE stdout line
+cp bench_detail.json "profiles/${R}_bench_100M_detail.json"           # everything the line leaves out
+cp "$OUT/loop_trace/loop_kernel_stats.csv" "profiles/${R}_knn_prop2_session_1560k_kernel_stats.csv"
+cp "$OUT/knn_prop2_round_timeline.txt" "profiles/${R}_knn_prop2_round_timeline.txt"
 cp "$OUT/bench_trace/bench_kernel_stats.csv" "profiles/${R}_bench_100M_kernel_stats.csv"
 cp "$OUT/clip_trace/clip_kernel_stats.csv" "profiles/${R}_clip_b200_kernel_stats.csv"
 cp "$OUT/knn_trace/knn_kernel_stats.csv" "profiles/${R}_knn_1560k_kernel_stats.csv"
