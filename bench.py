@@ -494,6 +494,33 @@ def clip_extras(device: int):
         del x2, o2
         bigger[B2] = {"ms_per_batch": dt2 * 1e3, "ms_per_batch_runs": runs2, "tiles_per_s": B2 / dt2, "tflops": B2 * GF_RUN / dt2 / 1e3,
                       "frac_of_bf16_dense_peak": B2 * GF_RUN / dt2 / 1e3 / 2500.0}
+    # the box's floor for a chain of dependent launches (state it next to the text figures, which are
+    # launch-bound: 6 launches a layer at 16 x 77, 4 for one short query): 200 one-element torch adds captured in a graph
+    # and replayed -- no host in the loop, nothing to compute, so the time per node is what a launch boundary costs here
+    floor_us = None
+    try:
+        z = torch.zeros(1, device=dev)
+        side = torch.cuda.Stream(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            z.add_(1.0)
+            torch.cuda.synchronize(dev)
+            g.capture_begin()
+            for _ in range(200):
+                z.add_(1.0)
+            g.capture_end()
+        torch.cuda.synchronize(dev)
+        g.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize(dev)
+        floor_us = (time.perf_counter() - t0) / 5 / 200 * 1e6
+        del g
+    except Exception as e:  # the figure is context, not a result
+        floor_us = None
+        sys.stderr.write(f"launch floor probe failed: {type(e).__name__}: {e}\n")
     ids = np.random.default_rng(0).integers(0, 49405, (16, 77)).astype(np.int32)
     ids[:, 0], ids[:, -1] = 49406, 49407
     dtt, runs_t = median_of(lambda: m.embed_text(ids))
@@ -541,6 +568,9 @@ def clip_extras(device: int):
             "text_batch": 16, "text_len": 77, "text_ms_per_batch_host_io": dtt * 1e3, "text_ms_per_batch_runs": runs_t,
             "texts_per_s": 16 / dtt, "text_tflops": 16 * 5.96 / dtt / 1e3, "text_frac_of_bf16_dense_peak": 16 * 5.96 / dtt / 1e3 / 2500.0,
             "single_query_8_tokens_ms_host_io": dt1 * 1e3, "single_query_8_tokens_ms_runs": runs_1,
+            "launch_floor_us": floor_us,
+            "launch_floor_note": "per node of a replayed graph of 200 dependent one-element kernels on this box; the text tower is "
+                                 "12 layers x 6 launches (16 x 77) / 12 x 4 (one short query) + 4",
             "weights": "transformers.CLIPModel(CLIPConfig()) random init, seed 1234", "dtype": "bf16 MFMA, f32 accumulate"}
 
 
@@ -816,6 +846,7 @@ def compact_line(full: dict) -> str:
     put("c3_text_16x77_ms", cl.get("text_ms_per_batch_host_io"))
     put("c3_text_frac", cl.get("text_frac_of_bf16_dense_peak"))
     put("c3_text_1x8_ms", cl.get("single_query_8_tokens_ms_host_io"))
+    put("c3_launch_floor_us", cl.get("launch_floor_us"), 3)
     put("c3_cpu_tiles_per_s", _get(cl, "cpu_baseline", "tiles_per_s"))
     put("c3_gpu_tiles_per_s", cl.get("tiles_per_s"))
     fl = ex.get("feedback_loop") or {}

@@ -829,13 +829,7 @@ ssw_status index_collect_topk(ssw_index *idx, hipStream_t on_stream, int32_t k, 
     return ssw_index_topk_fetch(idx, k, out_images, out_scores, out_best_rows, out_count);
 }
 
-// drop a selection that was enqueued but whose input turned out not to be ready (the caller enqueues it again)
-void index_abandon_topk(ssw_index *idx, hipStream_t on_stream) {
-    (void)hipStreamSynchronize(on_stream);
-    idx->small_pending_seq = 0;
-    idx->res_pending_seq = 0;
-    idx->ws.host_packed = nullptr;
-}
+int index_device(const ssw_index *idx) { return idx ? idx->device : -1; }
 }  // namespace ssw
 }  // extern "C++"
 

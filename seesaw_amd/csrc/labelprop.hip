@@ -1646,6 +1646,8 @@ ssw_status ssw_labelprop_round(ssw_lp *lp, ssw_index *index, int32_t propagate, 
     SSW_TRY(ssw_index_shape(index, &n, &D, &n_images));
     SSW_TRY(ssw_index_device_ptrs(index, &Xv, &scores));
     SSW_REQUIRE(n == lp->n, "the index has %lld rows, the graph %lld nodes", (long long)n, (long long)lp->n);
+    SSW_REQUIRE(index_device(index) == lp->device, "ssw_labelprop_round: the index lives on device %d, the graph on device %d",
+                index_device(index), lp->device);  // (one stream carries both halves of the round)
     for (int64_t i = 0; i < n_excluded; ++i)  // (checked before anything is enqueued)
         SSW_REQUIRE(excluded_images[i] >= 0 && excluded_images[i] < n_images, "excluded image %lld outside [0, %lld)",
                     (long long)excluded_images[i], (long long)n_images);

@@ -126,7 +126,7 @@ ssw_status index_enqueue_topk_resident(ssw_index *idx, hipStream_t on_stream, co
                                        int32_t k);
 ssw_status index_collect_topk(ssw_index *idx, hipStream_t on_stream, int32_t k, int64_t *out_images, float *out_scores,
                               int64_t *out_best_rows, int32_t *out_count);
-void index_abandon_topk(ssw_index *idx, hipStream_t on_stream);
+int index_device(const ssw_index *idx);
 
 // scan.hip: scores[i] = dot(X[i,:], q) in the fixed kernel order (see scan.hip).
 ssw_status launch_scan(const float *X, const float *q_dev, float *scores, int64_t n, int32_t dim,

@@ -50,4 +50,4 @@ for rep in range(2):
 print("mean latency ms", 1e3 * np.mean(g["latencies"]))
 print("per-round ms", [round(1e3 * v, 3) for v in g["latencies"]])
 st = pstats.Stats(pr)
-st.sort_stats(os.environ.get("SSW_PROFILE_SORT", "cumulative")).print_stats(35)
+st.sort_stats(os.environ.get("SSW_PROFILE_SORT", "cumulative")).print_stats(int(os.environ.get("SSW_PROFILE_ROWS", "35")))
