@@ -1301,6 +1301,11 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
                                db + o_ch, reinterpret_cast<const double *>(db + o_sv), (int)n_set, (int)n_unset, lp->prior, lp->f[0],
                                lp->is_label, lp->label_val, lp->stamp, ep, lp->mem, db + o_ids,
                                reinterpret_cast<const double *>(db + o_vals), (int)n_labels, lp->ids, lp->vals);
+            // from here on the device holds THESE labels: whatever happens below (an error return included), the kept
+            // state describes them or nothing -- it is valid again only where a branch says so
+            const int kept_levels = tk.levels;
+            tk.valid = false;
+            tk.ids = ids, tk.vals = vals;
             LpBmaxPtrs bm;
             for (int k = 0; k < ssw_lp::KEEP; ++k) bm.p[k] = lp->bmax[k];
             for (int k = 1; k <= tk.levels; ++k) {
@@ -1352,7 +1357,6 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
             LpState dst;
             memset(&dst, 0, sizeof(dst));
             dst.bound_violation = rctl.bound_violation;
-            tk.ids = ids, tk.vals = vals;  // the device now holds these labels whatever happens next
             if (rctl.overflow) {
                 // the change reaches more than n / 8 rows: rows beyond the list were not recomputed, so the kept iterates
                 // are no longer a run's -- start over with the full sweeps (from the labels just installed)
@@ -1369,6 +1373,7 @@ static ssw_status lp_run_tracked(ssw_lp *lp, const int64_t *label_ids, const dou
                     if (rctl.level_max[k] < eps) conv = k;
                 if (conv) {
                     st.sweeps = conv, st.done = 1, st.result_buf = conv - 1;
+                    tk.valid = true, tk.levels = kept_levels;
                     tk.sweeps = conv, tk.result = conv - 1;
                     lp->last_result = conv - 1;
                     lp->sweeps_hint = conv;

@@ -119,6 +119,7 @@ class KnnProp2(LoopBase):
 
     def set_text_vec(self, tvec):
         super().set_text_vec(tvec)
+        self._pending = None  # a shortlist selected under the previous query's prior is void
         self.state.knn_model.set_base_scores(self.q.index.score(tvec))
 
     def next_batch(self):
@@ -131,7 +132,8 @@ class KnnProp2(LoopBase):
             and getattr(p, "aug_weight", None) in (None, "level_max") and hasattr(q.index, "rescore_avg_from_device_scores")
         on_device = resident and (p.agg_method == "plain_score" or avg_on_device)
         pending, self._pending = getattr(self, "_pending", None), None
-        if on_device and pending is not None and pending[1] == len(q.returned) and pending[2] == p.shortlist_size:
+        if on_device and pending is not None and pending[1] == len(q.returned) and pending[2] == p.shortlist_size \
+                and pending[3] == getattr(model, "_labels_stamp", 0):
             cand = pending[0]  # refine() propagated AND selected in one device call (ssw_labelprop_round)
             scores = None
         elif on_device:  # propagated scores go from the graph handle to the index's score buffer on the GPU
@@ -164,6 +166,6 @@ class KnnProp2(LoopBase):
             # the update and the selection the next next_batch() will ask for, in ONE device call and one wait: nothing
             # next_batch's selection depends on (labels, returned images, shortlist size) changes in between
             cand = q.index.topk_after_update(model, idxs, labels, topk_dbidx=p.shortlist_size, exclude_dbidx=q.returned)
-            self._pending = (cand, len(q.returned), p.shortlist_size)
+            self._pending = (cand, len(q.returned), p.shortlist_size, getattr(model, "_labels_stamp", 0))
         else:
             model.update(idxs, labels)

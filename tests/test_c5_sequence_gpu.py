@@ -72,3 +72,53 @@ def test_c5_session_matches_reference(c5, name):
         assert out["nfound"] == int(g[f"{name}_nfound"])
     # the reference is seed-independent at this size for every loop but possibly the L-BFGS ones: hold a floor
     assert stable >= {"plain": 30, "knn_prop2": 30, "pseudo_lr": 30, "multi_reg": 19}[name], stable  # as recorded
+
+
+def test_a_new_text_query_voids_the_shortlist_refine_selected(c5, monkeypatch):
+    """Round 6: KnnProp2.refine propagates AND selects the next shortlist in one device call (ssw_labelprop_round); the
+    next next_batch() uses it -- unless something it depends on changed in between.  A session that refines, then gets a
+    NEW text query, then asks for the next batch must show what the three-call path (SSW_NO_FUSED_ROUND=1) shows, and so
+    must a session that asks for two batches in a row."""
+    from seesaw_amd.basic_types import BenchParams, IndexSpec, SessionParams
+    from seesaw_amd.seesaw_bench import fill_imdata
+    from seesaw_amd.seesaw_session import make_session
+    g, gdm, ds = c5
+    boxes, _ = ds.load_ground_truth()
+    boxes = boxes.assign(description="a " + boxes.category.astype(str))
+    box_c1 = boxes[boxes.category == "c1"]
+    p = SessionParams(index_spec=IndexSpec(d_name="lvis", i_name="multiscale", c_name=None), interactive="knn_prop2",
+                      interactive_options=OPTIONS["knn_prop2"], shortlist_size=50, agg_method="plain_score", aug_larger="greater",
+                      batch_size=1, start_policy="after_first_batch", index_options={"use_vec_index": False})
+    b = BenchParams(name="knn_prop2", ground_truth_category="c1", qstr="a c1", n_batches=30, max_results=10 ** 6)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("SSW_NO_FUSED_ROUND", raising=False)
+        else:
+            monkeypatch.setenv("SSW_NO_FUSED_ROUND", "1")
+        import contextlib
+        import io
+        shown = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = make_session(gdm, p, b=b)["session"]
+            s.set_text("a c1")
+
+            def one_round(refine=True):
+                shown.extend(int(v) for v in s.next())
+                batch = [fill_imdata(im, box_c1, b) for im in s.last_batch()]
+                s.update_last_batch(batch)
+                if refine:
+                    s.refine()
+            for _ in range(5):
+                one_round()
+            s.set_text("a c0")               # a new query between refine() and next()
+            for _ in range(3):
+                one_round()
+            one_round(refine=False)           # two batches in a row: the second finds no shortlist waiting
+            one_round()
+            one_round()
+        return shown
+
+    fused, plain = run(True), run(False)
+    assert len(fused) == 11 and len(set(fused)) == 11
+    assert fused == plain, (fused, plain)
