@@ -237,6 +237,8 @@ class MultiscaleIndex(AccessMethod):
 
     # ---- queries ----------------------------------------------------------------------
     def _excluded_positions(self, exclude_dbidx) -> np.ndarray:
+        if exclude_dbidx is not None and len(self.excluded) == 0 and hasattr(exclude_dbidx, "_v"):
+            return _positions_of(self._dbidx, exclude_dbidx._v)  # a BitMap's array is sorted and distinct already
         ids = [np.asarray(self.excluded, dtype=np.int64)]
         if exclude_dbidx is not None:
             ids.append(np.asarray(exclude_dbidx, dtype=np.int64))
@@ -398,55 +400,79 @@ class BoxFeedbackQuery(InteractiveQuery):
         return pd.DataFrame({"dbidx": idx._row_dbidx[rows], "ys": (miou > 0).astype("float"), "max_iou": miou},
                             index=pd.Index(rows))
 
-    def _matched_arrays(self, target_description=None):
-        """(tile rows of every seen image, their max IoU with the image's accepted boxes) as plain arrays"""
+    def _match_one(self, dbidx: int, target_description):
+        """(tile rows of image dbidx, their max IoU with the image's accepted boxes), or None for an image the index lacks"""
         idx = self.index
-        cache = self.__dict__.setdefault("_match_cache", {})
-        rows_all, iou_all = [], []
+        boxes = self.label_db.ldata[int(dbidx)] or []
+        if target_description is not None:
+            sel = [b for b in boxes if b.description == target_description]
+        else:
+            sel = [b for b in boxes if b.marked_accepted]
+        pos = int(np.searchsorted(idx._dbidx, dbidx))
+        if pos >= idx._dbidx.shape[0] or idx._dbidx[pos] != dbidx:
+            return None
+        rows = np.arange(idx._row_start[pos], idx._row_start[pos + 1])
+        miou = np.zeros(rows.shape[0])
+        if sel:
+            t = idx._box[rows].astype(np.float64)
+            g = np.array([[b.x1, b.y1, b.x2, b.y2] for b in sel], dtype=np.float32).astype(np.float64)
+            w = np.clip(np.minimum(t[:, None, 2], g[None, :, 2]) - np.maximum(t[:, None, 0], g[None, :, 0]), 0, None)
+            h = np.clip(np.minimum(t[:, None, 3], g[None, :, 3]) - np.maximum(t[:, None, 1], g[None, :, 1]), 0, None)
+            inter = w * h
+            union = ((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1]))[:, None] + \
+                    ((g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1]))[None, :] - inter
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = np.where(inter > 0, inter / union, 0.0)
+            miou = iou.max(axis=1)
+        return rows, miou
+
+    def _matched_arrays(self, target_description=None):
+        """(tile rows of every seen image, their max IoU with the image's accepted boxes) as plain READ-ONLY arrays, images in
+        ascending dbidx order (label_db.get_seen()).  The label store logs which images' labels changed (LabelDB.changes): a
+        call matches those and nothing else -- one image a round in a benchmark session, not every image seen so far -- and a
+        call with nothing new returns the arrays of the call before."""
+        import bisect
         ldb = self.label_db
-        stamps = getattr(ldb, "stamp", None)
-        for dbidx in sorted(ldb.ldata):  # == label_db.get_seen() (ascending dbidx)
-            # an image's entry is good for as long as its labels have not been put() again (LabelDB.stamp); a label
-            # store without stamps is keyed by the boxes themselves
-            fast = (dbidx, stamps[dbidx], target_description) if stamps is not None and dbidx in stamps else None
-            hit = cache.get(fast) if fast is not None else None
+        changes = getattr(ldb, "changes", None)
+        if changes is None or len(ldb.ldata) != len(getattr(ldb, "stamp", ())):
+            return self._matched_arrays_full(target_description)  # a label store without the change log
+        states = self.__dict__.setdefault("_match_state", {})
+        st = states.get(target_description)
+        if st is None:
+            st = states[target_description] = {"pos": 0, "entries": {}, "order": [], "cat": None}
+        if st["cat"] is not None and st["pos"] == len(changes):
+            return st["cat"]
+        entries, order = st["entries"], st["order"]
+        for dbidx in dict.fromkeys(changes[st["pos"]:]):  # (an image changed twice since is matched once)
+            hit = self._match_one(dbidx, target_description)
+            known = dbidx in entries
+            if hit is None:
+                if known:
+                    del entries[dbidx]
+                    order.remove(dbidx)
+                continue
+            entries[dbidx] = hit
+            if not known:
+                bisect.insort(order, dbidx)
+        st["pos"] = len(changes)
+        if order:
+            rows = np.concatenate([entries[d][0] for d in order])
+            miou = np.concatenate([entries[d][1] for d in order])
+        else:
+            rows, miou = np.zeros(0, dtype=np.int64), np.zeros(0)
+        rows.setflags(write=False)
+        miou.setflags(write=False)
+        st["cat"] = (rows, miou)
+        return st["cat"]
+
+    def _matched_arrays_full(self, target_description=None):
+        """_matched_arrays over every seen image (label stores without LabelDB.changes)"""
+        rows_all, iou_all = [], []
+        for dbidx in sorted(self.label_db.ldata):  # == label_db.get_seen() (ascending dbidx)
+            hit = self._match_one(dbidx, target_description)
             if hit is not None:
                 rows_all.append(hit[0])
                 iou_all.append(hit[1])
-                continue
-            boxes = ldb.ldata[int(dbidx)] or []
-            if target_description is not None:
-                sel = [b for b in boxes if b.description == target_description]
-            else:
-                sel = [b for b in boxes if b.marked_accepted]
-            key = fast if fast is not None else (int(dbidx), tuple((b.x1, b.y1, b.x2, b.y2) for b in sel))
-            hit = cache.get(key)
-            if hit is None:
-                pos = int(np.searchsorted(idx._dbidx, dbidx))
-                if pos >= idx._dbidx.shape[0] or idx._dbidx[pos] != dbidx:
-                    continue
-                rows = np.arange(idx._row_start[pos], idx._row_start[pos + 1])
-                miou = np.zeros(rows.shape[0])
-                if sel:
-                    t = idx._box[rows].astype(np.float64)
-                    g = np.array([[b.x1, b.y1, b.x2, b.y2] for b in sel], dtype=np.float32).astype(np.float64)
-                    w = np.clip(np.minimum(t[:, None, 2], g[None, :, 2]) - np.maximum(t[:, None, 0], g[None, :, 0]), 0, None)
-                    h = np.clip(np.minimum(t[:, None, 3], g[None, :, 3]) - np.maximum(t[:, None, 1], g[None, :, 1]), 0, None)
-                    inter = w * h
-                    union = ((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1]))[:, None] + \
-                            ((g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1]))[None, :] - inter
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        iou = np.where(inter > 0, inter / union, 0.0)
-                    miou = iou.max(axis=1)
-                hit = cache[key] = (rows, miou)
-                # one live entry per (image, description): the entry under the image's previous stamp can never hit again
-                latest = self.__dict__.setdefault("_match_latest", {})
-                old = latest.get((int(dbidx), target_description))
-                if old is not None and old != key:
-                    cache.pop(old, None)
-                latest[(int(dbidx), target_description)] = key
-            rows_all.append(hit[0])
-            iou_all.append(hit[1])
         if not rows_all:
             return np.zeros(0, dtype=np.int64), np.zeros(0)
         return np.concatenate(rows_all), np.concatenate(iou_all)

@@ -140,20 +140,23 @@ class LabelPropagation:
         score buffer and select the top k distinct non-excluded images there.  Same results as fit_resident /
         prior_as_result + scores_to_index + DeviceIndex.topk(None, k, excluded); one host wait when the propagation is
         an incremental update.  -> (image positions, scores f32, best rows)"""
-        ids = np.ascontiguousarray(np.asarray(label_ids).reshape(-1), dtype=np.int64)
-        vals = np.ascontiguousarray(np.asarray(label_values).reshape(-1), dtype=np.float64)
+        ids = np.ascontiguousarray(label_ids, dtype=np.int64).reshape(-1)
+        vals = np.ascontiguousarray(label_values, dtype=np.float64).reshape(-1)
         assert ids.shape == vals.shape
         ex = None if excluded is None else np.ascontiguousarray(excluded, dtype=np.int64)
         n_ex = 0 if ex is None else ex.shape[0]
         k = int(k)
-        buf = self.__dict__.get("_round_out")
-        if buf is None or buf[0].shape[0] < k:
-            buf = self._round_out = (np.empty(k, dtype=np.int64), np.empty(k, dtype=np.float32), np.empty(k, dtype=np.int64))
-        imgs, scs, rows = buf
-        cnt, sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
-        _lib.call("ssw_labelprop_round", self._h, device_index._h, int(bool(propagate)), _p(ids), _p(vals), ids.shape[0],
-                  self.reg_lambda, float(self.epsilon), self.max_iter, int(bool(mask_labeled)), _p(ex) if n_ex else None, n_ex, k,
-                  _p(imgs), _p(scs), _p(rows), ctypes.byref(cnt), ctypes.byref(sweeps), ctypes.byref(conv))
+        st = self.__dict__.get("_round_out")
+        if st is None or st[0].shape[0] < k:  # outputs and their addresses, made once (ndarray.ctypes costs ~1.5 us an access)
+            outs = (np.empty(k, dtype=np.int64), np.empty(k, dtype=np.float32), np.empty(k, dtype=np.int64))
+            cnt, sweeps, conv = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+            st = self._round_out = outs + (cnt, sweeps, conv, tuple(ctypes.c_void_p(a.ctypes.data) for a in outs),
+                                           (ctypes.byref(cnt), ctypes.byref(sweeps), ctypes.byref(conv)))
+        imgs, scs, rows, cnt, sweeps, conv, out_ptrs, refs = st
+        addr = lambda a: ctypes.c_void_p(a.__array_interface__["data"][0])  # noqa: E731
+        _lib.call("ssw_labelprop_round", self._h, device_index._h, int(bool(propagate)), addr(ids), addr(vals), ids.shape[0],
+                  self.reg_lambda, float(self.epsilon), self.max_iter, int(bool(mask_labeled)), addr(ex) if n_ex else None, n_ex, k,
+                  out_ptrs[0], out_ptrs[1], out_ptrs[2], refs[0], refs[1], refs[2])
         if propagate:
             self.last_sweeps, self.last_converged = sweeps.value, bool(conv.value)
             if not self.last_converged:

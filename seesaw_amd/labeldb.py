@@ -21,6 +21,7 @@ class LabelDB:
         self.ldata: Dict[int, Optional[List[Box]]] = {}
         self.stamp: Dict[int, int] = {}  # dbidx -> serial number of its latest put(): a cheap "did this image's labels change"
         self._serial = 0
+        self.changes: List[int] = []     # the dbidx of every put() that changed something, in order (entry i has serial i + 1)
 
     def put(self, dbidx: int, boxes: Optional[List[Box]]):
         dbidx = int(dbidx)
@@ -31,6 +32,7 @@ class LabelDB:
         if not unchanged:
             self._serial += 1
             self.stamp[dbidx] = self._serial
+            self.changes.append(dbidx)
 
     def get_seen(self) -> BitMap:
         return BitMap(self.ldata.keys())

@@ -74,7 +74,8 @@ class PseudoLR(PointBased):
             # and order (tests: the reference's pseudo_lr sessions)
             if drawn is None:
                 drawn = draw_unlabelled(model, self.options["sample_size"], device=lp.device)
-            lab = np.fromiter(sorted(model._label_map), dtype=np.int64, count=len(model._label_map))
+            lab = model._sorted_label_ids() if hasattr(model, "_sorted_label_ids") else \
+                np.fromiter(sorted(model._label_map), dtype=np.int64, count=len(model._label_map))
             scorer.fit(None, None, None, index=dev,
                        pseudo=(lp.device_scores_ptr(), lab, model.labels[lab], drawn, float(self.real_sample_weight)))
         else:

@@ -41,7 +41,8 @@ def makeXy_rows(lr, sample_size, drawn=None):
     has made the draw already (draw_unlabelled)."""
     label_map = getattr(lr, "_label_map", None)
     if label_map is not None:
-        rows = np.fromiter(sorted(label_map), dtype=np.int64, count=len(label_map))  # == nonzero(is_labeled > 0)
+        rows = lr._sorted_label_ids() if hasattr(lr, "_sorted_label_ids") else \
+            np.fromiter(sorted(label_map), dtype=np.int64, count=len(label_map))  # == nonzero(is_labeled > 0)
         y = lr.labels[rows]
         if drawn is None:
             # a ranker whose scores live on a GPU lends it to the draw's walk through the swaps (nprand.py)

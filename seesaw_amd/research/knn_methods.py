@@ -64,23 +64,40 @@ class BaseLabelPropagationRanker:
         self.propagate_now()
 
     def update_labels(self, idxs, labels):
-        """the bookkeeping half of update(): record the labels (no propagation yet)"""
+        """the bookkeeping half of update(): record the labels (no propagation yet).  The loops hand over the WHOLE
+        labelled set every round (getXy); only the entries that are new or carry another value touch the map."""
         idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
         labels = np.asarray(labels, dtype=np.float64).reshape(-1)
-        # np.isclose(label, 0) or np.isclose(label, 1) (atol 1e-8, rtol 1e-5) for the whole batch at once
-        assert np.all((np.abs(labels) <= 1e-8) | (np.abs(labels - 1.0) <= 1e-8 + 1e-5))
+        # np.isclose(label, 0) or np.isclose(label, 1) (atol 1e-8, rtol 1e-5) for the whole batch at once (exact 0 / 1 first)
+        assert ((labels == 0) | (labels == 1)).all() or \
+            np.all((np.abs(labels) <= 1e-8) | (np.abs(labels - 1.0) <= 1e-8 + 1e-5))
+        was_new = self.is_labeled[idxs] == 0
+        changed = was_new | (self.labels[idxs] != labels)
         self.labels[idxs] = labels  # (a repeated id keeps its last label, as the per-item loop did)
         self.is_labeled[idxs] = 1
-        self._label_map.update(zip(idxs.tolist(), labels.tolist()))
-        self._labels_stamp = getattr(self, "_labels_stamp", 0) + 1  # invalidates what was derived from the map
+        if changed.any():
+            ci = idxs[changed]
+            self._label_map.update(zip(ci.tolist(), self.labels[ci].tolist()))  # the values as assigned: last one wins
+            if was_new.any():  # the labelled ids, ascending (== sorted(_label_map) == nonzero(is_labeled))
+                self._sorted_ids = np.union1d(self._sorted_label_ids(), idxs[was_new])
+            self._labels_stamp = getattr(self, "_labels_stamp", 0) + 1  # invalidates what was derived from the labels
+
+    def _sorted_label_ids(self) -> np.ndarray:
+        ids = getattr(self, "_sorted_ids", None)
+        if ids is None or ids.shape[0] != len(self._label_map):  # (somebody wrote the map directly)
+            ids = self._sorted_ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))
+        return ids
+
+    def _refresh_has_negative(self) -> bool:
+        stamp = getattr(self, "_labels_stamp", 0)
+        if getattr(self, "_neg_stamp", None) != stamp:  # once per label change, not once per call
+            self._has_negative = bool((self.labels[self._sorted_label_ids()] == 0).any())
+            self._neg_stamp = stamp
+        return self._has_negative
 
     def propagate_now(self):
         """the other half: propagate the recorded labels (PseudoLR runs this beside its pseudo-label draw)"""
-        stamp = getattr(self, "_labels_stamp", 0)
-        if getattr(self, "_neg_stamp", None) != stamp:  # once per label update, not once per call
-            self._has_negative = any(v == 0 for v in self._label_map.values())
-            self._neg_stamp = stamp
-        has_negative = self._has_negative
+        has_negative = self._refresh_has_negative()
         if has_negative:  # the reference skips propagation until a negative label exists
             print(" propagating")
             self._current_scores = self._propagate(self.prior_scores)
@@ -120,7 +137,7 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
             self._no_negatives_yet()
 
     def _propagate(self, scores):
-        ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))  # == nonzero(is_labeled)
+        ids = self._sorted_label_ids()  # == nonzero(is_labeled)
         vals = self.labels.reshape(-1)[ids]
         if scores is self.prior_scores and self.lp._prior_installed and self.lp.reg_values is self.prior_scores:
             # the loop's case (update(): start == prior): nothing but the labels crosses PCIe; the f64 scores
@@ -145,11 +162,8 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
         Follows update()'s rule: no propagation before a negative label exists -- the prior ranks.
         -> (image positions, scores, best rows); the propagated scores stay on the device as after update()."""
         self.update_labels(idxs, labels)
-        stamp = self._labels_stamp
-        if getattr(self, "_neg_stamp", None) != stamp:
-            self._has_negative = any(v == 0 for v in self._label_map.values())
-            self._neg_stamp = stamp
-        ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))
+        self._refresh_has_negative()
+        ids = self._sorted_label_ids()
         if self._has_negative:
             print(" propagating")
             vals = self.labels.reshape(-1)[ids]
@@ -167,8 +181,7 @@ class LabelPropagationRanker2(BaseLabelPropagationRanker):
         # (set_prior): it becomes the resident result with the labelled nodes marked, so these rounds select and
         # re-score on the device like the later ones instead of uploading 12 MB of scores per round
         if self.lp._prior_installed and self.lp.reg_values is self.prior_scores:
-            ids = np.fromiter(sorted(self._label_map), dtype=np.int64, count=len(self._label_map))
-            self.lp.prior_as_result(ids)
+            self.lp.prior_as_result(self._sorted_label_ids())
             self._resident = True
             self._current_scores = None
 
