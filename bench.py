@@ -294,8 +294,38 @@ def feedback_loop_extras(device: int, full_images: int, with_cpu: bool = True, c
                     dev.profile(True)
                     np.random.seed(0)
                     with PhaseTimers() as ph:
-                        gp = benchmark_loop(session=ret["session"], box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
+                        # every round of this session stamped (name what the slowest round spends): time inside
+                        # session.next() / session.refine() and what the wrapped entry points took of it, round by round
+                        sess, per_round, mark = ret["session"], [], {}
+                        s_next, s_refine = sess.next, sess.refine
+
+                        def next_stamped(*a, **k):
+                            mark.clear()
+                            mark.update(t0=time.perf_counter(), snap=dict(ph.t))
+                            try:
+                                return s_next(*a, **k)
+                            finally:
+                                mark["next_ms"] = 1e3 * (time.perf_counter() - mark["t0"])
+
+                        def refine_stamped(*a, **k):
+                            t1 = time.perf_counter()
+                            try:
+                                return s_refine(*a, **k)
+                            finally:
+                                t2 = time.perf_counter()
+                                row = {"next_ms": mark.get("next_ms"), "bookkeeping_ms": 1e3 * (t1 - mark["t0"]) - mark.get("next_ms", 0.0),
+                                       "refine_ms": 1e3 * (t2 - t1)}
+                                row.update({k2 + "_ms": 1e3 * (ph.t[k2] - mark["snap"][k2]) for k2 in ph.t})
+                                per_round.append({k2: round(v, 4) for k2, v in row.items()})
+                        sess.next, sess.refine = next_stamped, refine_stamped
+                        gp = benchmark_loop(session=sess, box_data=boxes, subset=BitMap(ds.file_meta.index.values), b=b, p=p)
                     res[name]["phases_ms"] = ph.per_iteration_ms(dev, gp["latencies"])
+                    lat_ms = [round(1e3 * float(v), 4) for v in gp["latencies"]]
+                    slow = int(np.argmax(lat_ms)) if lat_ms else 0
+                    res[name]["rounds"] = {"latency_ms": lat_ms, "per_round": per_round, "slowest_round": slow + 1,
+                                           "slowest_round_phases": per_round[slow] if slow < len(per_round) else None,
+                                           "note": "the phase session's rounds (wrapped entry points): topk_call = scan + selection + fetch, "
+                                                   "label_prop = the graph handle's calls (the fused round includes its selection)"}
                     dev.profile(False)
                 if not with_cpu or name not in cpu_legs:
                     continue
@@ -863,6 +893,7 @@ def compact_line(full: dict) -> str:
             if short == "c5":
                 put(nm + "_ms_median", v.get("hip_ms_per_iter_median"))
                 put(nm + "_ms_slowest", v.get("hip_ms_slowest_iter"))
+                put(nm + "_slowest_round", _get(v, "rounds", "slowest_round"))
                 put(nm + "_identical_prefix", _get(v, "sequence_check", "identical_prefix"))
                 ph = v.get("phases_ms") or {}
                 for k_src, k_dst in (("label_prop", "label_prop_ms"), ("fit", "fit_ms"), ("sample_draw", "draw_ms"), ("host_other", "host_ms")):
